@@ -1,0 +1,120 @@
+"""Model hyper-parameters of the shipped CDSegNet configs, as data.
+
+Values restate configs/{scannet,scannet200,nuscenes}/CDSegNet.py:15-138 of the
+reference (the ``model = dict(...)`` block); only the keys the single-step
+inference path reads are kept, plus the ones the constructors must accept.
+"""
+import copy
+
+_BACKBONE = dict(
+    type="PT-v3m1",
+    c_in_channels=6,
+    n_in_channels=6,
+    order=("z", "z-trans", "hilbert", "hilbert-trans"),
+    c_stride=(4, 4),
+    c_enc_depths=(2, 2, 2),
+    c_enc_channels=(32, 64, 128),
+    c_enc_num_head=(2, 4, 8),
+    c_enc_patch_size=(1024, 1024, 1024),
+    c_dec_depths=(2, 2),
+    c_dec_channels=(64, 64),
+    c_dec_num_head=(4, 4),
+    c_dec_patch_size=(1024, 1024),
+    n_stride=(2, 2, 2, 2),
+    n_enc_depths=(2, 2, 2, 6, 6),
+    n_enc_channels=(32, 64, 128, 256, 512),
+    n_enc_num_head=(2, 4, 8, 16, 32),
+    n_enc_patch_size=(1024, 1024, 1024, 1024, 1024),
+    n_dec_depths=(2, 2, 2, 2),
+    n_dec_channels=(64, 64, 128, 256),
+    n_dec_num_head=(4, 4, 8, 16),
+    n_dec_patch_size=(1024, 1024, 1024, 1024),
+    mlp_ratio=4,
+    qkv_bias=True,
+    qk_scale=None,
+    attn_drop=0.0,
+    proj_drop=0.0,
+    drop_path=0.3,
+    shuffle_orders=True,
+    pre_norm=True,
+    enable_rpe=False,
+    enable_flash=True,
+    upcast_attention=False,
+    upcast_softmax=False,
+    cls_mode=False,
+    pdnorm_bn=False,
+    pdnorm_ln=False,
+    pdnorm_decouple=True,
+    pdnorm_adaptive=False,
+    pdnorm_affine=True,
+    pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D"),
+    num_classes=20,
+    T_dim=128,
+    tm_bidirectional=False,
+    tm_feat=1.0,
+    tm_restomer=False,
+    condition=True,
+    skip_connection_mode="cat",
+    b_factor=[1.0, 1.0, 1.0, 1.0],
+    s_factor=[1.0, 1.0, 1.0, 1.0],
+    skip_connection_scale=True,
+    skip_connection_scale_i=False,
+)
+
+_MODEL = dict(
+    type="DefaultSegmentorV2",
+    backbone=_BACKBONE,
+    criteria=None,
+    loss_type="GLS",
+    task_num=2,
+    num_classes=20,
+    T=1000,
+    beta_start=0,
+    beta_end=1000,
+    noise_schedule="cosine",
+    T_dim=128,
+    dm=True,
+    dm_input="xt",
+    dm_target="noise",
+    dm_min_snr=None,
+    condition=True,
+    c_in_channels=6,
+)
+
+
+def cdsegnet_config(dataset="scannet"):
+    """``model`` dict of configs/<dataset>/CDSegNet.py (criteria dropped: the tester
+    calls inference(eval=False), test.py:216)."""
+    m = copy.deepcopy(_MODEL)
+    b = m["backbone"]
+    if dataset == "scannet":
+        pass
+    elif dataset == "scannet200":
+        m["num_classes"] = b["num_classes"] = 200
+    elif dataset == "nuscenes":
+        # configs/nuscenes/CDSegNet.py:25-30,42
+        m["num_classes"] = b["num_classes"] = 16
+        m["c_in_channels"] = b["c_in_channels"] = 4
+        b["n_in_channels"] = 4
+        m["beta_start"], m["beta_end"], m["noise_schedule"] = 0.001, 0.005, "linear"
+        b["pdnorm_conditions"] = ("nuScenes", "SemanticKITTI", "Waymo")
+    else:
+        raise KeyError(dataset)
+    return m
+
+
+def mini_config(num_classes=13, in_channels=6, T_dim=64):
+    """Same architecture, reduced widths/depths (head dim stays 16): the end-to-end
+    golden fixture that fits in a few hundred KB."""
+    m = copy.deepcopy(_MODEL)
+    b = m["backbone"]
+    b.update(
+        c_in_channels=in_channels, n_in_channels=in_channels,
+        c_enc_depths=(1, 2, 1), c_enc_channels=(16, 32, 32), c_enc_num_head=(1, 2, 2),
+        c_dec_depths=(1, 1), c_dec_channels=(32, 32), c_dec_num_head=(2, 2),
+        n_enc_depths=(1, 1, 2, 1, 5), n_enc_channels=(16, 32, 32, 64, 64), n_enc_num_head=(1, 2, 2, 4, 4),
+        n_dec_depths=(1, 1, 1, 2), n_dec_channels=(32, 32, 32, 64), n_dec_num_head=(2, 2, 2, 4),
+        num_classes=num_classes, T_dim=T_dim,
+    )
+    m.update(num_classes=num_classes, T_dim=T_dim, c_in_channels=in_channels)
+    return m

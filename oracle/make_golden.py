@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON in the build container.
+
+Run from the repo root:  python oracle/make_golden.py
+Needs /root/reference (read-only) and therefore only works in the build container;
+the produced fixtures (data only: inputs, RNG draws, expected outputs) are committed
+and travel to the GPU box, the reference does not.
+
+The reference is imported with the stand-ins of oracle/refshim (see its README for
+what that pins and what it does not) and with ``torch.Tensor.cuda`` = identity
+(default.py:68-72,393,400,402 hard-code ``.cuda()``).  ``enable_flash=False`` selects
+the reference's own materialised-softmax CPU branch (ptv3.py:264-280).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("CDSEG_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from cdsegnet_amd import configs, synth  # noqa: E402  (data generators only)
+from cdsegnet_amd.param_init import fill_state_dict  # noqa: E402
+
+
+def load_reference():
+    sys.path.insert(0, os.path.join(HERE, "refshim"))
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for name, sub in (("pointcept.models", "pointcept/models"),
+                      ("pointcept.models.point_prompt_training", "pointcept/models/point_prompt_training")):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, sub)]
+        sys.modules[name] = m
+    import pointcept  # noqa: F401
+    import pointcept.models.point_prompt_training.prompt_driven_normalization as pdn
+    sys.modules["pointcept.models.point_prompt_training"].PDNorm = pdn.PDNorm
+    import pointcept.models.point_transformer_v3.point_transformer_v3m1_base as ptv3
+    import pointcept.models.default as default
+    import pointcept.models.utils.structure as structure
+    import pointcept.utils.comm as comm
+    return types.SimpleNamespace(ptv3=ptv3, default=default, structure=structure, comm=comm)
+
+
+class DrawRecorder:
+    """Record what the reference draws from the CPU generator, in order."""
+
+    def __enter__(self):
+        self.normal, self.randperm, self.randn_like = torch.normal, torch.randperm, torch.randn_like
+        self.log = []
+        rec = self
+
+        def normal(*a, **k):
+            r = rec.normal(*a, **k)
+            rec.log.append(("normal", r.clone()))
+            return r
+
+        def randperm(*a, **k):
+            r = rec.randperm(*a, **k)
+            rec.log.append(("randperm", r.clone()))
+            return r
+
+        def randn_like(*a, **k):
+            r = rec.randn_like(*a, **k)
+            rec.log.append(("randn_like", r.clone()))
+            return r
+
+        torch.normal, torch.randperm, torch.randn_like = normal, randperm, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.normal, torch.randperm, torch.randn_like = self.normal, self.randperm, self.randn_like
+
+
+def ref_model(ref, cfg, seed=0):
+    cfg = json.loads(json.dumps(cfg))  # deep copy, tuples -> lists is fine for the ctor
+    cfg["backbone"]["enable_flash"] = False
+    cfg["backbone"]["order"] = tuple(cfg["backbone"]["order"])
+    mtype = cfg.pop("type")
+    assert mtype == "DefaultSegmentorV2"
+    model = ref.default.DefaultSegmentorV2(**cfg)
+    sd = model.state_dict()
+    new = fill_state_dict(sd, seed=seed)
+    model.load_state_dict(new, strict=True)
+    model.eval()
+    return model, new
+
+
+def to_torch_input(scene):
+    return dict(
+        coord=torch.from_numpy(scene["coord"]),
+        grid_coord=torch.from_numpy(scene["grid_coord"]),
+        feat=torch.from_numpy(scene["feat"]),
+        offset=torch.from_numpy(scene["offset"]),
+    )
+
+
+# --------------------------------------------------------------------- fixtures
+def _random_cloud(seed, sizes, extent):
+    """Edge case: maximum depth (16 bits per axis) and three batch elements of ragged size."""
+    rng = np.random.default_rng(seed)
+    scenes = []
+    for n in sizes:
+        g = rng.integers(0, extent, (n * 2, 3))
+        g = np.unique(g, axis=0)[:n]
+        g = g[rng.permutation(len(g))]
+        g[0] = extent - 1
+        scenes.append(dict(coord=(g * 0.01).astype(np.float32), grid_coord=g.astype(np.int64),
+                           feat=rng.normal(size=(len(g), 6)).astype(np.float32),
+                           segment=np.zeros(len(g), dtype=np.int64)))
+    return synth.collate(scenes)
+
+
+def gen_serialization(ref):
+    """Point.serialization before the shuffle + padding plans + pooling structure."""
+    clouds = {
+        "tiny64": synth.room_scene(11, 64),
+        "room1500": synth.room_scene(12, 1500),
+        "batch2": synth.collate([synth.room_scene(13, 2300), synth.room_scene(14, 1200)]),
+        "lidar5000": synth.lidar_scene(15, 5000),
+        "rand16": _random_cloud(16, (700, 1030, 270), 65536),
+    }
+    orders = ("z", "z-trans", "hilbert", "hilbert-trans")
+    for name, sc in clouds.items():
+        p = ref.structure.Point(dict(coord=torch.from_numpy(sc["coord"]),
+                                     grid_coord=torch.from_numpy(sc["grid_coord"]),
+                                     offset=torch.from_numpy(sc["offset"]),
+                                     feat=torch.from_numpy(sc["feat"])))
+        p.serialization(order=orders, shuffle_orders=False)
+        out = dict(grid_coord=sc["grid_coord"], offset=sc["offset"], coord=sc["coord"], feat=sc["feat"],
+                   batch=p.batch.numpy(), depth=np.int64(p.serialized_depth),
+                   code=p.serialized_code.numpy(), order=p.serialized_order.numpy(),
+                   inverse=p.serialized_inverse.numpy())
+        # padding plans through the reference's own SerializedAttention helper
+        for K in (4, 16, 1024):
+            att = ref.ptv3.SerializedAttention(channels=16, num_heads=1, patch_size=K, enable_flash=False,
+                                               upcast_attention=False, upcast_softmax=False)
+            att.patch_size = K  # the non-flash ctor leaves 0 and sets it in forward
+            q = ref.structure.Point(dict(offset=torch.from_numpy(sc["offset"])))
+            pad, unpad, cu = att.get_padding_and_inverse(q)
+            out[f"pad_K{K}"], out[f"unpad_K{K}"], out[f"cu_K{K}"] = pad.numpy(), unpad.numpy(), cu.numpy()
+        # pooling structure through the reference's own SerializedPooling (no shuffle)
+        for stride in (2, 4):
+            bn = lambda c: torch.nn.BatchNorm1d(c, eps=1e-3)  # noqa: E731
+            pool = ref.ptv3.SerializedPooling(sc["feat"].shape[1], 8, stride=stride, norm_layer=bn, act_layer=torch.nn.GELU,
+                                              shuffle_orders=False)
+            sdp = fill_state_dict(pool.state_dict(), seed=3)
+            pool.load_state_dict(sdp)
+            pool.eval()
+            p.sparsify()
+            with torch.no_grad():
+                q = pool(p)
+            out[f"pool{stride}_cluster"] = q.pooling_inverse.numpy()
+            out[f"pool{stride}_grid"] = q.grid_coord.numpy()
+            out[f"pool{stride}_batch"] = q.batch.numpy()
+            out[f"pool{stride}_code"] = q.serialized_code.numpy()
+            out[f"pool{stride}_order"] = q.serialized_order.numpy()
+            out[f"pool{stride}_inverse"] = q.serialized_inverse.numpy()
+            out[f"pool{stride}_feat"] = q.feat.numpy()
+            out[f"pool{stride}_coord"] = q.coord.numpy()
+            for k, v in sdp.items():
+                out[f"pool{stride}_sd.{k}"] = v.numpy()
+        np.savez_compressed(os.path.join(OUT, f"serialization_{name}.npz"), **out)
+        print("serialization", name, sc["coord"].shape, "depth", int(p.serialized_depth))
+    # known answers + calc_t_emb row
+    g = torch.tensor([[1, 2, 3], [7, 0, 5], [300, 2, 9]])
+    from pointcept.models.utils.serialization import encode
+    ka = {o: encode(g, None, 9, o).numpy() for o in orders}
+    ts = 999 * torch.ones((3, 1), dtype=torch.int64)
+    ka["t_emb_999_128"] = ref.comm.calc_t_emb(ts, 128).numpy()
+    ka["t_emb_999_64"] = ref.comm.calc_t_emb(ts, 64).numpy()
+    ts = torch.tensor([[0], [1], [500], [999]], dtype=torch.int64)
+    ka["t_emb_multi_128"] = ref.comm.calc_t_emb(ts, 128).numpy()
+    ka["grid"] = g.numpy()
+    np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **ka)
+
+
+def run_e2e(ref, cfg, scene, seed, sd_seed, tag, keep_sd, noise_level=None, capture=()):
+    model, sd = ref_model(ref, cfg, seed=sd_seed)
+    inp = to_torch_input(scene)
+    feats = {}
+    hooks = []
+    for name in capture:
+        mod = dict(model.named_modules())[name]
+
+        def hook(m, i, o, name=name):
+            out = o[1] if isinstance(o, tuple) else o
+            feats[name] = out.feat.detach().clone().numpy()
+
+        hooks.append(mod.register_forward_hook(hook))
+    torch.manual_seed(seed)
+    with DrawRecorder() as rec, torch.no_grad():
+        out = model.inference(inp, eval=False, noise_level=noise_level)
+    logits = out["seg_logits"].numpy()
+    for h in hooks:
+        h.remove()
+    kinds = [k for k, _ in rec.log]
+    expect = (["randn_like"] if noise_level is not None else []) + ["normal"] + ["randperm"] * 8
+    assert kinds == expect, kinds
+    fx = dict(coord=scene["coord"], grid_coord=scene["grid_coord"], feat=scene["feat"], offset=scene["offset"],
+              logits=logits, seed=np.int64(seed), sd_seed=np.int64(sd_seed),
+              noise=[v for k, v in rec.log if k == "normal"][0].numpy(),
+              perms=np.stack([v.numpy() for k, v in rec.log if k == "randperm"]),
+              cfg_json=np.array(json.dumps(cfg)))
+    if noise_level is not None:
+        fx["feat_noise"] = rec.log[0][1].numpy()
+        fx["noise_level"] = np.float64(noise_level)
+    for k, v in feats.items():
+        fx["trace." + k] = v
+    if keep_sd:
+        for k, v in sd.items():
+            fx["sd." + k] = v.numpy()
+    else:
+        # parameters are regenerated by name (cdsegnet_amd.param_init); keep a checksum to catch drift
+        fx["sd_checksum"] = np.float64(sum(float(v.double().abs().sum()) for v in sd.values()))
+        fx["sd_keys"] = np.array(list(sd.keys()))
+        fx["sd_shapes"] = np.array([json.dumps(list(v.shape)) for v in sd.values()])
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **fx)
+    print(tag, scene["coord"].shape, "logits", logits.shape, float(np.abs(logits).mean()),
+          "params", sum(v.numel() for v in sd.values()))
+    return model
+
+
+def gen_e2e(ref):
+    cap = ("backbone._n_embedding", "backbone._n_enc.enc0", "backbone._c_enc.enc2", "backbone._n_enc.enc4",
+           "backbone._tm_dec0", "backbone._n_dec.dec3", "backbone._n_dec.dec0")
+    # mini model, one scene (3 patches at stage 0, padded last patch; short single patches deeper)
+    run_e2e(ref, configs.mini_config(), synth.room_scene(21, 2600), 54421566, 1, "mini_e2e_room", False, capture=cap)
+    # mini model, batch of two scenes (both > 1024 points so non-flash K == 1024)
+    sc = synth.collate([synth.room_scene(22, 1500), synth.room_scene(23, 1100)])
+    run_e2e(ref, configs.mini_config(), sc, 7, 2, "mini_e2e_batch2", False, capture=cap)
+    # mini nuScenes-like (4-ch input, c target = feat)
+    run_e2e(ref, configs.mini_config(num_classes=16, in_channels=4, T_dim=32), synth.lidar_scene(24, 3000), 99, 3,
+            "mini_e2e_lidar", False, capture=cap)
+    # mini with the reference's feature-noise knob (default.py:373-374)
+    run_e2e(ref, configs.mini_config(), synth.room_scene(25, 1300), 5, 4, "mini_e2e_noise", False, noise_level=0.1)
+    # full width (101 M parameters are regenerated by name; only data is stored)
+    model = run_e2e(ref, configs.cdsegnet_config("scannet"), synth.room_scene(31, 8000), 54421566, 0,
+                    "full_e2e_8k", False, capture=("backbone._n_enc.enc4", "backbone._tm_dec0"))
+    schema = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_schema_scannet.json"), "w") as f:
+        json.dump(schema, f, indent=0)
+    for ds in ("scannet200", "nuscenes"):
+        cfg = configs.cdsegnet_config(ds)
+        cfg = json.loads(json.dumps(cfg))
+        cfg["backbone"]["enable_flash"] = False
+        cfg.pop("type")
+        m = ref.default.DefaultSegmentorV2(**cfg)
+        with open(os.path.join(OUT, f"state_dict_schema_{ds}.json"), "w") as f:
+            json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, f, indent=0)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    which = sys.argv[1:] or ["ser", "e2e"]
+    if "ser" in which:
+        gen_serialization(ref)
+    if "e2e" in which:
+        gen_e2e(ref)

@@ -1,0 +1,156 @@
+"""CPU: the oracle (our restatement) against golden vectors captured from the reference's own code."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+from oracle import serialization as S
+from tests.helpers import fixture_cfg, fixture_draws, fixture_input, fixture_state_dict, load_fixture
+
+CLOUDS = ["tiny64", "room1500", "batch2", "lidar5000", "rand16"]
+
+
+def test_known_answers():
+    ka = load_fixture("known_answers.npz")
+    g = ka["grid"]
+    for o in S.ORDERS:
+        assert np.array_equal(S.encode(g, None, 9, o), ka[o]), o
+    # SURVEY.md 8-a5 literal values
+    assert S.encode(g, None, 9, "z").tolist() == [29, 357, 67242769]
+    assert S.encode(g, None, 9, "hilbert-trans").tolist() == [38, 154, 64676955]
+
+
+def test_calc_t_emb():
+    ka = load_fixture("known_answers.npz")
+    ts = 999 * torch.ones((3, 1), dtype=torch.int64)
+    assert np.array_equal(OM.calc_t_emb(ts, 128).numpy(), ka["t_emb_999_128"])
+    assert np.array_equal(OM.calc_t_emb(ts, 64).numpy(), ka["t_emb_999_64"])
+    ts = torch.tensor([[0], [1], [500], [999]], dtype=torch.int64)
+    assert np.array_equal(OM.calc_t_emb(ts, 128).numpy(), ka["t_emb_multi_128"])
+
+
+@pytest.mark.parametrize("name", CLOUDS)
+def test_serialization_bit_exact(name):
+    fx = load_fixture(f"serialization_{name}.npz")
+    batch = S.offset2batch(fx["offset"])
+    assert np.array_equal(batch, fx["batch"])
+    code, order, inverse, depth = S.serialization(fx["grid_coord"], batch)
+    assert depth == int(fx["depth"])
+    assert np.array_equal(code, fx["code"])
+    assert np.array_equal(order, fx["order"])
+    assert np.array_equal(inverse, fx["inverse"])
+    # codes are unique (one point per voxel) => the sort has no ties to break
+    for k in range(4):
+        assert len(np.unique(code[k])) == code.shape[1]
+
+
+@pytest.mark.parametrize("name", CLOUDS)
+@pytest.mark.parametrize("K", [4, 16, 1024])
+def test_padding_plan(name, K):
+    fx = load_fixture(f"serialization_{name}.npz")
+    pad, unpad, cu = S.padding_plan(fx["offset"], K)
+    assert np.array_equal(pad, fx[f"pad_K{K}"])
+    assert np.array_equal(unpad, fx[f"unpad_K{K}"])
+    assert np.array_equal(cu, fx[f"cu_K{K}"])
+
+
+def test_padding_plan_survey_example():
+    # n=10, K=4 -> pad=[0..9,6,7], unpad=[0..9], cu=[0,4,8,12]
+    pad, unpad, cu = S.padding_plan([10], 4)
+    assert pad.tolist() == list(range(10)) + [6, 7]
+    assert unpad.tolist() == list(range(10))
+    assert cu.tolist() == [0, 4, 8, 12]
+
+
+@pytest.mark.parametrize("name", CLOUDS)
+@pytest.mark.parametrize("stride", [2, 4])
+def test_pooling_structure_and_values(name, stride):
+    fx = load_fixture(f"serialization_{name}.npz")
+    pd = {2: 1, 4: 2}[stride]
+    cluster, counts, indices, idx_ptr, head, code, order, inverse = S.pooling_structure(fx["code"], pd)
+    assert np.array_equal(cluster, fx[f"pool{stride}_cluster"])
+    assert np.array_equal(code, fx[f"pool{stride}_code"])
+    assert np.array_equal(order, fx[f"pool{stride}_order"])
+    assert np.array_equal(inverse, fx[f"pool{stride}_inverse"])
+    assert np.array_equal(fx["grid_coord"][head] >> pd, fx[f"pool{stride}_grid"])
+    assert np.array_equal(fx["batch"][head], fx[f"pool{stride}_batch"])
+    # float side of the pooling (Linear -> segment max -> BN -> GELU; segment mean of coord)
+    sd = {k[len(f"pool{stride}_sd."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(f"pool{stride}_sd.")}
+    sd = {"down." + k: v for k, v in sd.items()}
+    p = OM.make_point(torch.from_numpy(fx["coord"]), fx["grid_coord"], fx["offset"],
+                      torch.from_numpy(fx["feat"]))
+    p.code, p.order, p.inverse, p.depth = fx["code"], fx["order"], fx["inverse"], int(fx["depth"])
+    q = OM.pooling(p, sd, "down", stride, None, False)
+    assert np.allclose(q.feat.numpy(), fx[f"pool{stride}_feat"], atol=1e-5)
+    assert np.allclose(q.coord.numpy(), fx[f"pool{stride}_coord"], atol=1e-4)
+
+
+def test_subm_conv_matches_dense_conv3d():
+    """spconv semantics are unpinned by the reference; pin the oracle's convention to F.conv3d."""
+    rng = np.random.default_rng(0)
+    for k, cin, cout in ((3, 5, 7), (5, 3, 4)):
+        D = 9
+        occ = rng.random((2, D, D, D)) < 0.3
+        b, x, y, z = np.nonzero(occ)
+        grid = np.stack([x, y, z], 1)
+        feat = torch.from_numpy(rng.normal(size=(len(b), cin)).astype(np.float32))
+        w = torch.from_numpy(rng.normal(size=(cout, k, k, k, cin)).astype(np.float32))
+        bias = torch.from_numpy(rng.normal(size=(cout,)).astype(np.float32))
+        nbr = OM.subm_neighbors(grid, b, k)
+        out = OM.subm_conv3d(feat, nbr, w, bias)
+        dense = torch.zeros(2, cin, D, D, D)
+        dense[b, :, x, y, z] = feat
+        ref = torch.nn.functional.conv3d(dense, w.permute(0, 4, 1, 2, 3).contiguous(), bias, padding=k // 2)
+        ref = ref[b, :, x, y, z]
+        assert torch.allclose(out, ref, atol=1e-4), (k, float((out - ref).abs().max()))
+
+
+E2E = ["mini_e2e_room", "mini_e2e_batch2", "mini_e2e_lidar", "mini_e2e_noise"]
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_e2e_mini_matches_reference(name):
+    fx = load_fixture(name + ".npz")
+    cfg = fixture_cfg(fx)
+    sd = fixture_state_dict(fx)
+    trace = {}
+    nl = float(fx["noise_level"]) if "noise_level" in fx.files else None
+    # the fixtures come from the reference's CPU (non-flash) branch: K = min(min_b n_b, 1024)
+    logits = OM.inference(cfg["backbone"], sd, fixture_input(fx), fixture_draws(fx), T=cfg["T"],
+                          noise_level=nl, run_dead=True, trace=trace, flash_semantics=False).numpy()
+    err = np.abs(logits - fx["logits"]).max()
+    assert err < 2e-4, err
+    assert (logits.argmax(1) == fx["logits"].argmax(1)).mean() > 0.999
+    if "trace.backbone._n_enc.enc4" in fx.files:
+        assert np.abs(trace["n_enc4"].numpy() - fx["trace.backbone._n_enc.enc4"]).max() < 2e-4
+        assert np.abs(trace["n_fused"].numpy() - fx["trace.backbone._tm_dec0"]).max() < 2e-4
+    # the c-decoder / c-head are dead code in single-step inference
+    logits2 = OM.inference(cfg["backbone"], sd, fixture_input(fx), fixture_draws(fx), T=cfg["T"],
+                           noise_level=nl, run_dead=False, flash_semantics=False).numpy()
+    assert np.array_equal(logits, logits2)
+    if len(fx["offset"]) == 1:  # one batch element: flash and non-flash patching coincide
+        logits3 = OM.inference(cfg["backbone"], sd, fixture_input(fx), fixture_draws(fx), T=cfg["T"],
+                               noise_level=nl, flash_semantics=True).numpy()
+        assert np.array_equal(logits, logits3)
+
+
+def test_rng_replay_matches_reference_draws():
+    fx = load_fixture("mini_e2e_room.npz")
+    d = OM.draw_rng(int(fx["seed"]), fx["noise"].shape[0], fx["noise"].shape[1])
+    assert np.array_equal(d["noise"].numpy(), fx["noise"])
+    assert np.array_equal(np.stack(d["perms"]), fx["perms"])
+    fx = load_fixture("mini_e2e_noise.npz")
+    d = OM.draw_rng(int(fx["seed"]), fx["noise"].shape[0], fx["noise"].shape[1], noise_level_like=fx["feat"].shape)
+    assert np.array_equal(d["feat_noise"].numpy(), fx["feat_noise"])
+    assert np.array_equal(d["noise"].numpy(), fx["noise"])
+    assert np.array_equal(np.stack(d["perms"]), fx["perms"])
+
+
+def test_e2e_full_width_matches_reference():
+    fx = load_fixture("full_e2e_8k.npz")
+    cfg = fixture_cfg(fx)
+    sd = fixture_state_dict(fx)
+    logits = OM.inference(cfg["backbone"], sd, fixture_input(fx), fixture_draws(fx), T=cfg["T"]).numpy()
+    err = np.abs(logits - fx["logits"]).max()
+    assert err < 5e-4, err
+    assert (logits.argmax(1) == fx["logits"].argmax(1)).mean() > 0.999
