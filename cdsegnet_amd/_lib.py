@@ -1,0 +1,96 @@
+"""ctypes binding of libcdseg_hip.so (C ABI declared in include/cdseg.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this
+module raises.  (`python -m cdsegnet_amd.build` or `__graft_entry__.build()` builds it.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_long, c_size_t, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcdseg_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SWISH = 0, 1, 2
+ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
+ERRORS = {-1: "CDSEG_ERR_ARG", -2: "CDSEG_ERR_LAUNCH", -3: "CDSEG_ERR_WORKSPACE", -4: "CDSEG_ERR_UNSUPPORTED"}
+
+
+class CdsegError(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+        ("res", c_void_p), ("add_src", c_void_p), ("add_idx", c_void_p), ("nbr", c_void_p), ("out_idx", c_void_p),
+        ("out", c_void_p), ("out2", c_void_p),
+        ("M", c_long),
+        ("N", c_int), ("K", c_int), ("kvol", c_int),
+        ("lda", c_int), ("ldo", c_int), ("ldo2", c_int), ("ldres", c_int), ("ldadd", c_int),
+        ("a_dtype", c_int), ("compute_dtype", c_int), ("out_dtype", c_int), ("out2_dtype", c_int),
+        ("act", c_int), ("out2_pre_add", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/cdseg.h declares
+SIGNATURES = {
+    "cdseg_abi_version": (c_int, []),
+    "cdseg_build_info": (c_char_p, []),
+    "cdseg_grid_max": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "cdseg_offset2batch": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "cdseg_encode": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "cdseg_encode4": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "cdseg_sort_ws_bytes": (c_size_t, [c_long]),
+    "cdseg_sort_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_size_t, c_void_p]),
+    "cdseg_invert_perm": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "cdseg_widen_i32": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "cdseg_gather_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "cdseg_scatter_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "cdseg_gather_i32": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "cdseg_plan_gather_grid": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "cdseg_pool_level": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cdseg_pool_gather": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "cdseg_nbr_table": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "cdseg_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "cdseg_stem_conv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
+                                c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "cdseg_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
+                                c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
+    "cdseg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "cdseg_segment_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "cdseg_segment_mean": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
+    "cdseg_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cdseg_randn": (c_int, [c_void_p, c_long, c_uint64, c_uint64, c_void_p]),
+    "cdseg_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
+    "cdseg_axpy": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises CdsegError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CdsegError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension was not built. "
+            "Run `python -m cdsegnet_amd.build` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise CdsegError(f"{what} failed: {ERRORS.get(status, status)}")

@@ -1,0 +1,321 @@
+// Serialized window attention for CDSegNet / PTv3 on gfx950 (head dim 16, patch <= 1024).
+//
+// ref: pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py
+//      :246-296 SerializedAttention (flash_attn_varlen_qkvpacked_func :282-288, CPU branch :264-280)
+//      :988-1055 SerializedCrossAttention (flash_attn_varlen_kvpacked_func :1038-1047)
+//
+// One workgroup (4 waves) = one (patch, head) x one slice of its queries.
+//  * the gather by serialized order is fused into the K/V staging loads and the Q fragment
+//    loads (row indices come from the slot plan, cdseg_pad_plan); the scatter by the inverse
+//    order and the dropping of the padding duplicates are fused into the store;
+//  * the whole K tile and V^T tile of the patch-head live in LDS for the lifetime of the block
+//    (bf16: 32 KB + 36 KB -> 2 blocks / CU; f32: 64 KB + 65 KB);
+//  * scores are computed TRANSPOSED (S^T = K Q^T) so that a query's scores stay inside one lane
+//    pair: the row max / row sum need no cross-lane traffic in the key loop;
+//  * two passes over the keys (max, then exp + PV) instead of an online rescale: with d = 16
+//    the kernel is bound by the VALU/transcendental work per score, not by MFMA, and a second
+//    QK^T MFMA (32 cycles per 1024 scores) is cheaper than the rescale bookkeeping;
+//  * bf16: v_mfma_f32_32x32x16_bf16 for both products; the MFMA k-slot <-> key assignment of
+//    the PV product is chosen so the exponentiated scores feed it straight from the
+//    accumulator registers (no permute), V^T is read to match; a row of ones appended to V^T
+//    makes the softmax denominator fall out of the same MFMA (row 16 of the result);
+//  * f32 (the 1e-3 parity mode): v_mfma_f32_16x16x4_f32 for both products, exact fp32.
+// LDS layouts are bank-conflict free for every fragment read (tools/lds_conflicts.py).
+#include "common.h"
+
+namespace {
+
+struct AttnP {
+  const void* q;
+  const void* k;
+  const void* v;
+  const int32_t* q_gidx;
+  const int32_t* kv_gidx;
+  const int32_t* widx;
+  const int32_t* patch_start;
+  void* out;
+  int ldq, ldk, ldv, ldo;
+  int num_heads;
+  float scale_log2e;
+};
+
+constexpr int VT_STRIDE_BF16 = 2056;  // bytes per V^T row (1024 bf16 + 8 B pad -> conflict-free b64 reads)
+constexpr int VT_ROWS_BF16 = 18;      // 16 head dims + ones row + zero row
+constexpr int KS_BYTES_BF16 = 1024 * 32;
+constexpr int SMEM_BF16 = KS_BYTES_BF16 + VT_ROWS_BF16 * VT_STRIDE_BF16;
+
+constexpr int VT_STRIDE_F32 = 4128;  // 1024 f32 + 32 B pad
+constexpr int KS_BYTES_F32 = 1024 * 64;
+constexpr int SMEM_F32 = KS_BYTES_F32 + 16 * VT_STRIDE_F32;
+
+// ------------------------------------------------------------------------------------ bf16
+__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vt = smem + KS_BYTES_BF16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int patch = blockIdx.x / p.num_heads;
+  const int head = blockIdx.x - patch * p.num_heads;
+  const int ps = p.patch_start[patch];
+  const int L = p.patch_start[patch + 1] - ps;
+  const int nkt = (L + 31) >> 5;  // 32-key tiles
+  const int Lp = nkt << 5;
+  const bf16_t* kb = (const bf16_t*)p.k + head * 16;
+  const bf16_t* vb = (const bf16_t*)p.v + head * 16;
+
+  // ---- stage K (row-major, 16-B halves swizzled) and V^T (+ ones row, zero row)
+  for (int s = tid; s < Lp; s += 256) {
+    uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
+    if (s < L) {
+      const long g = p.kv_gidx[ps + s];
+      const uint4* kr = reinterpret_cast<const uint4*>(kb + g * p.ldk);
+      const uint4* vr = reinterpret_cast<const uint4*>(vb + g * p.ldv);
+      k0 = kr[0]; k1 = kr[1];
+      v0 = vr[0]; v1 = vr[1];
+    }
+    const int sw = (s >> 3) & 1;
+    *reinterpret_cast<uint4*>(Ks + s * 32 + ((0 ^ sw) << 4)) = k0;
+    *reinterpret_cast<uint4*>(Ks + s * 32 + ((1 ^ sw) << 4)) = k1;
+    const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      *reinterpret_cast<uint16_t*>(Vt + (2 * d) * VT_STRIDE_BF16 + s * 2) = (uint16_t)(vw[d] & 0xffffu);
+      *reinterpret_cast<uint16_t*>(Vt + (2 * d + 1) * VT_STRIDE_BF16 + s * 2) = (uint16_t)(vw[d] >> 16);
+    }
+    *reinterpret_cast<uint16_t*>(Vt + 16 * VT_STRIDE_BF16 + s * 2) = (s < L) ? (uint16_t)0x3F80 : (uint16_t)0;
+    *reinterpret_cast<uint16_t*>(Vt + 17 * VT_STRIDE_BF16 + s * 2) = 0;
+  }
+  __syncthreads();
+
+  const int ql = lane & 31;  // query (B operand column) / key or head-dim row (A operand row)
+  const int h = lane >> 5;
+  const int vrow = ql < 17 ? ql : 17;
+  const char* vt_lane = Vt + vrow * VT_STRIDE_BF16 + h * 8;
+  const float c = p.scale_log2e;
+  const int nqt = (L + 31) >> 5;
+
+  for (int qt = blockIdx.y * 4 + wave; qt < nqt; qt += gridDim.y * 4) {
+    const int qslot = qt * 32 + ql;
+    const bool qvalid = qslot < L;
+    bf16x8_t qf = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qvalid) {
+      const long g = p.q_gidx[ps + qslot];
+      qf = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)p.q + g * p.ldq + head * 16 + h * 8);
+    }
+    // ---- pass 1: row max of S^T = K Q^T (lane (q,h) sees keys (r&3) + 8*(r>>2) + 4h of each tile)
+    float mloc = -INFINITY;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key = kt * 32 + ql;
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + key * 32 + ((h ^ ((key >> 3) & 1)) << 4));
+      f32x16_t s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, s, 0, 0, 0);
+      if (kt * 32 + 32 > L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[r] = -INFINITY;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+    }
+    const float m = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mc = m * c;
+    // ---- pass 2: P = exp2(S*c - m*c), O^T (+ row sums in row 16) += [V^T; 1; 0] P^T
+    f32x16_t o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key = kt * 32 + ql;
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + key * 32 + ((h ^ ((key >> 3) & 1)) << 4));
+      f32x16_t s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, s, 0, 0, 0);
+      float pr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r] * c - mc);
+      if (kt * 32 + 32 > L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) pr[r] = 0.f;
+      }
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        union { bf16x8_t v; uint32_t u[4]; } pf, vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
+        // k-slots 8h+j (j<4) <-> keys kbase + 4h + j ; (j>=4) <-> keys kbase + 8 + 4h + (j-4)
+        const char* vp = vt_lane + (kt * 32 + 16 * mf) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+        vf.u[0] = lo.x; vf.u[1] = lo.y; vf.u[2] = hi.x; vf.u[3] = hi.y;
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o, 0, 0, 0);
+      }
+    }
+    // ---- epilogue: O^T rows (r&3) + 8*(r>>2) + 4h; row 16 (lane h=0, r=8) is the denominator
+    const float lsum = __shfl(o[8], ql, 64);
+    const float inv = 1.0f / lsum;
+    if (qvalid) {
+      const int w = p.widx[ps + qslot];
+      if (w >= 0) {
+        bf16_t* orow = (bf16_t*)p.out + (long)w * p.ldo + head * 16 + 4 * h;
+        uint2 a, b;
+        a.x = pack_bf16x2(o[0] * inv, o[1] * inv);
+        a.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+        b.x = pack_bf16x2(o[4] * inv, o[5] * inv);
+        b.y = pack_bf16x2(o[6] * inv, o[7] * inv);
+        *reinterpret_cast<uint2*>(orow) = a;      // d = 4h .. 4h+3
+        *reinterpret_cast<uint2*>(orow + 8) = b;  // d = 8+4h .. 8+4h+3
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ f32
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vt = smem + KS_BYTES_F32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int patch = blockIdx.x / p.num_heads;
+  const int head = blockIdx.x - patch * p.num_heads;
+  const int ps = p.patch_start[patch];
+  const int L = p.patch_start[patch + 1] - ps;
+  const int nkt = (L + 15) >> 4;  // 16-key tiles
+  const int Lp = nkt << 4;
+  const float* kb = (const float*)p.k + head * 16;
+  const float* vb = (const float*)p.v + head * 16;
+
+  for (int s = tid; s < Lp; s += 256) {
+    uint4 kk[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kk[i] = vv[i] = make_uint4(0, 0, 0, 0);
+    if (s < L) {
+      const long g = p.kv_gidx[ps + s];
+      const uint4* kr = reinterpret_cast<const uint4*>(kb + g * p.ldk);
+      const uint4* vr = reinterpret_cast<const uint4*>(vb + g * p.ldv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { kk[i] = kr[i]; vv[i] = vr[i]; }
+    }
+    const int sw = (s >> 1) & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Ks + s * 64 + ((i ^ sw) << 4)) = kk[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint32_t*>(Vt + (4 * i + 0) * VT_STRIDE_F32 + s * 4) = vv[i].x;
+      *reinterpret_cast<uint32_t*>(Vt + (4 * i + 1) * VT_STRIDE_F32 + s * 4) = vv[i].y;
+      *reinterpret_cast<uint32_t*>(Vt + (4 * i + 2) * VT_STRIDE_F32 + s * 4) = vv[i].z;
+      *reinterpret_cast<uint32_t*>(Vt + (4 * i + 3) * VT_STRIDE_F32 + s * 4) = vv[i].w;
+    }
+  }
+  __syncthreads();
+
+  const int ql = lane & 15;
+  const int g4 = lane >> 4;
+  const float c = p.scale_log2e;
+  const int nqt = (L + 15) >> 4;
+
+  for (int qt = blockIdx.y * 4 + wave; qt < nqt; qt += gridDim.y * 4) {
+    const int qslot = qt * 16 + ql;
+    const bool qvalid = qslot < L;
+    f32x4_t qf = {0.f, 0.f, 0.f, 0.f};
+    if (qvalid) {
+      const long g = p.q_gidx[ps + qslot];
+      qf = *reinterpret_cast<const f32x4_t*>((const float*)p.q + g * p.ldq + head * 16 + 4 * g4);
+    }
+    // S^T tile (16 keys x 16 queries): k-slot g4 of step ss <-> head dim 4*g4 + ss.
+    // C layout: col = query = lane & 15, row = key offset = 4*g4 + r.
+    float mloc = -INFINITY;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key = kt * 16 + ql;
+      const f32x4_t kf = *reinterpret_cast<const f32x4_t*>(Ks + key * 64 + ((g4 ^ ((key >> 1) & 3)) << 4));
+      f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ss], qf[ss], s, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sv = s[r];
+        if (kt * 16 + 4 * g4 + r >= L) sv = -INFINITY;
+        mloc = fmaxf(mloc, sv);
+      }
+    }
+    float m = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mc = m * c;
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    float lloc = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key = kt * 16 + ql;
+      const f32x4_t kf = *reinterpret_cast<const f32x4_t*>(Ks + key * 64 + ((g4 ^ ((key >> 1) & 3)) << 4));
+      f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ss], qf[ss], s, 0, 0, 0);
+      // V^T fragment: row = head dim (lane & 15), keys kt*16 + 4*g4 + r
+      const f32x4_t vf = *reinterpret_cast<const f32x4_t*>(Vt + ql * VT_STRIDE_F32 + (kt * 16 + 4 * g4) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = __builtin_amdgcn_exp2f(s[r] * c - mc);
+        if (kt * 16 + 4 * g4 + r >= L) pv = 0.f;
+        lloc += pv;
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], pv, o, 0, 0, 0);
+      }
+    }
+    float l = lloc + __shfl_xor(lloc, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    // O^T C layout: col = query, row = head dim 4*g4 + r -> this lane owns O[q][4*g4 .. 4*g4+3]
+    if (qvalid) {
+      const int w = p.widx[ps + qslot];
+      if (w >= 0) {
+        float4 ov = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        *reinterpret_cast<float4*>((float*)p.out + (long)w * p.ldo + head * 16 + 4 * g4) = ov;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                               const int32_t* q_gidx, const int32_t* kv_gidx, const int32_t* widx,
+                               const int32_t* patch_start, int num_patches, int num_heads, int max_len, float scale,
+                               void* out, int ldo, int dtype, void* stream) {
+  if (num_patches <= 0 || num_heads <= 0) return CDSEG_OK;
+  if (max_len <= 0 || max_len > CDSEG_MAX_PATCH) return CDSEG_ERR_UNSUPPORTED;
+  const int esz = dtype == CDSEG_F32 ? 4 : 2;
+  // 16-byte alignment of every gathered row slice
+  if (((long)ldq * esz) & 15 || ((long)ldk * esz) & 15 || ((long)ldv * esz) & 15) return CDSEG_ERR_ARG;
+  if (dtype == CDSEG_F32 ? (ldo & 3) : (ldo & 3)) return CDSEG_ERR_ARG;
+  AttnP p;
+  p.q = q; p.k = k; p.v = v; p.q_gidx = q_gidx; p.kv_gidx = kv_gidx; p.widx = widx; p.patch_start = patch_start;
+  p.out = out; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.num_heads = num_heads;
+  p.scale_log2e = scale * 1.44269504088896340736f;
+  hipStream_t s = (hipStream_t)stream;
+  // split each patch-head's queries over enough blocks to fill 256 CUs several times over
+  const int tile = dtype == CDSEG_F32 ? 16 : 32;
+  const int nqt = (max_len + tile - 1) / tile;
+  int qsplit = (2048 + num_patches * num_heads - 1) / (num_patches * num_heads);
+  const int max_split = (nqt + 3) / 4;
+  if (qsplit > max_split) qsplit = max_split;
+  if (qsplit < 1) qsplit = 1;
+  if (qsplit > 8) qsplit = 8;
+  dim3 grid((unsigned)(num_patches * num_heads), (unsigned)qsplit), block(256);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BF16) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F32) !=
+            hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  if (dtype == CDSEG_BF16)
+    hipLaunchKernelGGL(attn_bf16_kernel, grid, block, SMEM_BF16, s, p);
+  else if (dtype == CDSEG_F32)
+    hipLaunchKernelGGL(attn_f32_kernel, grid, block, SMEM_F32, s, p);
+  else
+    return CDSEG_ERR_ARG;
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}

@@ -1,0 +1,66 @@
+// Shared device helpers for the CDSegNet hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cdseg.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits (storage type)
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA bf16 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+
+#define CDSEG_WAVE 64
+
+#define CDSEG_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return CDSEG_ERR_LAUNCH;            \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16 cast)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+  static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+  static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+// exact (erf) GELU, as torch.nn.GELU() default
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,427 @@
+// Integer side of the hot path: space-filling-curve codes, orders, pooling clusters,
+// sparse-conv neighbour tables, attention padding plans.  All HBM-bound index work:
+// coalesced loads/stores, no LDS needed; sorting/scanning uses rocPRIM device primitives.
+//
+// Reference behaviour restated (bit-exact, see tests/test_gpu_serialization.py):
+//   pointcept/models/utils/serialization/z_order.py:40-50,66-101   z-order key
+//   pointcept/models/utils/serialization/hilbert.py:91-198          Skilling Hilbert key
+//   pointcept/models/utils/serialization/default.py:8-24            order dispatch + batch bits
+//   pointcept/models/utils/structure.py:47-102                      Point.serialization
+//   .../point_transformer_v3m1_base.py:188-244                      get_padding_and_inverse
+//   .../point_transformer_v3m1_base.py:477-492                      pooling clusters
+#include "common.h"
+#include "curves.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+template <typename G, typename B>
+__global__ void encode_kernel(const G* __restrict__ grid, const B* __restrict__ batch, long n, int depth,
+                              int order_id, int64_t* __restrict__ code) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t x = (uint32_t)grid[3 * i + 0], y = (uint32_t)grid[3 * i + 1], z = (uint32_t)grid[3 * i + 2];
+  uint64_t k = curve_key(order_id, x, y, z, depth);
+  if (batch) k |= ((uint64_t)batch[i]) << (3 * depth);
+  code[i] = (int64_t)k;
+}
+
+// all four curves at once from an int32 grid (engine plan)
+__global__ void encode4_kernel(const int32_t* __restrict__ grid, const int32_t* __restrict__ batch, long n,
+                               int depth, int64_t* __restrict__ code /* (4, n) */) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t x = (uint32_t)grid[3 * i + 0], y = (uint32_t)grid[3 * i + 1], z = (uint32_t)grid[3 * i + 2];
+  const uint64_t b = ((uint64_t)batch[i]) << (3 * depth);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) code[(long)o * n + i] = (int64_t)(b | curve_key(o, x, y, z, depth));
+}
+
+template <typename G>
+__global__ void grid_max_kernel(const G* __restrict__ grid, long n3, unsigned long long* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  long long m = 0;
+  for (; i < n3; i += stride) {
+    long long v = (long long)grid[i];
+    m = v > m ? v : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    long long t = __shfl_xor(m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)m);
+}
+
+__global__ void offset2batch_kernel(const int64_t* __restrict__ offset, int nb, long n, int32_t* __restrict__ batch) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = nb - 1;  // first b with offset[b] > i
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (offset[mid] > i) hi = mid; else lo = mid + 1;
+  }
+  batch[i] = lo;
+}
+
+__global__ void iota_kernel(int32_t* __restrict__ v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (int32_t)i;
+}
+
+__global__ void invert_perm_kernel(const int32_t* __restrict__ perm, long n, int32_t* __restrict__ inv) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[perm[i]] = (int32_t)i;
+}
+
+__global__ void widen_kernel(const int32_t* __restrict__ src, long n, int64_t* __restrict__ dst) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// dst[i, :] = src[idx[i], :] for rows of `row_words` 32-bit words; idx < 0 -> zeros
+__global__ void gather_rows_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, long n_out,
+                                   int row_words, uint32_t* __restrict__ dst) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = n_out * row_words;
+  if (t >= total) return;
+  long r = t / row_words;
+  int c = (int)(t - r * row_words);
+  int s = idx[r];
+  dst[t] = s >= 0 ? src[(long)s * row_words + c] : 0u;
+}
+
+// dst[idx[i], :] = src[i, :]
+__global__ void scatter_rows_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, long n_in,
+                                    int row_words, uint32_t* __restrict__ dst) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = n_in * row_words;
+  if (t >= total) return;
+  long r = t / row_words;
+  int c = (int)(t - r * row_words);
+  int d = idx[r];
+  if (d >= 0) dst[(long)d * row_words + c] = src[t];
+}
+
+// stage-0 plan: sorted grid (int32) + batch from the sort permutation
+template <typename G>
+__global__ void gather_grid_kernel(const G* __restrict__ grid, const int32_t* __restrict__ perm,
+                                   const int64_t* __restrict__ zcode_sorted, long n, int depth,
+                                   int32_t* __restrict__ grid_out, int32_t* __restrict__ batch_out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long s = perm[i];
+  grid_out[3 * i + 0] = (int32_t)grid[3 * s + 0];
+  grid_out[3 * i + 1] = (int32_t)grid[3 * s + 1];
+  grid_out[3 * i + 2] = (int32_t)grid[3 * s + 2];
+  batch_out[i] = (int32_t)(((uint64_t)zcode_sorted[i]) >> (3 * depth));
+}
+
+// flags for one pooling level: a new cluster starts where the shifted z code changes
+__global__ void level_flag_kernel(const int64_t* __restrict__ zc, long n, int shift, int32_t* __restrict__ flag) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i == 0 || (zc[i] >> shift) != (zc[i - 1] >> shift)) ? 1 : 0;
+}
+
+// cluster = inclusive_scan(flag) - 1 ; seg_start[cluster] = i at run starts ; count = last + 1
+__global__ void level_finish_kernel(const int32_t* __restrict__ incl, const int32_t* __restrict__ flag, long n,
+                                    int32_t* __restrict__ cluster, int32_t* __restrict__ seg_start,
+                                    int32_t* __restrict__ count) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = incl[i] - 1;
+  cluster[i] = c;
+  if (flag[i]) seg_start[c] = (int32_t)i;
+  if (i == n - 1) {
+    seg_start[c + 1] = (int32_t)n;
+    *count = c + 1;
+  }
+}
+
+// pooled level arrays from the first fine point of every cluster
+__global__ void pool_gather_kernel(const int32_t* __restrict__ seg_start, long m, long n_fine, int pd,
+                                   const int32_t* __restrict__ grid_f, const int32_t* __restrict__ batch_f,
+                                   const int64_t* __restrict__ code_f /* (4,n_fine) */,
+                                   int32_t* __restrict__ grid_c, int32_t* __restrict__ batch_c,
+                                   int64_t* __restrict__ code_c /* (4,m) */) {
+  long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const long h = seg_start[j];
+  grid_c[3 * j + 0] = grid_f[3 * h + 0] >> pd;
+  grid_c[3 * j + 1] = grid_f[3 * h + 1] >> pd;
+  grid_c[3 * j + 2] = grid_f[3 * h + 2] >> pd;
+  batch_c[j] = batch_f[h];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) code_c[(long)o * m + j] = code_f[(long)o * n_fine + h] >> (3 * pd);
+}
+
+__global__ void gather_i32_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, long n,
+                                  int32_t* __restrict__ dst) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+// neighbour table by binary search in the sorted (batch | z-order) codes.
+// one thread per (point, offset); column a*k*k + b*k + c  <->  (dx,dy,dz) = (a-r, b-r, c-r)
+__global__ void nbr_table_kernel(const int64_t* __restrict__ zc, const int32_t* __restrict__ grid,
+                                 const int32_t* __restrict__ batch, long n, int depth, int ksize, int kmajor,
+                                 int32_t* __restrict__ nbr) {
+  const int kv = ksize * ksize * ksize;
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * kv) return;
+  const long i = t / kv;
+  const int o = (int)(t - i * kv);
+  const int r = ksize >> 1;
+  const int a = o / (ksize * ksize), b = (o / ksize) % ksize, c = o % ksize;
+  const int x = grid[3 * i + 0] + a - r, y = grid[3 * i + 1] + b - r, z = grid[3 * i + 2] + c - r;
+  const int lim = 1 << depth;
+  int res = -1;
+  if (o == kv / 2) {
+    res = (int)i;
+  } else if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+    const int64_t key = (int64_t)((((uint64_t)batch[i]) << (3 * depth)) | z_key((uint32_t)x, (uint32_t)y, (uint32_t)z, depth));
+    long lo = 0, hi = n;  // lower_bound
+    while (lo < hi) {
+      long mid = (lo + hi) >> 1;
+      if (zc[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n && zc[lo] == key) res = (int)lo;
+  }
+  nbr[kmajor ? (long)o * n + i : t] = res;
+}
+
+// attention slot plan (ptv3.py:188-244 in scatter form).  For padded slot p of batch element b:
+//   local < n_b  : rank = local                       (real slot, its output is kept)
+//   local >= n_b : rank = local - K                   (borrowed from the previous patch's tail)
+// gidx[p] = order[offs[b] + rank] (order == nullptr -> identity), widx[p] = real ? gidx[p] : -1
+__global__ void pad_plan_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ offs,
+                                const int32_t* __restrict__ offs_pad, int nb, int K, long n_pad,
+                                int32_t* __restrict__ gidx, int32_t* __restrict__ widx) {
+  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pad) return;
+  int lo = 0, hi = nb - 1;  // first b with offs_pad[b+1] > p
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (offs_pad[mid + 1] > p) hi = mid; else lo = mid + 1;
+  }
+  const int b = lo;
+  const int local = (int)(p - offs_pad[b]);
+  const int nbp = offs[b + 1] - offs[b];
+  const bool real = local < nbp;
+  const int rank = offs[b] + (real ? local : local - K);
+  const int g = order ? order[rank] : rank;
+  gidx[p] = g;
+  widx[p] = real ? g : -1;
+}
+
+inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+extern "C" {
+
+int cdseg_grid_max(const void* grid, int elem_bytes, long n3, int64_t* out_dev, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out_dev, 0, sizeof(int64_t), s) != hipSuccess) return CDSEG_ERR_LAUNCH;
+  if (n3 <= 0) return CDSEG_OK;
+  int blocks = (int)((n3 + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL(grid_max_kernel<int64_t>, dim3(blocks), dim3(256), 0, s, (const int64_t*)grid, n3,
+                       (unsigned long long*)out_dev);
+  else if (elem_bytes == 4)
+    hipLaunchKernelGGL(grid_max_kernel<int32_t>, dim3(blocks), dim3(256), 0, s, (const int32_t*)grid, n3,
+                       (unsigned long long*)out_dev);
+  else
+    return CDSEG_ERR_ARG;
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_offset2batch(const int64_t* offset, int nb, long n, int32_t* batch, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (nb <= 0) return CDSEG_ERR_ARG;
+  hipLaunchKernelGGL(offset2batch_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, offset, nb, n, batch);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_encode(const void* grid, int grid_elem_bytes, const void* batch, int batch_elem_bytes, long n, int depth,
+                 int order_id, int64_t* code, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (depth < 0 || depth > 16 || order_id < 0 || order_id > 3) return CDSEG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (batch == nullptr) batch_elem_bytes = 8;
+#define LAUNCH_ENC(G, B)                                                                                       \
+  hipLaunchKernelGGL((encode_kernel<G, B>), grid1d(n), dim3(256), 0, s, (const G*)grid, (const B*)batch, n, depth, \
+                     order_id, code)
+  if (grid_elem_bytes == 8 && batch_elem_bytes == 8) LAUNCH_ENC(int64_t, int64_t);
+  else if (grid_elem_bytes == 8 && batch_elem_bytes == 4) LAUNCH_ENC(int64_t, int32_t);
+  else if (grid_elem_bytes == 4 && batch_elem_bytes == 8) LAUNCH_ENC(int32_t, int64_t);
+  else if (grid_elem_bytes == 4 && batch_elem_bytes == 4) LAUNCH_ENC(int32_t, int32_t);
+  else return CDSEG_ERR_ARG;
+#undef LAUNCH_ENC
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_encode4(const int32_t* grid, const int32_t* batch, long n, int depth, int64_t* code4, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (depth < 0 || depth > 16) return CDSEG_ERR_ARG;
+  hipLaunchKernelGGL(encode4_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, grid, batch, n, depth, code4);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+size_t cdseg_sort_ws_bytes(long n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
+                            (int32_t*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0, false);
+  size_t scan_bytes = 0;
+  (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n,
+                          rocprim::plus<int32_t>(), (hipStream_t)0, false);
+  if (scan_bytes > bytes) bytes = scan_bytes;
+  // + room for an iota value array and a flag / scan pair used by the callers below
+  return bytes + 3 * (size_t)n * sizeof(int32_t) + 1024;
+}
+
+// keys are non-negative int64 codes; vals_in == nullptr -> iota.  Stable LSD radix sort (rocPRIM).
+int cdseg_sort_pairs(const int64_t* keys_in, int64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, long n,
+                     int end_bit, void* ws, size_t ws_bytes, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (end_bit <= 0 || end_bit > 64) end_bit = 64;
+  char* w = (char*)ws;
+  size_t need = cdseg_sort_ws_bytes(n);
+  if (ws_bytes < need) return CDSEG_ERR_WORKSPACE;
+  const int32_t* vin = vals_in;
+  size_t off = 0;
+  if (!vin) {
+    int32_t* io = (int32_t*)w;
+    hipLaunchKernelGGL(iota_kernel, grid1d(n), dim3(256), 0, s, io, n);
+    vin = io;
+    off = (((size_t)n * sizeof(int32_t)) + 255) & ~(size_t)255;
+  }
+  size_t tmp_bytes = ws_bytes - off;
+  hipError_t e = rocprim::radix_sort_pairs(w + off, tmp_bytes, (const uint64_t*)keys_in, (uint64_t*)keys_out, vin,
+                                           vals_out, (size_t)n, 0u, (unsigned)end_bit, s, false);
+  if (e != hipSuccess) return CDSEG_ERR_LAUNCH;
+  return CDSEG_OK;
+}
+
+int cdseg_invert_perm(const int32_t* perm, long n, int32_t* inv, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipLaunchKernelGGL(invert_perm_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, perm, n, inv);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_widen_i32(const int32_t* src, long n, int64_t* dst, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipLaunchKernelGGL(widen_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, src, n, dst);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_gather_rows(const void* src, const int32_t* idx, long n_out, int row_bytes, void* dst, void* stream) {
+  if (n_out <= 0) return CDSEG_OK;
+  if (row_bytes <= 0 || (row_bytes & 3)) return CDSEG_ERR_ARG;
+  const int rw = row_bytes / 4;
+  hipLaunchKernelGGL(gather_rows_kernel, grid1d(n_out * rw), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src,
+                     idx, n_out, rw, (uint32_t*)dst);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_scatter_rows(const void* src, const int32_t* idx, long n_in, int row_bytes, void* dst, void* stream) {
+  if (n_in <= 0) return CDSEG_OK;
+  if (row_bytes <= 0 || (row_bytes & 3)) return CDSEG_ERR_ARG;
+  const int rw = row_bytes / 4;
+  hipLaunchKernelGGL(scatter_rows_kernel, grid1d(n_in * rw), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src,
+                     idx, n_in, rw, (uint32_t*)dst);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_gather_i32(const int32_t* src, const int32_t* idx, long n, int32_t* dst, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipLaunchKernelGGL(gather_i32_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, src, idx, n, dst);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_plan_gather_grid(const void* grid, int grid_elem_bytes, const int32_t* perm, const int64_t* zcode_sorted,
+                           long n, int depth, int32_t* grid_out, int32_t* batch_out, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (grid_elem_bytes == 8)
+    hipLaunchKernelGGL(gather_grid_kernel<int64_t>, grid1d(n), dim3(256), 0, s, (const int64_t*)grid, perm,
+                       zcode_sorted, n, depth, grid_out, batch_out);
+  else if (grid_elem_bytes == 4)
+    hipLaunchKernelGGL(gather_grid_kernel<int32_t>, grid1d(n), dim3(256), 0, s, (const int32_t*)grid, perm,
+                       zcode_sorted, n, depth, grid_out, batch_out);
+  else
+    return CDSEG_ERR_ARG;
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// One pooling level over the z-sorted codes: cluster id per fine point, run starts, count.
+// shift = 3 * pooling_depth bits.  ws: >= cdseg_sort_ws_bytes(n).
+int cdseg_pool_level(const int64_t* zcode_sorted, long n, int shift, int32_t* cluster, int32_t* seg_start,
+                     int32_t* count_dev, void* ws, size_t ws_bytes, void* stream) {
+  if (n <= 0) return CDSEG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (ws_bytes < cdseg_sort_ws_bytes(n)) return CDSEG_ERR_WORKSPACE;
+  char* w = (char*)ws;
+  const size_t arr = (((size_t)n * sizeof(int32_t)) + 255) & ~(size_t)255;
+  int32_t* flag = (int32_t*)w;
+  int32_t* incl = (int32_t*)(w + arr);
+  char* tmp = w + 2 * arr;
+  size_t tmp_bytes = ws_bytes - 2 * arr;
+  hipLaunchKernelGGL(level_flag_kernel, grid1d(n), dim3(256), 0, s, zcode_sorted, n, shift, flag);
+  hipError_t e = rocprim::inclusive_scan(tmp, tmp_bytes, (const int32_t*)flag, incl, (size_t)n,
+                                         rocprim::plus<int32_t>(), s, false);
+  if (e != hipSuccess) return CDSEG_ERR_LAUNCH;
+  hipLaunchKernelGGL(level_finish_kernel, grid1d(n), dim3(256), 0, s, incl, flag, n, cluster, seg_start, count_dev);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling_depth, const int32_t* grid_f,
+                      const int32_t* batch_f, const int64_t* code4_f, int32_t* grid_c, int32_t* batch_c,
+                      int64_t* code4_c, void* stream) {
+  if (m <= 0) return CDSEG_OK;
+  hipLaunchKernelGGL(pool_gather_kernel, grid1d(m), dim3(256), 0, (hipStream_t)stream, seg_start, m, n_fine,
+                     pooling_depth, grid_f, batch_f, code4_f, grid_c, batch_c, code4_c);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
+                    int ksize, int kmajor, int32_t* nbr, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (ksize != 3 && ksize != 5) return CDSEG_ERR_ARG;
+  const long total = n * ksize * ksize * ksize;
+  hipLaunchKernelGGL(nbr_table_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid, batch, n,
+                     depth, ksize, kmajor, nbr);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_pad_plan(const int32_t* order, const int32_t* offs, const int32_t* offs_pad, int nb, int patch, long n_pad,
+                   int32_t* gidx, int32_t* widx, void* stream) {
+  if (n_pad <= 0) return CDSEG_OK;
+  if (nb <= 0 || patch <= 0) return CDSEG_ERR_ARG;
+  hipLaunchKernelGGL(pad_plan_kernel, grid1d(n_pad), dim3(256), 0, (hipStream_t)stream, order, offs, offs_pad, nb,
+                     patch, n_pad, gidx, widx);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+}  // extern "C"

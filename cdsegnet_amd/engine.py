@@ -1,0 +1,532 @@
+"""Single-step-inference engine: runs DefaultSegmentorV2.inference / PT-v3m1.forward
+(ref: pointcept/models/default.py:371-422, point_transformer_v3m1_base.py:1757-1815) on the
+HIP kernels of libcdseg_hip.so.
+
+MI355X-first data layout (not the reference's):
+  * every stage's points are PHYSICALLY stored in (batch | z-order) sorted order, so sparse-conv
+    neighbour gathers, pooling segments (contiguous runs) and un-pooling gathers are
+    memory-coherent; the other three curves are int32 rank->row maps used only by the attention
+    gather.  All ops are permutation-equivariant, the head scatters logits back to the caller's
+    order, so results equal the reference's;
+  * the c-branch (stride 4,4) visits the same voxel sets as n-branch stages 0/2/4, so both
+    branches share one set of "levels" (codes, orders, neighbour tables, padding plans);
+  * residual stream fp32; GEMM / attention operands in the compute dtype T (bf16 or fp32), with a
+    T-typed shadow copy `xc` written by the producing epilogue.  `xc` also reproduces the
+    reference's stale `sparse_conv_feat` after un-pooling (oracle/model.py: unpooling);
+  * the per-point timestep embedding collapses to one vector (t is uniform in SSI): a table row,
+    two GEMVs and one GEMV for all t_mlp's give a per-block bias (SURVEY.md finding 6);
+  * c-decoder / c-head are dead code in SSI and are skipped (SURVEY.md finding 5).
+Host<->device syncs: offset + grid max (depth), pooled point counts (one copy for all levels).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import CdsegError
+
+CURVES = ("z", "z-trans", "hilbert", "hilbert-trans")
+
+
+def _pooling_depth(stride):
+    return (math.ceil(stride) - 1).bit_length()
+
+
+class Level:
+    """One voxel resolution of the scene, points in (batch | z) sorted order."""
+
+    def __init__(self, cum, depth, n, grid, batch, code4, offs_host):
+        self.cum, self.depth, self.n = cum, depth, n
+        self.grid, self.batch, self.code4 = grid, batch, code4
+        self.offs_host = offs_host  # (B+1) python ints
+        self._order = {}
+        self._nbr = {}
+        self._pad = {}
+        self._slots = {}
+
+    def order(self, curve):
+        """rank -> physical row for a curve (None = identity for z)."""
+        if curve == 0:
+            return None
+        if curve not in self._order:
+            nb = len(self.offs_host) - 1
+            end_bit = min(64, 3 * self.depth + max(1, nb.bit_length()))
+            _, perm = ops.sort_pairs(self.code4[curve], None, end_bit=end_bit)
+            self._order[curve] = perm
+        return self._order[curve]
+
+    def nbr(self, ksize, kmajor=False):
+        key = (ksize, kmajor)
+        if key not in self._nbr:
+            self._nbr[key] = ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
+        return self._nbr[key]
+
+    def pad(self, patch_size, enable_flash):
+        """(K, n_pad, offs_dev, offs_pad_dev, patch_start_dev, max_len) - ref: ptv3.py:188-250."""
+        key = (patch_size, enable_flash)
+        if key not in self._pad:
+            counts = np.diff(np.asarray(self.offs_host, dtype=np.int64))
+            K = int(patch_size) if enable_flash else int(min(int(counts.min()), patch_size))
+            pad_counts = np.where(counts > K, (counts + K - 1) // K * K, counts)
+            offs_pad = np.concatenate([[0], np.cumsum(pad_counts)])
+            starts = []
+            for b in range(len(counts)):
+                starts.append(np.arange(offs_pad[b], offs_pad[b + 1], K))
+            patch_start = np.concatenate(starts + [offs_pad[-1:]]).astype(np.int32)
+            max_len = int(np.diff(patch_start).max())
+            dev = self.grid.device
+            self._pad[key] = (K, int(offs_pad[-1]),
+                              torch.tensor(np.asarray(self.offs_host, dtype=np.int32), device=dev),
+                              torch.tensor(offs_pad.astype(np.int32), device=dev),
+                              torch.tensor(patch_start, device=dev), max_len)
+        return self._pad[key]
+
+    def slots(self, curve, patch_size, enable_flash):
+        key = (curve, patch_size, enable_flash)
+        if key not in self._slots:
+            K, n_pad, offs, offs_pad, _, _ = self.pad(patch_size, enable_flash)
+            self._slots[key] = ops.pad_plan(self.order(curve), offs, offs_pad, K, n_pad)
+        return self._slots[key]
+
+
+class Plan:
+    def __init__(self):
+        self.levels = {}
+        self.links = {}
+
+    def link(self, a, b):
+        """fine level a -> coarse level b: (cluster (n_a) int32, seg_start (n_b + 1) int32)."""
+        if (a, b) not in self.links:
+            la, lb = self.levels[a], self.levels[b]
+            cluster, seg, _ = ops.pool_level(la.code4[0], 3 * (lb.cum - la.cum))
+            self.links[(a, b)] = (cluster, seg)
+        return self.links[(a, b)]
+
+
+class State:
+    """A branch's activations at one level."""
+
+    def __init__(self, level, x, xc, curves):
+        self.level, self.x, self.xc, self.curves = level, x, xc, curves
+        self.parent = None
+
+
+class Engine:
+    def __init__(self, model, precision="bf16"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(precision)
+        self.model, self.precision = model, precision
+        self.T = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.device = None
+        self.w = None
+        self.rng_offset = 0
+
+    # ------------------------------------------------------------------ weights
+    def prepare(self, device):
+        if self.w is not None and self.device == device:
+            return
+        self.device = device
+        T = self.T
+        w = {}
+
+        def f32(t):
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+        def lin(mod, pre):
+            w[pre + ".w"] = mod.weight.detach().to(device=device, dtype=T).contiguous()
+            w[pre + ".b"] = f32(mod.bias) if mod.bias is not None else None
+
+        def conv(mod, pre):
+            w[pre + ".w"] = mod.weight.detach().reshape(mod.weight.shape[0], -1).to(device=device, dtype=T).contiguous()
+            w[pre + ".b"] = f32(mod.bias) if mod.bias is not None else None
+
+        def ln(mod, pre):
+            w[pre + ".g"], w[pre + ".b"] = f32(mod.weight), f32(mod.bias)
+
+        def bn(mod, pre):  # eval BatchNorm1d folded to scale / shift (ref: eps=1e-3, ptv3.py:1440)
+            scale = mod.weight.detach().double() / torch.sqrt(mod.running_var.detach().double() + mod.eps)
+            shift = mod.bias.detach().double() - mod.running_mean.detach().double() * scale
+            w[pre + ".scale"], w[pre + ".shift"] = f32(scale), f32(shift)
+
+        def block(mod, pre):
+            conv(mod.cpe[0], pre + ".cpe0")
+            lin(mod.cpe[1], pre + ".cpe1")
+            ln(mod.cpe[2], pre + ".cpe2")
+            ln(mod.norm1[0], pre + ".norm1")
+            lin(mod.attn.qkv, pre + ".qkv")
+            lin(mod.attn.proj, pre + ".proj")
+            ln(mod.norm2[0], pre + ".norm2")
+            lin(mod.mlp[0].fc1, pre + ".fc1")
+            lin(mod.mlp[0].fc2, pre + ".fc2")
+
+        def stem(mod, pre):
+            cw = mod.stem.conv.weight.detach()  # (out, k,k,k, in) -> (kvol, in, out) fp32
+            w[pre + ".w"] = f32(cw.reshape(cw.shape[0], -1, cw.shape[-1]).permute(1, 2, 0))
+            bn(mod.stem.norm, pre + ".bn")
+
+        def pool(mod, pre):
+            lin(mod.proj, pre + ".proj")
+            bn(mod.norm[0], pre + ".bn")
+
+        def unpool(mod, pre):
+            lin(mod.proj[0], pre + ".proj")
+            bn(mod.proj[1], pre + ".proj_bn")
+            lin(mod.proj_skip[0], pre + ".skip")
+            bn(mod.proj_skip[1], pre + ".skip_bn")
+
+        bb = self.model.backbone
+        stem(bb._n_embedding, "n_emb")
+        for s in range(bb.n_num_stages):
+            enc = getattr(bb._n_enc, f"enc{s}")
+            if s > 0:
+                pool(enc.down, f"n_enc{s}.down")
+            for name, mod in enc._modules.items():
+                if name.startswith("block"):
+                    block(mod, f"n_enc{s}.{name}")
+        for s in range(bb.n_num_stages - 1):
+            dec = getattr(bb._n_dec, f"dec{s}")
+            unpool(dec.up, f"n_dec{s}.up")
+            for name, mod in dec._modules.items():
+                if name.startswith("block"):
+                    block(mod, f"n_dec{s}.{name}")
+        if isinstance(bb._n_head, torch.nn.Linear):
+            lin(bb._n_head, "n_head")
+        if bb.condition:
+            stem(bb._c_embedding, "c_emb")
+            tw, tb, toff = [], [], {}
+            off = 0
+            for s in range(bb.c_num_stages):
+                enc = getattr(bb._c_enc, f"enc{s}")
+                if s > 0:
+                    pool(enc.down, f"c_enc{s}.down")
+                for name, mod in enc._modules.items():
+                    if name.startswith("block"):
+                        block(mod, f"c_enc{s}.{name}")
+                        if bb.T_dim != -1:
+                            tw.append(f32(mod.t_mlp.weight))
+                            tb.append(f32(mod.t_mlp.bias))
+                            toff[f"c_enc{s}.{name}"] = (off, off + mod.channels)
+                            off += mod.channels
+            if bb.T_dim != -1:
+                w["t.fc1.w"], w["t.fc1.b"] = f32(bb.fc_t1.weight), f32(bb.fc_t1.bias)
+                w["t.fc2.w"], w["t.fc2.b"] = f32(bb.fc_t2.weight), f32(bb.fc_t2.bias)
+                w["t.mlp.w"], w["t.mlp.b"] = torch.cat(tw).contiguous(), torch.cat(tb).contiguous()
+                w["t.table"] = f32(self.model.t_emb_table)
+                self.t_slices = toff
+            cb = bb._tm_dec0.cross_block2
+            conv(cb.q_cpe[0], "x.q_cpe0"); lin(cb.q_cpe[1], "x.q_cpe1"); ln(cb.q_cpe[2], "x.q_cpe2")
+            conv(cb.kv_cpe[0], "x.kv_cpe0"); lin(cb.kv_cpe[1], "x.kv_cpe1"); ln(cb.kv_cpe[2], "x.kv_cpe2")
+            ln(cb.q_norm1[0], "x.q_norm1"); ln(cb.kv_norm1[0], "x.kv_norm1"); ln(cb.q_norm2[0], "x.q_norm2")
+            lin(cb.attn.q, "x.q"); lin(cb.attn.kv, "x.kv"); lin(cb.attn.proj, "x.proj")
+            lin(cb.mlp[0].fc1, "x.fc1"); lin(cb.mlp[0].fc2, "x.fc2")
+            if cb.tm_feat != 1.0:
+                c = cb.q_channels
+                w["x.feat_scale"] = torch.full((c,), cb.tm_feat, dtype=torch.float32, device=device)
+                w["x.feat_zero"] = torch.zeros(c, dtype=torch.float32, device=device)
+        self.w = w
+
+    # ------------------------------------------------------------------ plan
+    def build_plan(self, grid, offset_dev, offset_host, n):
+        bb = self.model.backbone
+        nb = len(offset_host)
+        depth = int(ops.grid_max(grid).item()).bit_length()
+        # same guards as the reference (structure.py:69,74)
+        assert depth * 3 + nb.bit_length() <= 63, "serialization code does not fit int64"
+        assert depth <= 16, "grid extent exceeds 2^16 voxels per axis"
+        end_bit = min(64, 3 * depth + max(1, nb.bit_length()))
+        batch = ops.offset2batch(offset_dev, n)
+        zc = ops.encode(grid, batch, depth, "z")
+        zs, perm0 = ops.sort_pairs(zc, None, end_bit=end_bit)
+        grid0, bat0 = ops.plan_gather_grid(grid, perm0, zs, depth)
+        code0 = ops.encode4(grid0, bat0, depth)
+
+        def cum_depths(strides):
+            cum, d = [0], depth
+            for s in strides:
+                pd = _pooling_depth(s)
+                if pd > d:  # ref: ptv3.py:466-467
+                    pd = 0
+                d -= pd
+                cum.append(cum[-1] + pd)
+            return cum
+
+        n_cum = cum_depths(bb.n_stride)
+        c_cum = cum_depths(bb.c_stride) if bb.condition else [0]
+        all_cum = sorted(set(n_cum + c_cum))
+        plan = Plan()
+        plan.perm0, plan.n_cum, plan.c_cum, plan.depth = perm0, n_cum, c_cum, depth
+        offs0 = [0] + [int(v) for v in offset_host]
+        plan.levels[0] = Level(0, depth, n, grid0, bat0, code0, offs0)
+        coarse = [c for c in all_cum if c > 0]
+        if coarse:
+            dev = grid.device
+            counts = torch.empty(len(coarse), dtype=torch.int32, device=dev)
+            last_idx = torch.tensor([v - 1 for v in offset_host], dtype=torch.int32, device=dev)
+            tmp, ends = [], []
+            for i, cum in enumerate(coarse):
+                cluster, seg, _ = ops.pool_level(zs, 3 * cum, count_out=counts[i:i + 1])
+                tmp.append((cluster, seg))
+                ends.append(ops.gather_i32(cluster, last_idx))
+            host = torch.cat([counts] + ends).cpu().tolist()  # the one sync for all pooled sizes
+            for i, cum in enumerate(coarse):
+                m = host[i]
+                e = host[len(coarse) + i * nb: len(coarse) + (i + 1) * nb]
+                g, b, c4 = ops.pool_gather(tmp[i][1], m, n, cum, grid0, bat0, code0)
+                plan.levels[cum] = Level(cum, depth - cum, m, g, b, c4, [0] + [v + 1 for v in e])
+                plan.links[(0, cum)] = (tmp[i][0], tmp[i][1])
+        return plan
+
+    # ------------------------------------------------------------------ layers
+    def _buf(self, rows, cols, dtype):
+        return torch.empty((rows, cols), dtype=dtype, device=self.device)
+
+    def _cpe(self, st, pre, xc, tbias=None):
+        """x += LN(Linear(SubMConv3d(xc)))  [+ t bias]   (ref: ptv3.py:401-411)."""
+        w, lv = self.w, st.level
+        c = st.x.shape[1]
+        y = self._buf(lv.n, c, self.T)
+        ops.gemm(xc, w[pre + "0.w"], y, bias=w[pre + "0.b"], nbr=lv.nbr(3), kvol=27)
+        y2 = self._buf(lv.n, c, torch.float32)
+        ops.gemm(y, w[pre + "1.w"], y2, bias=w[pre + "1.b"])
+        ops.layernorm(y2, w[pre + "2.g"], w[pre + "2.b"], st.x, res=st.x, colbias=tbias)
+
+    def _mlp(self, st, pre_norm, pre_fc, shadow=True):
+        w = self.w
+        n, c = st.x.shape
+        h = self._buf(n, c, self.T)
+        ops.layernorm(st.x, w[pre_norm + ".g"], w[pre_norm + ".b"], h)
+        hid = w[pre_fc + "1.w"].shape[0]
+        u = self._buf(n, hid, self.T)
+        ops.gemm(h, w[pre_fc + "1.w"], u, bias=w[pre_fc + "1.b"], act=ops.ACT_GELU)
+        if self.T == torch.float32:
+            ops.gemm(u, w[pre_fc + "2.w"], st.x, bias=w[pre_fc + "2.b"], res=st.x)
+            st.xc = st.x
+        else:
+            st.xc = self._buf(n, c, self.T)
+            ops.gemm(u, w[pre_fc + "2.w"], st.x, bias=w[pre_fc + "2.b"], res=st.x, out2=st.xc)
+
+    def run_block(self, st, mod, pre, tbias=None):
+        """ref: ptv3.py:399-428."""
+        w, lv = self.w, st.level
+        n, c = st.x.shape
+        self._cpe(st, pre + ".cpe", st.xc, tbias)
+        h = self._buf(n, c, self.T)
+        ops.layernorm(st.x, w[pre + ".norm1.g"], w[pre + ".norm1.b"], h)
+        qkv = self._buf(n, 3 * c, self.T)
+        ops.gemm(h, w[pre + ".qkv.w"], qkv, bias=w[pre + ".qkv.b"])
+        att = mod.attn
+        curve = st.curves[att.order_index]
+        gidx, widx = lv.slots(curve, att.patch_size, att.enable_flash)
+        _, _, _, _, patch_start, max_len = lv.pad(att.patch_size, att.enable_flash)
+        o = self._buf(n, c, self.T)
+        ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
+                      att.scale, o)
+        ops.gemm(o, w[pre + ".proj.w"], st.x, bias=w[pre + ".proj.b"], res=st.x)
+        self._mlp(st, pre + ".norm2", pre + ".fc")
+
+    def run_embedding(self, plan, feat_phys, pre, curves):
+        w, lv = self.w, plan.levels[0]
+        cout = w[pre + ".w"].shape[2]
+        x = self._buf(lv.n, cout, torch.float32)
+        xc = x if self.T == torch.float32 else self._buf(lv.n, cout, self.T)
+        ops.stem_conv(feat_phys, lv.nbr(5, kmajor=True), w[pre + ".w"], w[pre + ".bn.scale"], w[pre + ".bn.shift"], x,
+                      None if xc is x else xc)
+        return State(lv, x, xc, curves)
+
+    def run_pooling(self, plan, st, pre, cum_to, perm):
+        """ref: ptv3.py:464-555: Linear -> segment max -> BN -> GELU; orders re-shuffled."""
+        w = self.w
+        fine, coarse = st.level, plan.levels[cum_to]
+        _, seg = plan.link(fine.cum, cum_to)
+        cout = w[pre + ".proj.w"].shape[0]
+        y = self._buf(fine.n, cout, self.T)
+        ops.gemm(st.xc, w[pre + ".proj.w"], y, bias=w[pre + ".proj.b"])
+        x = self._buf(coarse.n, cout, torch.float32)
+        xc = x if self.T == torch.float32 else self._buf(coarse.n, cout, self.T)
+        ops.segment_max(y, seg, coarse.n, w[pre + ".bn.scale"], w[pre + ".bn.shift"], ops.ACT_GELU, x,
+                        None if xc is x else xc)
+        curves = st.curves if perm is None else [st.curves[int(j)] for j in perm]
+        out = State(coarse, x, xc, curves)
+        out.parent = st
+        return out
+
+    def run_unpooling(self, plan, st, pre):
+        """n-branch un-pooling, 'add' mode (ref: ptv3.py:597-630).  xc keeps the PRE-add skip
+        feature: the reference leaves sparse_conv_feat stale there and the next CPE conv reads it."""
+        w = self.w
+        parent = st.parent
+        fine, coarse = parent.level, st.level
+        cluster, _ = plan.link(fine.cum, coarse.cum)
+        cout = w[pre + ".proj.w"].shape[0]
+        child = self._buf(coarse.n, cout, torch.float32)
+        ops.gemm(st.xc, w[pre + ".proj.w"], child, bias=w[pre + ".proj.b"], scale=w[pre + ".proj_bn.scale"],
+                 shift=w[pre + ".proj_bn.shift"], act=ops.ACT_GELU)
+        x = self._buf(fine.n, cout, torch.float32)
+        xc = self._buf(fine.n, cout, self.T)
+        ops.gemm(parent.xc, w[pre + ".skip.w"], x, bias=w[pre + ".skip.b"], scale=w[pre + ".skip_bn.scale"],
+                 shift=w[pre + ".skip_bn.shift"], act=ops.ACT_GELU, add_src=child, add_idx=cluster, out2=xc,
+                 out2_pre_add=True)
+        out = State(fine, x, xc, parent.curves)
+        out.parent = parent.parent
+        return out
+
+    def run_cross_block(self, nst, cst):
+        """ref: ptv3.py:1179-1223 + :988-1055 (cross_block2: n <- c, the NN->CN feature injection)."""
+        w = self.w
+        cb = self.model.backbone._tm_dec0.cross_block2
+        att = cb.attn
+        lv = nst.level
+        if cst.level is not lv:
+            raise CdsegError("cross attention needs the c- and n-branch bottlenecks on the same voxel set "
+                             "(ref: ptv3.py:1009 reuses the q padding for kv)")
+        n, cq = nst.x.shape
+        self._cpe(nst, "x.q_cpe", nst.xc)
+        self._cpe(cst, "x.kv_cpe", cst.xc)
+        hq = self._buf(n, cq, self.T)
+        ops.layernorm(nst.x, w["x.q_norm1.g"], w["x.q_norm1.b"], hq)
+        hkv = self._buf(n, cst.x.shape[1], self.T)
+        ops.layernorm(cst.x, w["x.kv_norm1.g"], w["x.kv_norm1.b"], hkv)
+        q = self._buf(n, cq, self.T)
+        ops.gemm(hq, w["x.q.w"], q, bias=w["x.q.b"])
+        kv = self._buf(n, 2 * cq, self.T)
+        ops.gemm(hkv, w["x.kv.w"], kv, bias=w["x.kv.b"])
+        K = att.q_patch_size
+        q_gidx, widx = lv.slots(nst.curves[att.order_index], K, att.enable_flash)
+        kv_gidx, _ = lv.slots(cst.curves[att.order_index], K, att.enable_flash)
+        _, _, _, _, patch_start, max_len = lv.pad(K, att.enable_flash)
+        o = self._buf(n, cq, self.T)
+        ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o)
+        if cb.tm_feat == 1.0:
+            ops.gemm(o, w["x.proj.w"], nst.x, bias=w["x.proj.b"], res=nst.x)
+        else:  # q_shortcut + feat_scale * attn
+            ops.gemm(o, w["x.proj.w"], nst.x, bias=w["x.proj.b"], scale=w["x.feat_scale"], shift=w["x.feat_zero"],
+                     res=nst.x)
+        self._mlp(nst, "x.q_norm2", "x.fc")
+
+    # ------------------------------------------------------------------ randomness
+    def draw(self, n, feat_shape, c_ch, noise_level, n_perms):
+        """The reference's CPU-generator consumption order (SURVEY.md finding 3)."""
+        m = self.model
+        d = {}
+        if noise_level is not None:
+            d["feat_noise"] = torch.randn(feat_shape) if m.noise_source == "torch_cpu" else None
+        if m.condition and m.dm and m.dm_input == "xt":
+            d["noise"] = (torch.normal(0, 1, size=(n, c_ch), dtype=torch.float32)
+                          if m.noise_source == "torch_cpu" else None)
+        if m.backbone.shuffle_orders:
+            no = len(m.backbone.order)
+            d["perms"] = [torch.randperm(no).tolist() for _ in range(n_perms)]
+        return d
+
+    def _device_randn(self, shape):
+        seed = torch.initial_seed()
+        out = ops.randn(shape, seed, self.rng_offset, self.device)
+        self.rng_offset += 1
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def inference(self, input_dict, noise_level=None, draws=None):
+        m, bb = self.model, self.model.backbone
+        feat = input_dict["feat"]
+        dev = feat.device  # CPU tensors are rejected by every op (cdsegnet_amd.ops): no CPU fallback
+        self.prepare(dev)
+        w = self.w
+        grid = input_dict["grid_coord"]
+        offset = input_dict["offset"]
+        n = feat.shape[0]
+        offset_host = input_dict["offset_host"] if "offset_host" in input_dict else offset.cpu().tolist()
+        offset_host = [int(v) for v in offset_host]
+        cond = bb.condition
+        c_ch = m.c_in_channels
+        n_perms = (2 + len(bb.c_stride) + len(bb.n_stride)) if cond else (1 + len(bb.n_stride))
+        if draws is None:
+            draws = self.draw(n, tuple(feat.shape), c_ch, noise_level, n_perms)
+        feat = feat.float().contiguous()
+        if noise_level is not None:  # ref: default.py:373-374 (perturbs feat and rebinds it in input_dict)
+            fn = draws.get("feat_noise")
+            fn = self._device_randn(tuple(feat.shape)) if fn is None else fn.to(dev, torch.float32)
+            feat = ops.axpy(feat, fn.contiguous(), noise_level)
+            input_dict["feat"] = feat
+        perms = list(draws["perms"]) if bb.shuffle_orders else [None] * n_perms
+        pi = iter(perms)
+        no = len(bb.order)
+        base_curves = [CURVES.index(o) for o in bb.order]
+
+        plan = self.build_plan(grid, offset.to(torch.int64), offset_host, n)
+        self.last_plan = plan
+
+        def shuffled(perm):
+            return list(base_curves) if perm is None else [base_curves[int(j)] for j in perm]
+
+        n_cum, c_cum = plan.n_cum, plan.c_cum
+        if cond:
+            c_curves = shuffled(next(pi))
+        n_curves = shuffled(next(pi))
+
+        featp = ops.gather_rows(feat, plan.perm0)
+        tb = {}
+        if cond:
+            if m.dm and m.dm_input == "xt":  # ref: default.py:392-394
+                nz = draws.get("noise")
+                if nz is None:
+                    c_feat = self._device_randn((n, c_ch))  # any order is equally random
+                else:
+                    c_feat = ops.gather_rows(nz.to(dev, torch.float32).contiguous(), plan.perm0)
+                t = m.T - 1
+            else:
+                tgt = feat if c_ch == feat.shape[1] else input_dict["coord"].float().contiguous()
+                c_feat = ops.gather_rows(tgt, plan.perm0)
+                t = 0
+            if bb.T_dim != -1:  # ref: ptv3.py:1772-1778 on the (uniform) embedding row
+                v = ops.gemv(w["t.fc1.w"], w["t.fc1.b"], w["t.table"][t], ops.ACT_SWISH)
+                v = ops.gemv(w["t.fc2.w"], w["t.fc2.b"], v, ops.ACT_SWISH)
+                tall = ops.gemv(w["t.mlp.w"], w["t.mlp.b"], v, ops.ACT_NONE)
+                tb = {k: tall[a:b] for k, (a, b) in self.t_slices.items()}
+
+        def enc_stage(st, branch, s, cum, perm):
+            enc = getattr(getattr(bb, f"_{branch}_enc"), f"enc{s}")
+            if s > 0:
+                st = self.run_pooling(plan, st, f"{branch}_enc{s}.down", cum[s], perm)
+            for name, mod in enc._modules.items():
+                if name.startswith("block"):
+                    key = f"{branch}_enc{s}.{name}"
+                    self.run_block(st, mod, key, tb.get(key))
+            return st
+
+        # ref: ptv3.py:1781-1794 (the c/n interleave only matters for the order of the randperm draws)
+        if cond:
+            cst = self.run_embedding(plan, c_feat, "c_emb", c_curves)
+        nst = self.run_embedding(plan, featp, "n_emb", n_curves)
+        if cond:
+            assert bb.c_num_stages == 3 and bb.n_num_stages == 5, "interleave hard-wired as in ptv3.py:1785-1794"
+            cst = enc_stage(cst, "c", 0, c_cum, None)
+            nst = enc_stage(nst, "n", 0, n_cum, None)
+            cst = enc_stage(cst, "c", 1, c_cum, next(pi))
+            nst = enc_stage(nst, "n", 1, n_cum, next(pi))
+            nst = enc_stage(nst, "n", 2, n_cum, next(pi))
+            cst = enc_stage(cst, "c", 2, c_cum, next(pi))
+            nst = enc_stage(nst, "n", 3, n_cum, next(pi))
+            nst = enc_stage(nst, "n", 4, n_cum, next(pi))
+            self.run_cross_block(nst, cst)
+        else:
+            for s in range(bb.n_num_stages):
+                nst = enc_stage(nst, "n", s, n_cum, next(pi) if s > 0 else None)
+        self.trace = {"n_bottleneck": nst.x}
+        # decoder (c-decoder and c-head are dead code in SSI: skipped)
+        for s in reversed(range(bb.n_num_stages - 1)):
+            dec = getattr(bb._n_dec, f"dec{s}")
+            if dec.up.skip_connection_mode != "add" or dec.up.skip_connection_scale_i is not None:
+                raise NotImplementedError("n-branch un-pooling other than 'add' without scaling")
+            nst = self.run_unpooling(plan, nst, f"n_dec{s}.up")
+            for name, mod in dec._modules.items():
+                if name.startswith("block"):
+                    self.run_block(nst, mod, f"n_dec{s}.{name}")
+        # head, scattered back to the caller's point order (ref: ptv3.py:1813)
+        if "n_head.w" in w:
+            logits = torch.empty((n, w["n_head.w"].shape[0]), dtype=torch.float32, device=dev)
+            ops.gemm(nst.xc, w["n_head.w"], logits, bias=w["n_head.b"], out_idx=plan.perm0)
+        else:
+            logits = torch.empty((n, nst.x.shape[1]), dtype=torch.float32, device=dev)
+            ops.scatter_rows(nst.x, plan.perm0, logits)
+        return logits

@@ -1,0 +1,407 @@
+"""Model-registry surface of the hot path: ``DefaultSegmentorV2`` + ``"PT-v3m1"``.
+
+Same registry names, constructor kwargs and ``state_dict`` schema as the reference
+(ref: pointcept/models/default.py:13-72, pointcept/models/point_transformer_v3/
+point_transformer_v3m1_base.py:1340-1755), so released checkpoints load ``strict=True`` and
+``tools/test_*.py`` can call ``model.inference(input_dict, eval=False, noise_level=...)``
+unchanged.  The ``nn.Module`` tree below only OWNS parameters (names/shapes = the reference's);
+the forward pass is executed by ``cdsegnet_amd.engine`` on hand-written HIP kernels.
+Options that every shipped CDSegNet config leaves off (RPE, PDNorm, Restormer fusion,
+bidirectional fusion, FreeU, cls_mode) are accepted by the constructors and rejected loudly.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .registry import MODELS, build_model
+
+
+class PointSequential(nn.Module):
+    """Named container with the reference's ``add`` (ref: pointcept/models/modules.py:19-56)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for idx, m in enumerate(args):
+            self.add_module(str(idx), m)
+        for name, m in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, m)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError(f"index {idx} is out of range")
+        return list(self._modules.values())[idx]
+
+
+class SubMConv3d(nn.Module):
+    """Parameter holder for spconv.SubMConv3d: weight (out, k, k, k, in) [spconv-2.x KRSC], bias (out)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, indice_key=None, padding=0):
+        super().__init__()
+        k = kernel_size
+        self.in_channels, self.out_channels, self.kernel_size, self.indice_key = in_channels, out_channels, k, indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, k, k, k, in_channels))
+        fan_in = k * k * k * in_channels
+        nn.init.uniform_(self.weight, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in)))
+        else:
+            self.register_parameter("bias", None)
+
+
+class MLP(nn.Module):
+    def __init__(self, in_channels, hidden_channels, out_channels):
+        super().__init__()
+        self.fc1 = nn.Linear(in_channels, hidden_channels)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_channels, out_channels)
+
+
+def _reject(**flags):
+    for name, (value, allowed) in flags.items():
+        if value != allowed:
+            raise NotImplementedError(
+                f"{name}={value!r}: this option is disabled in every shipped CDSegNet config and is not part of the "
+                f"MI355X hot path (supported: {allowed!r})")
+
+
+class SerializedAttention(nn.Module):
+    def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, order_index=0,
+                 enable_flash=True):
+        super().__init__()
+        assert channels % num_heads == 0
+        if channels // num_heads != 16:
+            raise NotImplementedError("the HIP attention kernels are specialised for head dim 16 (C/H == 16)")
+        if patch_size > 1024:
+            raise NotImplementedError("patch_size > 1024")
+        self.channels, self.num_heads, self.patch_size = channels, num_heads, patch_size
+        self.scale = qk_scale or (channels // num_heads) ** -0.5
+        self.order_index = order_index
+        self.enable_flash = enable_flash
+        self.qkv = nn.Linear(channels, channels * 3, bias=qkv_bias)
+        self.proj = nn.Linear(channels, channels)
+
+
+class Block(nn.Module):
+    """ref: ptv3.py:326-428."""
+
+    def __init__(self, channels, num_heads, patch_size=48, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 order_index=0, cpe_indice_key=None, enable_flash=True, T_dim=-1, pre_norm=True):
+        super().__init__()
+        _reject(pre_norm=(pre_norm, True))
+        self.channels, self.T_dim = channels, T_dim
+        self.cpe = PointSequential(
+            SubMConv3d(channels, channels, 3, bias=True, indice_key=cpe_indice_key),
+            nn.Linear(channels, channels),
+            nn.LayerNorm(channels),
+        )
+        self.norm1 = PointSequential(nn.LayerNorm(channels))
+        self.attn = SerializedAttention(channels, num_heads, patch_size, qkv_bias, qk_scale, order_index, enable_flash)
+        self.norm2 = PointSequential(nn.LayerNorm(channels))
+        self.mlp = PointSequential(MLP(channels, int(channels * mlp_ratio), channels))
+        self.drop_path = PointSequential(nn.Identity())
+        if T_dim != -1:
+            self.t_mlp = nn.Linear(T_dim, channels)
+
+
+class SerializedPooling(nn.Module):
+    """ref: ptv3.py:431-555."""
+
+    def __init__(self, in_channels, out_channels, stride=2, reduce="max", shuffle_orders=True, T_dim=-1):
+        super().__init__()
+        assert stride == 2 ** (math.ceil(stride) - 1).bit_length()
+        _reject(reduce=(reduce, "max"))
+        self.in_channels, self.out_channels, self.stride, self.T_dim = in_channels, out_channels, stride, T_dim
+        self.shuffle_orders = shuffle_orders
+        self.proj = nn.Linear(in_channels, out_channels)
+        self.norm = PointSequential(nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.01))
+        self.act = PointSequential(nn.GELU())
+
+
+class SerializedUnpooling(nn.Module):
+    """ref: ptv3.py:558-630."""
+
+    def __init__(self, in_channels, skip_channels, out_channels, skip_connection_mode="add", b=1.0, s=1.0,
+                 skip_connection_scale=False, skip_connection_scale_i=False):
+        super().__init__()
+        if b != 1 or s != 1:
+            raise NotImplementedError("FreeU (b/s factors != 1) is off in every shipped config; not on the hot path")
+        bn = lambda c: nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)  # noqa: E731
+        self.proj = PointSequential(nn.Linear(in_channels, out_channels), bn(out_channels), nn.GELU())
+        self.proj_skip = PointSequential(nn.Linear(skip_channels, out_channels), bn(out_channels), nn.GELU())
+        self.skip_connection_mode = skip_connection_mode
+        self.skip_connection_scale = skip_connection_scale
+        self.skip_connection_scale_i = skip_connection_scale_i
+        if skip_connection_mode == "cat":
+            self.proj_cat = PointSequential(nn.Linear(out_channels * 2, out_channels))
+
+
+class Embedding(nn.Module):
+    """ref: ptv3.py:633-663."""
+
+    def __init__(self, in_channels, embed_channels):
+        super().__init__()
+        self.in_channels, self.embed_channels = in_channels, embed_channels
+        self.stem = PointSequential(conv=SubMConv3d(in_channels, embed_channels, 5, bias=False, indice_key="stem",
+                                                    padding=1))
+        self.stem.add(nn.BatchNorm1d(embed_channels, eps=1e-3, momentum=0.01), name="norm")
+        self.stem.add(nn.GELU(), name="act")
+
+
+class SerializedCrossAttention(nn.Module):
+    """ref: ptv3.py:859-1055."""
+
+    def __init__(self, q_channels, kv_channels, num_heads, q_patch_size, kv_patch_size, qkv_bias=True, qk_scale=None,
+                 order_index=0, enable_flash=True):
+        super().__init__()
+        assert q_channels % num_heads == 0 and kv_channels % num_heads == 0
+        if q_channels // num_heads != 16:
+            raise NotImplementedError("the HIP attention kernels are specialised for head dim 16 (C/H == 16)")
+        self.q_channels, self.kv_channels, self.num_heads = q_channels, kv_channels, num_heads
+        self.q_patch_size, self.kv_patch_size = q_patch_size, kv_patch_size
+        self.scale = qk_scale or (q_channels // num_heads) ** -0.5
+        self.order_index, self.enable_flash = order_index, enable_flash
+        self.q = nn.Linear(q_channels, q_channels, bias=qkv_bias)
+        self.kv = nn.Linear(kv_channels, q_channels * 2, bias=qkv_bias)
+        self.proj = nn.Linear(q_channels, q_channels)
+
+
+class CrossBlock(nn.Module):
+    """ref: ptv3.py:1058-1223."""
+
+    def __init__(self, q_channels, kv_channels, num_heads, q_patch_size, kv_patch_size, mlp_ratio=4.0, qkv_bias=True,
+                 qk_scale=None, order_index=0, q_cpe_indice_key=None, kv_cpe_indice_key=None, enable_flash=True,
+                 tm_feat=1.0):
+        super().__init__()
+        if not isinstance(tm_feat, (int, float)):
+            raise NotImplementedError(f"tm_feat={tm_feat!r}: learned fusion scales are off in every shipped config")
+        self.tm_feat = float(tm_feat)
+        self.q_channels, self.kv_channels = q_channels, kv_channels
+        self.q_cpe = PointSequential(SubMConv3d(q_channels, q_channels, 3, bias=True, indice_key=q_cpe_indice_key),
+                                     nn.Linear(q_channels, q_channels), nn.LayerNorm(q_channels))
+        self.kv_cpe = PointSequential(SubMConv3d(kv_channels, kv_channels, 3, bias=True, indice_key=kv_cpe_indice_key),
+                                      nn.Linear(kv_channels, kv_channels), nn.LayerNorm(kv_channels))
+        self.q_norm1 = PointSequential(nn.LayerNorm(q_channels))
+        self.kv_norm1 = PointSequential(nn.LayerNorm(kv_channels))
+        self.attn = SerializedCrossAttention(q_channels, kv_channels, num_heads, q_patch_size, kv_patch_size, qkv_bias,
+                                             qk_scale, order_index, enable_flash)
+        self.q_norm2 = PointSequential(nn.LayerNorm(q_channels))
+        self.mlp = PointSequential(MLP(q_channels, int(q_channels * mlp_ratio), q_channels))
+        self.drop_path = PointSequential(nn.Identity())
+
+
+class TransferModule(nn.Module):
+    """ref: ptv3.py:1225-1337 (tm_bidirectional=False: only cross_block2(n <- c))."""
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.cross_block2 = CrossBlock(**kw)
+
+
+@MODELS.register_module("PT-v3m1")
+class PointTransformerV3(nn.Module):
+    """ref: ptv3.py:1340-1755 (constructor) / :1757-1846 (forward, run by engine.backbone_forward)."""
+
+    def __init__(
+        self,
+        c_in_channels=6, n_in_channels=6, order=("z", "z_trans"),
+        c_stride=(4, 4), c_enc_depths=(2, 2, 2), c_enc_channels=(32, 64, 128), c_enc_num_head=(2, 4, 8),
+        c_enc_patch_size=(1024, 1024, 1024), c_dec_depths=(2, 2), c_dec_channels=(64, 64), c_dec_num_head=(4, 4),
+        c_dec_patch_size=(1024, 1024),
+        n_stride=(2, 2, 2, 2), n_enc_depths=(2, 2, 2, 6, 2), n_enc_channels=(32, 64, 128, 256, 512),
+        n_enc_num_head=(2, 4, 8, 16, 32), n_enc_patch_size=(48, 48, 48, 48, 48), n_dec_depths=(2, 2, 2, 2),
+        n_dec_channels=(64, 64, 128, 256), n_dec_num_head=(4, 4, 8, 16), n_dec_patch_size=(48, 48, 48, 48),
+        mlp_ratio=4, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0, drop_path=0.3, pre_norm=True,
+        shuffle_orders=True, enable_rpe=False, enable_flash=True, upcast_attention=True, upcast_softmax=True,
+        cls_mode=False, pdnorm_bn=False, pdnorm_ln=False, pdnorm_decouple=True, pdnorm_adaptive=False,
+        pdnorm_affine=True, pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D"),
+        num_classes=20, T_dim=128, tm_bidirectional=False, tm_feat=1.0, tm_restomer=False, condition=False,
+        skip_connection_mode="add", b_factor=(1.0, 1.0, 1.0, 1.0), s_factor=(1.0, 1.0, 1.0, 1.0),
+        skip_connection_scale=False, skip_connection_scale_i=False,
+    ):
+        super().__init__()
+        _reject(enable_rpe=(enable_rpe, False), cls_mode=(cls_mode, False), pdnorm_bn=(pdnorm_bn, False),
+                pdnorm_ln=(pdnorm_ln, False), tm_bidirectional=(tm_bidirectional, False),
+                tm_restomer=(tm_restomer, False), pre_norm=(pre_norm, True))
+        self.order = [order] if isinstance(order, str) else list(order)
+        for o in self.order:
+            if o not in ("z", "z-trans", "hilbert", "hilbert-trans"):
+                raise NotImplementedError(f"serialization order {o!r}")
+        self.shuffle_orders = shuffle_orders
+        self.num_classes, self.T_dim, self.condition = num_classes, T_dim, condition
+        self.enable_flash = enable_flash
+        self.n_num_stages = len(n_enc_depths)
+        self.n_stride, self.c_stride = tuple(n_stride), tuple(c_stride)
+        assert self.n_num_stages == len(n_stride) + 1 == len(n_enc_channels) == len(n_enc_num_head) == len(n_enc_patch_size)
+        assert self.n_num_stages == len(n_dec_depths) + 1 == len(n_dec_channels) + 1 == len(n_dec_num_head) + 1
+
+        no = len(self.order)
+        blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, enable_flash=enable_flash)
+        self._n_embedding = Embedding(n_in_channels, n_enc_channels[0])
+        self._n_enc = PointSequential()
+        for s in range(self.n_num_stages):
+            enc = PointSequential()
+            if s > 0:
+                enc.add(SerializedPooling(n_enc_channels[s - 1], n_enc_channels[s], stride=n_stride[s - 1]), name="down")
+            for i in range(n_enc_depths[s]):
+                enc.add(Block(n_enc_channels[s], n_enc_num_head[s], n_enc_patch_size[s], order_index=i % no,
+                              cpe_indice_key=f"stage{s}", **blk), name=f"block{i}")
+            if len(enc) != 0:
+                self._n_enc.add(enc, name=f"enc{s}")
+        self._n_dec = PointSequential()
+        n_dec_channels = list(n_dec_channels) + [n_enc_channels[-1]]
+        for s in reversed(range(self.n_num_stages - 1)):
+            dec = PointSequential()
+            dec.add(SerializedUnpooling(n_dec_channels[s + 1], n_enc_channels[s], n_dec_channels[s],
+                                        skip_connection_mode="cat" if skip_connection_mode == "cat_all" else "add",
+                                        b=b_factor[s], s=s_factor[s],
+                                        skip_connection_scale_i=(s + 1) if skip_connection_scale_i else None),
+                    name="up")
+            for i in range(n_dec_depths[s]):
+                dec.add(Block(n_dec_channels[s], n_dec_num_head[s], n_dec_patch_size[s], order_index=i % no,
+                              cpe_indice_key=f"stage{s}", **blk), name=f"block{i}")
+            self._n_dec.add(dec, name=f"dec{s}")
+        self._n_head = nn.Linear(n_dec_channels[0], num_classes) if num_classes > 0 else nn.Identity()
+
+        if self.condition:
+            self.c_num_stages = len(c_enc_depths)
+            assert self.c_num_stages == len(c_stride) + 1 == len(c_enc_channels) == len(c_enc_num_head)
+            self._c_embedding = Embedding(c_in_channels, c_enc_channels[0])
+            if T_dim != -1:
+                self.fc_t1 = nn.Linear(T_dim, 4 * T_dim)
+                self.fc_t2 = nn.Linear(4 * T_dim, T_dim)
+            self._c_enc = PointSequential()
+            for s in range(self.c_num_stages):
+                enc = PointSequential()
+                if s > 0:
+                    enc.add(SerializedPooling(c_enc_channels[s - 1], c_enc_channels[s], stride=c_stride[s - 1],
+                                              T_dim=T_dim), name="down")
+                for i in range(c_enc_depths[s]):
+                    enc.add(Block(c_enc_channels[s], c_enc_num_head[s], c_enc_patch_size[s], order_index=i % no,
+                                  cpe_indice_key=f"stage{s}", T_dim=T_dim, **blk), name=f"block{i}")
+                if len(enc) != 0:
+                    self._c_enc.add(enc, name=f"enc{s}")
+            self._c_dec = PointSequential()
+            c_dec_channels = list(c_dec_channels) + [c_enc_channels[-1]]
+            for s in reversed(range(self.c_num_stages - 1)):
+                dec = PointSequential()
+                dec.add(SerializedUnpooling(c_dec_channels[s + 1], c_enc_channels[s], c_dec_channels[s],
+                                            skip_connection_mode="add" if skip_connection_mode == "add" else "cat",
+                                            skip_connection_scale=skip_connection_scale), name="up")
+                for i in range(c_dec_depths[s]):
+                    dec.add(Block(c_dec_channels[s], c_dec_num_head[s], c_dec_patch_size[s], order_index=i % no,
+                                  cpe_indice_key=f"stage{s}", T_dim=T_dim, **blk), name=f"block{i}")
+                self._c_dec.add(dec, name=f"dec{s}")
+            self._c_head = nn.Linear(n_dec_channels[0], c_in_channels) if num_classes > 0 else nn.Identity()
+            self._tm_dec0 = TransferModule(
+                q_channels=n_dec_channels[-1], kv_channels=c_dec_channels[-1], num_heads=n_enc_num_head[-1],
+                q_patch_size=n_enc_patch_size[-1], kv_patch_size=c_enc_patch_size[-1], mlp_ratio=mlp_ratio,
+                qkv_bias=qkv_bias, qk_scale=qk_scale, order_index=0, q_cpe_indice_key="stage2",
+                kv_cpe_indice_key="stage2", enable_flash=enable_flash, tm_feat=tm_feat)
+
+    def forward(self, c_point=None, n_point=None):
+        raise NotImplementedError(
+            "PT-v3m1 on MI355X is driven through DefaultSegmentorV2.inference (cdsegnet_amd.engine); "
+            "the training forward is outside the single-step-inference hot path")
+
+
+def calc_t_emb_table(T, t_emb_dim):
+    """Rows t = 0..T-1 of the sinusoidal timestep embedding, built once on the host with the very
+    ops the reference uses per call (ref: pointcept/utils/comm.py:21-39), so a row is bit-identical
+    to ``calc_t_emb(t * ones((N,1)), dim)[0]``."""
+    assert t_emb_dim % 2 == 0
+    half = t_emb_dim // 2
+    c = np.log(10000) / (half - 1)
+    f = torch.exp(torch.arange(half) * -c)
+    ts = torch.arange(T, dtype=torch.int64)[:, None]
+    e = ts * f
+    return torch.cat((torch.sin(e), torch.cos(e)), 1)
+
+
+def diffusion_betas(kind, start, stop, T):
+    """ref: default.py:127-189 (only the schedules the shipped configs use)."""
+    if kind == "linear":
+        scale = 1000 / T
+        return torch.linspace(scale * start, scale * stop, T, dtype=torch.float64)
+    if kind == "cosine":
+        s = 0.008
+        t = torch.linspace(start, stop, T + 1, dtype=torch.float64) / T
+        ac = torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** 2
+        ac = ac / ac[0]
+        return torch.clip(1 - ac[1:] / ac[:-1], 0, 0.999)
+    raise NotImplementedError(f"noise_schedule={kind!r}")
+
+
+@MODELS.register_module()
+class DefaultSegmentorV2(nn.Module):
+    """CNF wrapper (ref: default.py:13-494).  ``inference`` is the single-step path (SSI)."""
+
+    def __init__(self, backbone=None, criteria=None, loss_type="EW", task_num=2, num_classes=20, T=1000,
+                 beta_start=0.0001, beta_end=0.02, noise_schedule="linear", T_dim=128, dm=False, dm_input="xt",
+                 dm_target="noise", dm_min_snr=None, condition=False, c_in_channels=6):
+        super().__init__()
+        self.backbone = build_model(backbone)
+        self.criteria_cfg = criteria  # losses are outside the inference path (tester passes eval=False)
+        self.loss_type, self.task_num = loss_type, task_num
+        self.num_classes, self.T, self.T_dim = num_classes, T, T_dim
+        self.beta_start, self.beta_end, self.noise_schedule = beta_start, beta_end, noise_schedule
+        self.condition, self.dm, self.dm_input, self.dm_target = condition, dm, dm_input, dm_target
+        self.dm_min_snr, self.c_in_channels = dm_min_snr, c_in_channels
+        if self.dm:
+            # diffusion tables: plain attributes like the reference's (default.py:57-72); unused by SSI
+            beta = diffusion_betas(noise_schedule, beta_start, beta_end, T)
+            alpha = 1 - beta
+            self.Beta, self.Alpha = beta.float(), alpha.float()
+            self.Alpha_bar = torch.cumprod(alpha, 0).float()
+        if T_dim != -1:
+            self.t_emb_table = calc_t_emb_table(T, T_dim)  # (T, T_dim) host table, uploaded on first use
+        # engine knobs (not part of the reference API)
+        self.precision = "bf16"        # "bf16" (MFMA bf16, fp32 accumulate/residual) | "fp32" (exact-fp32 MFMA)
+        self.noise_source = "torch_cpu"  # "torch_cpu" replays the reference's CPU-generator draws | "device"
+        self._engine = None
+
+    # -- engine cache management -------------------------------------------------------------
+    def _drop_engine(self):
+        self._engine = None
+
+    def load_state_dict(self, *a, **k):
+        self._drop_engine()
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_engine()
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        from .engine import Engine
+        if self._engine is None or self._engine.precision != self.precision:
+            self._engine = Engine(self, self.precision)
+        return self._engine
+
+    # -- reference API -----------------------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, input_dict, eval=True, noise_level=None, draws=None):
+        """ref: default.py:371-422.  Returns dict(seg_logits=(N, num_classes) fp32 on the input's device).
+        ``draws`` (optional) injects the random draws: dict(noise=(N,c_in) tensor, perms=[8 x (4,)],
+        feat_noise=(N,C) when noise_level is set); by default they are drawn from torch's CPU generator in
+        the reference's consumption order, so ``torch.manual_seed`` reproduces the reference bit-for-bit."""
+        if eval:
+            raise NotImplementedError("eval=True (loss computation) is outside the inference hot path; "
+                                      "the reference tester calls inference(eval=False) (engines/test.py:216)")
+        return dict(seg_logits=self.engine().inference(input_dict, noise_level=noise_level, draws=draws))
+
+    def forward(self, input_dict):
+        raise NotImplementedError("training forward (default.py:424-493) is outside the single-step-inference hot path")

@@ -1,0 +1,321 @@
+"""Torch-tensor wrappers over the C ABI (include/cdseg.h).
+
+Each function mirrors one reference call site (cited in include/cdseg.h) and is a thin
+marshalling layer: PyTorch provides device memory and the stream, every computation runs in
+the hand-written HIP kernels of libcdseg_hip.so.  No fallbacks: tensors must live on a GPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_SWISH, BF16, F32, GemmArgs, check
+
+__all__ = ["ACT_NONE", "ACT_GELU", "ACT_SWISH", "F32", "BF16"]
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_WS = {}
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CdsegError("cdsegnet_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+
+
+def dt(t):
+    return _DT[t.dtype]
+
+
+def workspace(nbytes, device):
+    """Per-device scratch buffer (grown geometrically, never shrunk)."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------ serialization
+def grid_max(grid):
+    _need_gpu(grid)
+    grid = grid.contiguous()
+    out = torch.empty(1, dtype=torch.int64, device=grid.device)
+    check(_lib.load().cdseg_grid_max(_ptr(grid), grid.element_size(), grid.numel(), _ptr(out), _stream()), "grid_max")
+    return out
+
+
+def offset2batch(offset, n):
+    _need_gpu(offset)
+    offset = offset.contiguous().to(torch.int64)
+    out = torch.empty(n, dtype=torch.int32, device=offset.device)
+    check(_lib.load().cdseg_offset2batch(_ptr(offset), offset.numel(), n, _ptr(out), _stream()), "offset2batch")
+    return out
+
+
+def encode(grid, batch, depth, order):
+    """serialization/default.py:8-24.  grid (N,3) int32|int64; batch None|int32|int64 -> int64 codes."""
+    _need_gpu(grid, batch)
+    grid = grid.contiguous()
+    n = grid.shape[0]
+    code = torch.empty(n, dtype=torch.int64, device=grid.device)
+    b = None if batch is None else batch.contiguous()
+    oid = _lib.ORDER_IDS[order] if isinstance(order, str) else int(order)
+    check(_lib.load().cdseg_encode(_ptr(grid), grid.element_size(), _ptr(b), 0 if b is None else b.element_size(), n,
+                                   int(depth), oid, _ptr(code), _stream()), "encode")
+    return code
+
+
+def encode4(grid_i32, batch_i32, depth):
+    _need_gpu(grid_i32, batch_i32)
+    n = grid_i32.shape[0]
+    code = torch.empty((4, n), dtype=torch.int64, device=grid_i32.device)
+    check(_lib.load().cdseg_encode4(_ptr(grid_i32), _ptr(batch_i32), n, int(depth), _ptr(code), _stream()), "encode4")
+    return code
+
+
+def sort_pairs(keys, vals=None, end_bit=64):
+    """Stable radix sort of non-negative int64 keys with int32 payload (iota if vals is None)."""
+    _need_gpu(keys, vals)
+    lib = _lib.load()
+    keys = keys.contiguous()
+    n = keys.numel()
+    keys_out = torch.empty_like(keys)
+    vals_out = torch.empty(n, dtype=torch.int32, device=keys.device)
+    nbytes = lib.cdseg_sort_ws_bytes(n)
+    ws = workspace(nbytes, keys.device)
+    check(lib.cdseg_sort_pairs(_ptr(keys), _ptr(keys_out), _ptr(vals), _ptr(vals_out), n, int(end_bit), _ptr(ws),
+                               ws.numel(), _stream()), "sort_pairs")
+    return keys_out, vals_out
+
+
+def invert_perm(perm):
+    _need_gpu(perm)
+    inv = torch.empty_like(perm)
+    check(_lib.load().cdseg_invert_perm(_ptr(perm), perm.numel(), _ptr(inv), _stream()), "invert_perm")
+    return inv
+
+
+def widen(x_i32):
+    out = torch.empty(x_i32.shape, dtype=torch.int64, device=x_i32.device)
+    check(_lib.load().cdseg_widen_i32(_ptr(x_i32), x_i32.numel(), _ptr(out), _stream()), "widen")
+    return out
+
+
+def gather_rows(src, idx):
+    """dst[i] = src[idx[i]] (rows), idx int32, idx<0 -> zero row."""
+    _need_gpu(src, idx)
+    src = src.contiguous()
+    row_bytes = src[0].numel() * src.element_size() if src.dim() > 1 else src.element_size()
+    out = torch.empty((idx.numel(),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    check(_lib.load().cdseg_gather_rows(_ptr(src), _ptr(idx), idx.numel(), row_bytes, _ptr(out), _stream()),
+          "gather_rows")
+    return out
+
+
+def scatter_rows(src, idx, out):
+    _need_gpu(src, idx, out)
+    src = src.contiguous()
+    row_bytes = src[0].numel() * src.element_size() if src.dim() > 1 else src.element_size()
+    check(_lib.load().cdseg_scatter_rows(_ptr(src), _ptr(idx), idx.numel(), row_bytes, _ptr(out), _stream()),
+          "scatter_rows")
+    return out
+
+
+def gather_i32(src, idx):
+    out = torch.empty(idx.numel(), dtype=torch.int32, device=src.device)
+    check(_lib.load().cdseg_gather_i32(_ptr(src), _ptr(idx), idx.numel(), _ptr(out), _stream()), "gather_i32")
+    return out
+
+
+def plan_gather_grid(grid, perm, zcode_sorted, depth):
+    grid = grid.contiguous()
+    n = grid.shape[0]
+    g = torch.empty((n, 3), dtype=torch.int32, device=grid.device)
+    b = torch.empty(n, dtype=torch.int32, device=grid.device)
+    check(_lib.load().cdseg_plan_gather_grid(_ptr(grid), grid.element_size(), _ptr(perm), _ptr(zcode_sorted), n,
+                                             int(depth), _ptr(g), _ptr(b), _stream()), "plan_gather_grid")
+    return g, b
+
+
+def pool_level(zcode_sorted, shift_bits, count_out=None):
+    """Clusters of z-sorted points at one pooling level -> (cluster (n), seg_start (n+1, first count+1 valid),
+    count (1,) int32 on device)."""
+    lib = _lib.load()
+    n = zcode_sorted.numel()
+    dev = zcode_sorted.device
+    cluster = torch.empty(n, dtype=torch.int32, device=dev)
+    seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    count = count_out if count_out is not None else torch.empty(1, dtype=torch.int32, device=dev)
+    ws = workspace(lib.cdseg_sort_ws_bytes(n), dev)
+    check(lib.cdseg_pool_level(_ptr(zcode_sorted), n, int(shift_bits), _ptr(cluster), _ptr(seg_start), _ptr(count),
+                               _ptr(ws), ws.numel(), _stream()), "pool_level")
+    return cluster, seg_start, count
+
+
+def pool_gather(seg_start, m, n_fine, pooling_depth, grid_f, batch_f, code4_f):
+    dev = grid_f.device
+    grid_c = torch.empty((m, 3), dtype=torch.int32, device=dev)
+    batch_c = torch.empty(m, dtype=torch.int32, device=dev)
+    code_c = torch.empty((4, m), dtype=torch.int64, device=dev)
+    check(_lib.load().cdseg_pool_gather(_ptr(seg_start), m, n_fine, int(pooling_depth), _ptr(grid_f), _ptr(batch_f),
+                                        _ptr(code4_f), _ptr(grid_c), _ptr(batch_c), _ptr(code_c), _stream()),
+          "pool_gather")
+    return grid_c, batch_c, code_c
+
+
+def nbr_table(zcode_sorted, grid_i32, batch_i32, depth, ksize, kmajor=False):
+    n = grid_i32.shape[0]
+    kv = ksize ** 3
+    shape = (kv, n) if kmajor else (n, kv)
+    nbr = torch.empty(shape, dtype=torch.int32, device=grid_i32.device)
+    check(_lib.load().cdseg_nbr_table(_ptr(zcode_sorted), _ptr(grid_i32), _ptr(batch_i32), n, int(depth), int(ksize),
+                                      1 if kmajor else 0, _ptr(nbr), _stream()), "nbr_table")
+    return nbr
+
+
+def pad_plan(order, offs, offs_pad, patch, n_pad):
+    dev = offs.device
+    gidx = torch.empty(n_pad, dtype=torch.int32, device=dev)
+    widx = torch.empty(n_pad, dtype=torch.int32, device=dev)
+    check(_lib.load().cdseg_pad_plan(_ptr(order), _ptr(offs), _ptr(offs_pad), offs.numel() - 1, int(patch), n_pad,
+                                     _ptr(gidx), _ptr(widx), _stream()), "pad_plan")
+    return gidx, widx
+
+
+# ------------------------------------------------------------------ float ops
+def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
+         nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1):
+    """out = epilogue(A @ W^T) (or the gathered-A sparse-conv form when nbr is given).
+    A (M,K) [or the gather source], W (N, kvol*K), both of the compute dtype."""
+    _need_gpu(A, W, out)
+    a = GemmArgs()
+    a.A, a.W, a.bias, a.scale, a.shift = A.data_ptr(), W.data_ptr(), _dp(bias), _dp(scale), _dp(shift)
+    a.res, a.add_src, a.add_idx, a.nbr, a.out_idx = _dp(res), _dp(add_src), _dp(add_idx), _dp(nbr), _dp(out_idx)
+    a.out, a.out2 = out.data_ptr(), _dp(out2)
+    a.M = int(M if M is not None else (nbr.shape[0] if nbr is not None else A.shape[0]))
+    a.N = W.shape[0]
+    a.kvol = int(kvol)
+    a.K = W.shape[1] // a.kvol
+    a.lda = A.stride(0)
+    a.ldo = out.stride(0)
+    a.ldo2 = out2.stride(0) if out2 is not None else 0
+    a.ldres = res.stride(0) if res is not None else 0
+    a.ldadd = add_src.stride(0) if add_src is not None else 0
+    a.a_dtype = dt(A)
+    a.compute_dtype = dt(W)
+    a.out_dtype = dt(out)
+    a.out2_dtype = dt(out2) if out2 is not None else 0
+    a.act = int(act)
+    a.out2_pre_add = 1 if out2_pre_add else 0
+    for t in (bias, scale, shift, res, add_src):
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.CdsegError("gemm epilogue vectors / residuals are float32")
+    check(_lib.load().cdseg_gemm(ctypes.byref(a), _stream()), "gemm")
+    return out
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):
+    """SubMConv3d(k=5, bias=False) + folded BN + GELU.  w_packed (kvol, Cin, Cout) fp32."""
+    n, cin = x.shape
+    kvol, _, cout = w_packed.shape
+    check(_lib.load().cdseg_stem_conv(_ptr(x), x.stride(0), _ptr(nbr_kmajor), _ptr(w_packed), _ptr(scale), _ptr(shift),
+                                      n, cin, cout, kvol, _ptr(out), out.stride(0), _ptr(out2),
+                                      dt(out2) if out2 is not None else 0, out2.stride(0) if out2 is not None else 0,
+                                      _stream()), "stem_conv")
+    return out
+
+
+def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=None):
+    m, c = x.shape
+    check(_lib.load().cdseg_layernorm(_ptr(x), dt(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(res),
+                                      res.stride(0) if res is not None else 0, _ptr(colbias), _ptr(out), dt(out),
+                                      out.stride(0), _ptr(out2), dt(out2) if out2 is not None else 0,
+                                      out2.stride(0) if out2 is not None else 0, m, c, _stream()), "layernorm")
+    return out
+
+
+def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out):
+    """q/k/v: 2-D views (rows, H*16) of the projection buffers (any row stride); out (rows, H*16)."""
+    num_patches = patch_start.numel() - 1
+    if not (q.dtype == k.dtype == v.dtype == out.dtype):
+        raise _lib.CdsegError("attention: q, k, v, out must share a dtype")
+    check(_lib.load().cdseg_attention(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),
+                                      _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads),
+                                      int(max_len), float(scale), _ptr(out), out.stride(0), dt(q), _stream()),
+          "attention")
+    return out
+
+
+def segment_max(y, seg_start, m, scale, shift, act, out, out2=None):
+    c = y.shape[1]
+    check(_lib.load().cdseg_segment_max(_ptr(y), dt(y), y.stride(0), _ptr(seg_start), m, c, _ptr(scale), _ptr(shift),
+                                        int(act), _ptr(out), out.stride(0), _ptr(out2),
+                                        dt(out2) if out2 is not None else 0, out2.stride(0) if out2 is not None else 0,
+                                        _stream()), "segment_max")
+    return out
+
+
+def segment_mean(x, seg_start, m):
+    out = torch.empty((m, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(_lib.load().cdseg_segment_mean(_ptr(x), x.stride(0), _ptr(seg_start), m, x.shape[1], _ptr(out),
+                                         out.stride(0), _stream()), "segment_mean")
+    return out
+
+
+def gemv(w, b, x, act=ACT_NONE):
+    n, k = w.shape
+    y = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(_lib.load().cdseg_gemv(_ptr(w), _ptr(b), _ptr(x), n, k, int(act), _ptr(y), _stream()), "gemv")
+    return y
+
+
+def randn(shape, seed, offset, device):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.load().cdseg_randn(_ptr(out), out.numel(), int(seed) & (2 ** 64 - 1), int(offset), _stream()), "randn")
+    return out
+
+
+def cast(src, dtype):
+    src = src.contiguous()
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.load().cdseg_cast(_ptr(src), dt(src), _ptr(out), _DT[dtype], src.numel(), _stream()), "cast")
+    return out
+
+
+def axpy(a, b, alpha):
+    out = torch.empty_like(a)
+    check(_lib.load().cdseg_axpy(_ptr(a), _ptr(b), float(alpha), _ptr(out), a.numel(), _stream()), "axpy")
+    return out
+
+
+# ------------------------------------------------------------------ reference-shaped composites
+def serialization(grid_coord, batch, orders=("z", "z-trans", "hilbert", "hilbert-trans"), depth=None):
+    """Point.serialization before the shuffle (structure.py:47-93): code, order, inverse as (k, N) int64
+    in the caller's point order - the drop-in for the reference's encode + argsort + scatter_."""
+    _need_gpu(grid_coord, batch)
+    if depth is None:
+        depth = int(grid_max(grid_coord).item()).bit_length()
+    codes, orders_, inverses = [], [], []
+    nb = int(batch.max().item()) + 1 if batch.numel() else 1
+    end_bit = 3 * depth + max(1, nb.bit_length())
+    for o in orders:
+        c = encode(grid_coord, batch, depth, o)
+        _, perm = sort_pairs(c, None, end_bit=min(64, end_bit))
+        codes.append(c)
+        orders_.append(widen(perm))
+        inverses.append(widen(invert_perm(perm)))
+    return torch.stack(codes), torch.stack(orders_), torch.stack(inverses), depth

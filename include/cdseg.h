@@ -1,0 +1,189 @@
+/* cdseg.h - C ABI of libcdseg_hip.so: the MI355X (gfx950) kernels behind CDSegNet's
+ * single-step-inference hot path.
+ *
+ * Drop-in boundary.  The reference (a Python program on PyTorch) reaches its fused
+ * arithmetic through third-party Python ops; each entry point below is what a binding
+ * for that call site would bind (plain device pointers + sizes, no torch types), and
+ * cdsegnet_amd/ops.py is the ctypes binding the build ships (INTEGRATION.md shows the
+ * equivalent stubs on the reference side).  "ref:" cites the reference interface
+ * replaced, relative to /root/reference/pointcept/.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *  - every function is asynchronous on `stream`, returns CDSEG_OK (0) or a negative
+ *    CDSEG_ERR_* code, and never allocates (callers own all buffers and workspaces);
+ *  - dtypes: CDSEG_F32 = float32, CDSEG_BF16 = bfloat16 (raw uint16 bits);
+ *  - index arrays are int32 unless stated; codes are int64 (non-negative).
+ *  - attention head dimension is 16 (every stage of every shipped config: C/H = 16).
+ */
+#ifndef CDSEG_H
+#define CDSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDSEG_OK 0
+#define CDSEG_ERR_ARG (-1)
+#define CDSEG_ERR_LAUNCH (-2)
+#define CDSEG_ERR_WORKSPACE (-3)
+#define CDSEG_ERR_UNSUPPORTED (-4)
+
+#define CDSEG_F32 0
+#define CDSEG_BF16 1
+
+#define CDSEG_ORDER_Z 0
+#define CDSEG_ORDER_Z_TRANS 1
+#define CDSEG_ORDER_HILBERT 2
+#define CDSEG_ORDER_HILBERT_TRANS 3
+
+#define CDSEG_ACT_NONE 0
+#define CDSEG_ACT_GELU 1  /* exact erf GELU (nn.GELU()) */
+#define CDSEG_ACT_SWISH 2 /* x * sigmoid(x), ref: models/point_transformer_v3/point_transformer_v3m1_base.py:30-31 */
+
+#define CDSEG_HEAD_DIM 16
+#define CDSEG_MAX_PATCH 1024
+
+/* library / device identification (host-only helpers) */
+int cdseg_abi_version(void);
+const char* cdseg_build_info(void);
+
+/* ------------------------------------------------------------------ serialization
+ * ref: models/utils/structure.py:47-102 (Point.serialization),
+ *      models/utils/serialization/default.py:8-24 (encode), z_order.py:66-101, hilbert.py:91-198 */
+
+/* max over all grid coordinates -> *out_dev (int64); depth = bit_length(max).  ref: structure.py:66 */
+int cdseg_grid_max(const void* grid, int elem_bytes, long n3, int64_t* out_dev, void* stream);
+/* batch[i] = index of the batch element owning point i.  ref: models/utils/misc.py:18-23 (offset2batch) */
+int cdseg_offset2batch(const int64_t* offset, int nb, long n, int32_t* batch, void* stream);
+/* code[i] = (batch[i] << 3*depth) | curve_key(order_id, grid[i]).  grid (n,3) int32|int64,
+ * batch int32|int64 or NULL.  ref: serialization/default.py:8-24 */
+int cdseg_encode(const void* grid, int grid_elem_bytes, const void* batch, int batch_elem_bytes, long n, int depth,
+                 int order_id, int64_t* code, void* stream);
+/* all four curves, code4 is (4,n) row-major in CDSEG_ORDER_* order */
+int cdseg_encode4(const int32_t* grid, const int32_t* batch, long n, int depth, int64_t* code4, void* stream);
+/* stable radix sort of (code, value) pairs = torch.argsort(code) when vals_in == NULL (iota).
+ * ref: structure.py:83 (torch.argsort), ptv3.py:493.  ws from cdseg_sort_ws_bytes(n). */
+size_t cdseg_sort_ws_bytes(long n);
+int cdseg_sort_pairs(const int64_t* keys_in, int64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, long n,
+                     int end_bit, void* ws, size_t ws_bytes, void* stream);
+/* inv[perm[i]] = i.  ref: structure.py:84-90 (scatter_ of arange) */
+int cdseg_invert_perm(const int32_t* perm, long n, int32_t* inv, void* stream);
+int cdseg_widen_i32(const int32_t* src, long n, int64_t* dst, void* stream);
+
+/* row gathers / scatters (rows of row_bytes % 4 == 0 bytes); idx < 0 gathers zeros / skips */
+int cdseg_gather_rows(const void* src, const int32_t* idx, long n_out, int row_bytes, void* dst, void* stream);
+int cdseg_scatter_rows(const void* src, const int32_t* idx, long n_in, int row_bytes, void* dst, void* stream);
+int cdseg_gather_i32(const int32_t* src, const int32_t* idx, long n, int32_t* dst, void* stream);
+
+/* engine plan, stage 0: int32 grid + batch in z-sorted ("physical") order */
+int cdseg_plan_gather_grid(const void* grid, int grid_elem_bytes, const int32_t* perm, const int64_t* zcode_sorted,
+                           long n, int depth, int32_t* grid_out, int32_t* batch_out, void* stream);
+
+/* ------------------------------------------------------------------ pooling structure
+ * ref: ptv3.py:477-492 (code >> 3*depth, torch.unique, sort(cluster), idx_ptr, head).
+ * On z-sorted points a cluster is a contiguous run: cluster ids are an inclusive scan of the
+ * run-start flags, seg_start (count+1 entries) are the run starts, *count_dev the number of runs. */
+int cdseg_pool_level(const int64_t* zcode_sorted, long n, int shift_bits, int32_t* cluster, int32_t* seg_start,
+                     int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
+/* pooled grid / batch / codes from the first fine point of each run.  ref: ptv3.py:489-491, 519-525 */
+int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling_depth, const int32_t* grid_f,
+                      const int32_t* batch_f, const int64_t* code4_f, int32_t* grid_c, int32_t* batch_c,
+                      int64_t* code4_c, void* stream);
+
+/* ------------------------------------------------------------------ sparse-conv kernel map
+ * ref: spconv.SubMConv3d indice pairs (third party; call sites ptv3.py:356,647,1106,1118).
+ * nbr (n, ksize^3): row index of the occupied voxel at grid + (a-r, b-r, c-r), column
+ * a*k*k + b*k + c, or -1 (kmajor != 0: stored transposed, (ksize^3, n)).  Points must be sorted
+ * by (batch | z-order) code. */
+int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
+                    int ksize, int kmajor, int32_t* nbr, void* stream);
+
+/* ------------------------------------------------------------------ attention padding plan
+ * ref: ptv3.py:188-244 (get_padding_and_inverse) in gather/scatter form: for every padded slot
+ * the row to read (gidx) and the row to write (widx, -1 for the borrowed duplicates).
+ * order: rank -> row for the curve of this block (NULL = identity); offs/offs_pad (nb+1). */
+int cdseg_pad_plan(const int32_t* order, const int32_t* offs, const int32_t* offs_pad, int nb, int patch, long n_pad,
+                   int32_t* gidx, int32_t* widx, void* stream);
+
+/* ------------------------------------------------------------------ dense / gathered GEMM
+ * out = epilogue(A @ W^T): nn.Linear (ref: ptv3.py:170-171, 310-313, 463, 597-599, 1562) and,
+ * with nbr != NULL, spconv.SubMConv3d as a gathered-A GEMM over kvol offsets
+ * (W is the conv weight (N, kvol, K) flattened = (out, k0, k1, k2, in)).
+ * epilogue: v = acc + bias; v = v*scale + shift (folded eval BatchNorm1d, ref: ptv3.py:1440);
+ *           v = act(v); [out2 = v if out2_pre_add]; v += res; v += add_src[add_idx[m]];
+ *           out[out_idx ? out_idx[m] : m] = v; [out2 = v otherwise] */
+typedef struct cdseg_gemm_args {
+  const void* A;          /* (M, lda) a_dtype; with nbr: the gather source (rows indexed by nbr) */
+  const void* W;          /* (N, kvol*K) compute dtype, K contiguous */
+  const float* bias;      /* (N) or NULL */
+  const float* scale;     /* (N) or NULL */
+  const float* shift;     /* (N) or NULL (required with scale) */
+  const float* res;       /* (M, ldres) or NULL */
+  const float* add_src;   /* (*, ldadd) or NULL */
+  const int32_t* add_idx; /* (M) */
+  const int32_t* nbr;     /* (M, kvol) or NULL */
+  const int32_t* out_idx; /* (M) or NULL */
+  void* out;              /* (M, ldo) out_dtype */
+  void* out2;             /* (M, ldo2) out2_dtype or NULL */
+  long M;
+  int N, K, kvol;
+  int lda, ldo, ldo2, ldres, ldadd;
+  int a_dtype, compute_dtype, out_dtype, out2_dtype;
+  int act;
+  int out2_pre_add;
+} cdseg_gemm_args;
+int cdseg_gemm(const cdseg_gemm_args* args_host, void* stream);
+
+/* stem: SubMConv3d(Cin -> Cout, k=5, bias=False) + eval BN + GELU on the VALU (Cin is 4..6).
+ * ref: ptv3.py:633-663.  w is repacked (kvol, Cin, Cout) fp32. */
+int cdseg_stem_conv(const float* x, int ldx, const int32_t* nbr, const float* w, const float* scale,
+                    const float* shift, long n, int cin, int cout, int kvol, float* out, int ldo, void* out2,
+                    int out2_dtype, int ldo2, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * out = [res +] LayerNorm(x) * gamma + beta [+ colbias]; optional second copy out2.
+ * ref: nn.LayerNorm(eps 1e-5) at ptv3.py:365, 367, 381 and the CPE residual ptv3.py:401-404,
+ * t-embedding bias ptv3.py:406-411. */
+int cdseg_layernorm(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, float eps,
+                    const float* res, int ldres, const float* colbias, void* out, int out_dtype, int ldo,
+                    void* out2, int out2_dtype, int ldo2, long m, int c, void* stream);
+
+/* ------------------------------------------------------------------ serialized window attention
+ * ref: ptv3.py:246-296 (SerializedAttention core; flash_attn_varlen_qkvpacked_func :282-288)
+ *      ptv3.py:988-1055 (SerializedCrossAttention core; flash_attn_varlen_kvpacked_func :1038-1047)
+ * For patch p (slots patch_start[p] .. patch_start[p+1], length <= 1024) and head h:
+ *   O = softmax(scale * Q K^T) V over the full patch (no mask), head dim 16,
+ *   Q row of slot s = q[q_gidx[s]*ldq + h*16 ..], K/V rows by kv_gidx, output row widx[s] (skip if -1).
+ * The gather by serialized order, the padding duplicates and the scatter by inverse are fused. */
+int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const int32_t* q_gidx,
+                    const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
+                    int num_heads, int max_len, float scale, void* out, int ldo, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ pooling reduce
+ * out[j] = act(max_{i in run j} y[i] * scale + shift), runs = seg_start (m+1).
+ * ref: ptv3.py:510-515 (torch_scatter.segment_csr(..., "max")) + norm/act :548-551 */
+int cdseg_segment_max(const void* y, int y_dtype, int ldy, const int32_t* seg_start, long m, int c,
+                      const float* scale, const float* shift, int act, float* out, int ldo, void* out2,
+                      int out2_dtype, int ldo2, void* stream);
+/* segment mean of coord (ref: ptv3.py:513-515) */
+int cdseg_segment_mean(const float* x, int ldx, const int32_t* seg_start, long m, int c, float* out, int ldo,
+                       void* stream);
+
+/* ------------------------------------------------------------------ small dense helpers */
+/* y = act(W x + b), W (n,k) fp32: the timestep-embedding MLP, ref: ptv3.py:1772-1778, :406-411 */
+int cdseg_gemv(const float* w, const float* b, const float* x, int n, int k, int act, float* y, void* stream);
+/* standard normal draws (Philox4x32-10 + Box-Muller), the noise-branch input.  ref: default.py:393 */
+int cdseg_randn(float* out, long n, uint64_t seed, uint64_t offset, void* stream);
+int cdseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* out = a + alpha * b (fp32).  ref: default.py:228-236 (add_gaussian_noise) */
+int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDSEG_H */

@@ -1,0 +1,222 @@
+"""TEST INFRASTRUCTURE: a PyTorch-CPU emulation of the C-ABI ops (same signatures as
+cdsegnet_amd.ops), used ONLY to exercise the engine's HOST logic (plan building, curve/slot
+bookkeeping, buffer plumbing, quirks) in the GPU-less build container.  It is never imported by
+the product; tests monkeypatch ``cdsegnet_amd.engine.ops`` with this module."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import model as OM
+from oracle import serialization as S
+
+ACT_NONE, ACT_GELU, ACT_SWISH = 0, 1, 2
+F32, BF16 = 0, 1
+
+
+def grid_max(grid):
+    return grid.max().reshape(1).to(torch.int64)
+
+
+def offset2batch(offset, n):
+    return torch.from_numpy(S.offset2batch(offset.numpy())).int()
+
+
+def encode(grid, batch, depth, order):
+    name = order if isinstance(order, str) else S.ORDERS[order]
+    return torch.from_numpy(S.encode(grid.numpy(), None if batch is None else batch.numpy(), depth, name))
+
+
+def encode4(grid, batch, depth):
+    return torch.stack([encode(grid, batch, depth, o) for o in S.ORDERS])
+
+
+def sort_pairs(keys, vals=None, end_bit=64):
+    assert int(keys.max()) < (1 << end_bit) if end_bit < 64 else True
+    ks, perm = torch.sort(keys, stable=True)
+    v = perm.int() if vals is None else vals[perm]
+    return ks, v
+
+
+def invert_perm(perm):
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = torch.arange(len(perm), dtype=perm.dtype)
+    return inv
+
+
+def widen(x):
+    return x.long()
+
+
+def gather_rows(src, idx):
+    out = src[idx.long().clamp(min=0)]
+    out[idx < 0] = 0
+    return out
+
+
+def scatter_rows(src, idx, out):
+    m = idx >= 0
+    out[idx[m].long()] = src[m]
+    return out
+
+
+def gather_i32(src, idx):
+    return src[idx.long()]
+
+
+def plan_gather_grid(grid, perm, zs, depth):
+    return grid[perm.long()].int(), (zs >> (3 * depth)).int()
+
+
+def pool_level(zs, shift, count_out=None):
+    sh = zs >> shift
+    flag = torch.ones_like(sh, dtype=torch.int32)
+    flag[1:] = (sh[1:] != sh[:-1]).int()
+    cluster = (torch.cumsum(flag, 0) - 1).int()
+    m = int(cluster[-1]) + 1
+    seg = torch.full((len(zs) + 1,), -12345, dtype=torch.int32)
+    seg[:m] = torch.nonzero(flag).flatten().int()
+    seg[m] = len(zs)
+    cnt = torch.tensor([m], dtype=torch.int32)
+    if count_out is not None:
+        count_out.copy_(cnt)
+        cnt = count_out
+    return cluster, seg, cnt
+
+
+def pool_gather(seg, m, n_fine, pd, grid_f, batch_f, code4_f):
+    h = seg[:m].long()
+    return grid_f[h] >> pd, batch_f[h], code4_f[:, h] >> (3 * pd)
+
+
+def nbr_table(zs, grid, batch, depth, ksize, kmajor=False):
+    t = torch.from_numpy(OM.subm_neighbors(grid.numpy(), batch.numpy(), ksize)).int()
+    return t.t().contiguous() if kmajor else t
+
+
+def pad_plan(order, offs, offs_pad, patch, n_pad):
+    offs, offs_pad = offs.numpy().astype(np.int64), offs_pad.numpy().astype(np.int64)
+    gidx = np.empty(n_pad, dtype=np.int32)
+    widx = np.empty(n_pad, dtype=np.int32)
+    for b in range(len(offs) - 1):
+        nb = offs[b + 1] - offs[b]
+        for p in range(offs_pad[b], offs_pad[b + 1]):
+            local = p - offs_pad[b]
+            real = local < nb
+            rank = offs[b] + (local if real else local - patch)
+            g = rank if order is None else int(order[rank])
+            gidx[p] = g
+            widx[p] = g if real else -1
+    return torch.from_numpy(gidx), torch.from_numpy(widx)
+
+
+def _act(v, act):
+    if act == ACT_GELU:
+        return F.gelu(v)
+    if act == ACT_SWISH:
+        return v * torch.sigmoid(v)
+    return v
+
+
+def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
+         nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1):
+    assert A.dtype == W.dtype
+    Af, Wf = A.float(), W.float()
+    if nbr is None:
+        v = Af @ Wf.t()
+    else:
+        K = W.shape[1] // kvol
+        v = torch.zeros(nbr.shape[0], W.shape[0])
+        for o in range(kvol):
+            j = nbr[:, o].long()
+            m = j >= 0
+            v[m] += Af[j[m]] @ Wf[:, o * K:(o + 1) * K].t()
+    if bias is not None:
+        v = v + bias
+    if scale is not None:
+        v = v * scale + shift
+    v = _act(v, act)
+    if out2 is not None and out2_pre_add:
+        out2.copy_(v.to(out2.dtype))
+    if res is not None:
+        v = v + res
+    if add_src is not None:
+        v = v + add_src[add_idx.long()]
+    if out_idx is not None:
+        out[out_idx.long()] = v.to(out.dtype)
+    else:
+        out.copy_(v.to(out.dtype))
+    if out2 is not None and not out2_pre_add:
+        out2.copy_(v.to(out2.dtype))
+    return out
+
+
+def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):
+    kvol, cin, cout = w_packed.shape
+    v = torch.zeros(x.shape[0], cout)
+    for k in range(kvol):
+        j = nbr_kmajor[k].long()
+        m = j >= 0
+        v[m] += x[j[m]] @ w_packed[k]
+    v = F.gelu(v * scale + shift)
+    out.copy_(v)
+    if out2 is not None:
+        out2.copy_(v.to(out2.dtype))
+    return out
+
+
+def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=None):
+    v = F.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps)
+    if res is not None:
+        v = v + res
+    if colbias is not None:
+        v = v + colbias
+    out.copy_(v.to(out.dtype))
+    if out2 is not None:
+        out2.copy_(v.to(out2.dtype))
+    return out
+
+
+def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out):
+    ps = patch_start.numpy().astype(np.int64)
+    assert int(np.diff(ps).max()) == max_len
+    qq, kk, vv = q.float()[q_gidx.long()], k.float()[kv_gidx.long()], v.float()[kv_gidx.long()]
+    o = OM._patch_attention(qq, kk, vv, ps, num_heads, scale)
+    m = widx >= 0
+    out[widx[m].long()] = o[m].to(out.dtype)
+    return out
+
+
+def segment_max(y, seg_start, m, scale, shift, act, out, out2=None):
+    seg = seg_start[:m + 1].long()
+    cluster = np.repeat(np.arange(m), np.diff(seg.numpy()))
+    v = OM.segment_max(y.float(), cluster, m)
+    if scale is not None:
+        v = v * scale + shift
+    v = _act(v, act)
+    out.copy_(v)
+    if out2 is not None:
+        out2.copy_(v.to(out2.dtype))
+    return out
+
+
+def segment_mean(x, seg_start, m):
+    seg = seg_start[:m + 1].long()
+    cluster = np.repeat(np.arange(m), np.diff(seg.numpy()))
+    return OM.segment_mean(x, cluster, m)
+
+
+def gemv(w, b, x, act=ACT_NONE):
+    return _act(w @ x + b, act)
+
+
+def randn(shape, seed, offset, device):
+    g = torch.Generator().manual_seed((seed + offset) & 0x7FFFFFFF)
+    return torch.randn(shape, generator=g)
+
+
+def cast(src, dtype):
+    return src.to(dtype)
+
+
+def axpy(a, b, alpha):
+    return a + alpha * b

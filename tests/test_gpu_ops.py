@@ -1,0 +1,409 @@
+"""GPU: every HIP kernel, called through the C ABI (cdsegnet_amd.ops -> libcdseg_hip.so), against
+the CPU oracle on the same seeded inputs.  Integer work must be bit-exact; fp32 kernels within
+1e-4..1e-3 of the fp32 oracle (tolerances written at each assert); bf16 kernels within bf16
+rounding of the fp32 oracle evaluated on bf16-rounded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import model as OM
+from oracle import serialization as S
+from tests.helpers import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+CLOUDS = ["tiny64", "room1500", "batch2", "lidar5000", "rand16"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cdsegnet_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def report(name, **kw):
+    print(f"[measure] {name}: " + ", ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in kw.items()))
+
+
+# ------------------------------------------------------------------ integer kernels (bit-exact)
+@pytest.mark.parametrize("name", CLOUDS)
+def test_serialization_bit_exact_vs_reference_golden(ops, name):
+    fx = load_fixture(f"serialization_{name}.npz")
+    grid, batch = dev(fx["grid_coord"]), dev(fx["batch"])
+    assert int(ops.grid_max(grid).item()).bit_length() == int(fx["depth"])
+    b32 = ops.offset2batch(dev(fx["offset"]), len(fx["batch"]))
+    assert np.array_equal(b32.cpu().numpy(), fx["batch"])
+    code, order, inverse, depth = ops.serialization(grid, batch)
+    assert depth == int(fx["depth"])
+    assert np.array_equal(code.cpu().numpy(), fx["code"])
+    assert np.array_equal(order.cpu().numpy(), fx["order"])
+    assert np.array_equal(inverse.cpu().numpy(), fx["inverse"])
+    # int32 grid / batch inputs take a different kernel instantiation
+    for o in range(4):
+        c = ops.encode(grid.int(), batch.int(), depth, o)
+        assert np.array_equal(c.cpu().numpy(), fx["code"][o])
+
+
+def test_encode_known_answers_and_empty(ops):
+    ka = load_fixture("known_answers.npz")
+    g = dev(ka["grid"])
+    for o in S.ORDERS:
+        assert np.array_equal(ops.encode(g, None, 9, o).cpu().numpy(), ka[o])
+    empty = torch.empty((0, 3), dtype=torch.int64, device="cuda")
+    assert ops.encode(empty, None, 9, "z").numel() == 0
+
+
+def test_sort_pairs_large_random(ops):
+    rng = np.random.default_rng(0)
+    keys = rng.integers(0, 2 ** 48, 300000)
+    ks, perm = ops.sort_pairs(dev(keys), None, end_bit=48)
+    ref = np.argsort(keys, kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), ref)
+    assert np.array_equal(ks.cpu().numpy(), keys[ref])
+    inv = ops.invert_perm(perm).cpu().numpy()
+    assert np.array_equal(inv[ref], np.arange(len(keys)))
+
+
+def _physical(ops, fx):
+    """z-sorted ("physical") view of a fixture cloud, the engine's internal layout."""
+    grid, batch = dev(fx["grid_coord"]), dev(fx["batch"])
+    depth = int(fx["depth"])
+    zc = ops.encode(grid, batch, depth, "z")
+    zs, perm0 = ops.sort_pairs(zc)
+    g0, b0 = ops.plan_gather_grid(grid, perm0, zs, depth)
+    p = perm0.cpu().numpy()
+    assert np.array_equal(g0.cpu().numpy(), fx["grid_coord"][p])
+    assert np.array_equal(b0.cpu().numpy(), fx["batch"][p])
+    return zs, perm0, g0, b0, depth, p
+
+
+@pytest.mark.parametrize("name", CLOUDS)
+@pytest.mark.parametrize("pd", [1, 2])
+def test_pooling_structure_vs_reference_golden(ops, name, pd):
+    fx = load_fixture(f"serialization_{name}.npz")
+    stride = {1: 2, 2: 4}[pd]
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    code4 = ops.encode4(g0, b0, depth)
+    assert np.array_equal(code4.cpu().numpy(), fx["code"][:, p])
+    cluster, seg, cnt = ops.pool_level(zs, 3 * pd)
+    m = int(cnt.item())
+    ref_cluster = fx[f"pool{stride}_cluster"]
+    assert m == ref_cluster.max() + 1
+    cl = cluster.cpu().numpy()
+    # same partition as the reference (cluster ids are numbered by the z curve here, by code[0] = z there)
+    assert np.array_equal(cl, ref_cluster[p])
+    sg = seg.cpu().numpy()[:m + 1]
+    assert sg[0] == 0 and sg[-1] == n and np.all(np.diff(sg) > 0)
+    assert np.array_equal(cl[sg[:-1]], np.arange(m)) and np.all(np.diff(cl) >= 0)
+    gc, bc, cc = ops.pool_gather(seg, m, n, pd, g0, b0, code4)
+    # pooled level is again z-sorted: compare with the reference's pooled arrays sorted by its z code
+    rorder = fx[f"pool{stride}_order"][0]
+    assert np.array_equal(cc.cpu().numpy(), fx[f"pool{stride}_code"][:, rorder])
+    assert np.array_equal(gc.cpu().numpy(), fx[f"pool{stride}_grid"][rorder])
+    assert np.array_equal(bc.cpu().numpy(), fx[f"pool{stride}_batch"][rorder])
+
+
+@pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000"])
+@pytest.mark.parametrize("ksize", [3, 5])
+def test_neighbour_table_vs_oracle(ops, name, ksize):
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    ref = OM.subm_neighbors(fx["grid_coord"][p], fx["batch"][p], ksize)  # indices already in physical numbering
+    nbr = ops.nbr_table(zs, g0, b0, depth, ksize).cpu().numpy()
+    assert np.array_equal(nbr, ref)
+    nbr_t = ops.nbr_table(zs, g0, b0, depth, ksize, kmajor=True).cpu().numpy()
+    assert np.array_equal(nbr_t, ref.T)
+
+
+@pytest.mark.parametrize("name", CLOUDS)
+@pytest.mark.parametrize("K", [4, 16, 1024])
+def test_pad_plan_vs_reference_golden(ops, name, K):
+    fx = load_fixture(f"serialization_{name}.npz")
+    pad, unpad = fx[f"pad_K{K}"], fx[f"unpad_K{K}"]
+    n = len(fx["batch"])
+    offs = np.concatenate([[0], fx["offset"]]).astype(np.int32)
+    counts = np.diff(offs)
+    pc = np.where(counts > K, (counts + K - 1) // K * K, counts)
+    offs_pad = np.concatenate([[0], np.cumsum(pc)]).astype(np.int32)
+    assert offs_pad[-1] == len(pad)
+    order = fx["order"][2].astype(np.int32)  # any curve; ranks -> rows
+    gidx, widx = ops.pad_plan(dev(order), dev(offs), dev(offs_pad), K, int(offs_pad[-1]))
+    gidx, widx = gidx.cpu().numpy(), widx.cpu().numpy()
+    assert np.array_equal(gidx, order[pad])  # ptv3.py:259: order = serialized_order[i][pad]
+    # ptv3.py:260 inverse = unpad[serialized_inverse]: the kept slot of point j is unpad[rank_j]
+    inv = fx["inverse"][2]
+    kept = np.full(len(pad), -1, dtype=np.int64)
+    kept[unpad[inv]] = np.arange(n)
+    assert np.array_equal(widx, kept)
+    g2, w2 = ops.pad_plan(None, dev(offs), dev(offs_pad), K, int(offs_pad[-1]))
+    assert np.array_equal(g2.cpu().numpy(), pad)
+
+
+# ------------------------------------------------------------------ GEMM
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 96, 32), (777, 20, 64), (4096, 128, 128), (300, 512, 512), (65, 2048, 512),
+                                   (130, 40, 16), (5000, 64, 2048)])
+def test_gemm_plain(ops, dtype, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    if dtype == torch.bfloat16:
+        A, W = _bf16_round(A), _bf16_round(W)
+    ref = A.double() @ W.double().t() + b.double()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm(dev(A, dtype), dev(W, dtype), out, bias=dev(b))
+    err = (out.cpu().double() - ref).abs().max().item()
+    report(f"gemm {dtype} {M}x{N}x{K}", max_err=err)
+    assert err < (2e-5 * K ** 0.5 + 1e-5)  # fp32 accumulation of exactly-representable products
+    # GELU + residual + second (bf16) copy, asymmetric on purpose (catches transposed C layouts)
+    out2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(dev(A, dtype), dev(W, dtype), out, bias=dev(b), act=ops.ACT_GELU, res=dev(res), out2=out2)
+    ref2 = F.gelu(ref.float()).double() + res.double()
+    err2 = (out.cpu().double() - ref2).abs().max().item()
+    assert err2 < (2e-5 * K ** 0.5 + 1e-4), err2
+    assert (out2.float().cpu() - ref2.float()).abs().max().item() < 0.02 * ref2.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_bn_gather_add_scatter(ops, dtype):
+    g = torch.Generator().manual_seed(3)
+    M, N, K, Mc = 1500, 64, 128, 400
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    if dtype == torch.bfloat16:
+        A, W = _bf16_round(A), _bf16_round(W)
+    b, sc, sh = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    child = torch.randn(Mc, N, generator=g)
+    idx = torch.randint(0, Mc, (M,), generator=g).int()
+    perm = torch.randperm(M, generator=g).int()
+    pre = F.gelu(((A.double() @ W.double().t() + b.double()) * sc.double() + sh.double()).float())
+    ref = pre + child[idx.long()]
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    out2 = torch.zeros(M, N, dtype=dtype, device="cuda")
+    ops.gemm(dev(A, dtype), dev(W, dtype), out, bias=dev(b), scale=dev(sc), shift=dev(sh), act=ops.ACT_GELU,
+             add_src=dev(child), add_idx=dev(idx), out_idx=dev(perm), out2=out2, out2_pre_add=True)
+    got = out.cpu()
+    assert (got[perm.long()] - ref).abs().max().item() < 5e-4
+    tol2 = 1e-4 if dtype == torch.float32 else 0.03
+    assert (out2.float().cpu() - pre).abs().max().item() < tol2 * (1 + pre.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name,C", [("room1500", 32), ("batch2", 64), ("lidar5000", 16), ("room1500", 128)])
+def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    nbr = ops.nbr_table(zs, g0, b0, depth, 3)
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n, C, generator=g)
+    w = torch.randn(C, 3, 3, 3, C, generator=g) / (27 * C) ** 0.5
+    b = torch.randn(C, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = _bf16_round(x), _bf16_round(w)
+    ref = OM.subm_conv3d(x, nbr.cpu().numpy().astype(np.int64), w, b)
+    out = torch.empty(n, C, dtype=torch.float32, device="cuda")
+    ops.gemm(dev(x, dtype), dev(w.reshape(C, -1), dtype), out, bias=dev(b), nbr=nbr, kvol=27)
+    err = (out.cpu() - ref).abs().max().item()
+    report(f"conv {dtype} {name} C={C}", max_err=err)
+    assert err < 2e-4
+
+
+@pytest.mark.parametrize("name,cin,cout", [("room1500", 6, 32), ("lidar5000", 4, 16), ("batch2", 6, 64)])
+def test_stem_conv_vs_oracle(ops, name, cin, cout):
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    nbr_t = ops.nbr_table(zs, g0, b0, depth, 5, kmajor=True)
+    g = torch.Generator().manual_seed(cin * cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 5, 5, 5, cin, generator=g) / (125 * cin) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    ref = F.gelu(OM.subm_conv3d(x, nbr_t.cpu().numpy().T.astype(np.int64), w, None) * sc + sh)
+    out = torch.empty(n, cout, dtype=torch.float32, device="cuda")
+    out2 = torch.empty(n, cout, dtype=torch.bfloat16, device="cuda")
+    wp = w.reshape(cout, 125, cin).permute(1, 2, 0).contiguous()
+    ops.stem_conv(dev(x), nbr_t, dev(wp), dev(sc), dev(sh), out, out2)
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    assert (out2.float().cpu() - ref).abs().max().item() < 0.01 * (1 + ref.abs().max().item())
+
+
+# ------------------------------------------------------------------ LayerNorm / pooling reduce / small ops
+@pytest.mark.parametrize("C", [16, 32, 48, 64, 128, 256, 512, 2048])
+def test_layernorm(ops, C):
+    g = torch.Generator().manual_seed(C)
+    M = 1237
+    x = torch.randn(M, C, generator=g) * 3 + 1
+    gm, bt = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    res, cb = torch.randn(M, C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gm, bt, 1e-5)
+    out = torch.empty(M, C, dtype=torch.float32, device="cuda")
+    ops.layernorm(dev(x), dev(gm), dev(bt), out)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    xr = dev(res)
+    ops.layernorm(dev(x), dev(gm), dev(bt), xr, res=xr, colbias=dev(cb))  # in place on the residual
+    assert (xr.cpu() - (ref + res + cb)).abs().max().item() < 2e-5
+    ob = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+    ops.layernorm(dev(x, torch.bfloat16), dev(gm), dev(bt), ob)
+    refb = F.layer_norm(_bf16_round(x), (C,), gm, bt, 1e-5)
+    assert (ob.float().cpu() - refb).abs().max().item() < 0.02 * (1 + refb.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segment_max_and_mean(ops, dtype):
+    g = torch.Generator().manual_seed(1)
+    m, C = 700, 64
+    counts = torch.randint(1, 9, (m,), generator=g)
+    seg = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)])
+    n = int(seg[-1])
+    y = torch.randn(n, C, generator=g)
+    if dtype == torch.bfloat16:
+        y = _bf16_round(y)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g)  # negative scales too: max must come first
+    cluster = np.repeat(np.arange(m), counts.numpy())
+    ref = F.gelu(OM.segment_max(y, cluster, m) * sc + sh)
+    out = torch.empty(m, C, dtype=torch.float32, device="cuda")
+    out2 = torch.empty(m, C, dtype=torch.bfloat16, device="cuda")
+    ops.segment_max(dev(y, dtype), dev(seg.int()), m, dev(sc), dev(sh), ops.ACT_GELU, out, out2)
+    assert (out.cpu() - ref).abs().max().item() < 1e-5
+    assert (out2.float().cpu() - ref).abs().max().item() < 0.01 * (1 + ref.abs().max().item())
+    xyz = torch.randn(n, 3, generator=g)
+    mean = ops.segment_mean(dev(xyz), dev(seg.int()), m)
+    assert (mean.cpu() - OM.segment_mean(xyz, cluster, m)).abs().max().item() < 1e-5
+
+
+def test_timestep_embedding_chain(ops):
+    """table row -> fc_t1 -> swish -> fc_t2 -> swish -> t_mlp == the reference's per-point chain (one row)."""
+    from cdsegnet_amd.models import calc_t_emb_table
+    ka = load_fixture("known_answers.npz")
+    table = calc_t_emb_table(1000, 128)
+    assert np.array_equal(table[999].numpy(), ka["t_emb_999_128"][0])
+    assert np.array_equal(table[[0, 1, 500, 999]].numpy(), ka["t_emb_multi_128"])
+    g = torch.Generator().manual_seed(0)
+    w1, b1 = torch.randn(512, 128, generator=g) / 11, torch.randn(512, generator=g)
+    w2, b2 = torch.randn(128, 512, generator=g) / 22, torch.randn(128, generator=g)
+    ref = OM.swish(F.linear(OM.swish(F.linear(table[999], w1, b1)), w2, b2))
+    v = ops.gemv(dev(w1), dev(b1), dev(table[999]), ops.ACT_SWISH)
+    v = ops.gemv(dev(w2), dev(b2), v, ops.ACT_SWISH)
+    assert (v.cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_randn_cast_axpy_gather(ops):
+    z = ops.randn((1 << 20,), 1234, 0, torch.device("cuda")).cpu()
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    assert abs((z ** 4).mean().item() - 3) < 0.05
+    z2 = ops.randn((1 << 20,), 1234, 1, torch.device("cuda")).cpu()
+    assert (z == z2).float().mean().item() < 1e-3
+    assert torch.equal(ops.randn((1 << 20,), 1234, 0, torch.device("cuda")).cpu(), z)
+    x = torch.randn(1000, 7)
+    assert torch.equal(ops.cast(dev(x), torch.bfloat16).cpu(), x.to(torch.bfloat16))
+    assert torch.allclose(ops.axpy(dev(x), dev(x), 0.5).cpu(), 1.5 * x)
+    idx = torch.randint(0, 1000, (333,)).int()
+    x8 = torch.randn(1000, 8)
+    assert torch.equal(ops.gather_rows(dev(x8), dev(idx)).cpu(), x8[idx.long()])
+
+
+# ------------------------------------------------------------------ attention
+def _attention_case(ops, dtype, lens_pts, H, K, seed, cross=False):
+    """lens_pts: points per batch element.  Builds the reference's padded patch structure with the oracle,
+    runs the oracle attention on (bf16-rounded) inputs and the HIP kernel through the slot plan."""
+    g = torch.Generator().manual_seed(seed)
+    C = 16 * H
+    offset = np.cumsum(lens_pts)
+    n = int(offset[-1])
+    qkv = torch.randn(n, 3 * C, generator=g)
+    qkv[:, :C] *= 2.0  # sharper softmax
+    if dtype == torch.bfloat16:
+        qkv = _bf16_round(qkv)
+    # a random "serialized order" that keeps batch elements contiguous
+    order = np.concatenate([s + torch.randperm(int(c), generator=g).numpy() for s, c in
+                            zip(np.concatenate([[0], offset[:-1]]), lens_pts)]).astype(np.int64)
+    order_kv = order if not cross else np.concatenate(
+        [s + torch.randperm(int(c), generator=g).numpy() for s, c in zip(np.concatenate([[0], offset[:-1]]), lens_pts)])
+    inverse = np.empty(n, dtype=np.int64)
+    inverse[order] = np.arange(n)
+    pad, unpad, cu = S.padding_plan(offset, K)
+    q = qkv[:, :C][torch.from_numpy(order[pad])]
+    k = qkv[:, C:2 * C][torch.from_numpy(order_kv[pad])]
+    v = qkv[:, 2 * C:][torch.from_numpy(order_kv[pad])]
+    scale = 16 ** -0.5
+    ref = OM._patch_attention(q, k, v, cu, H, scale)[torch.from_numpy(unpad[inverse])]
+    # HIP path
+    offs = np.concatenate([[0], offset]).astype(np.int32)
+    counts = np.diff(offs)
+    pc = np.where(counts > K, (counts + K - 1) // K * K, counts)
+    offs_pad = np.concatenate([[0], np.cumsum(pc)]).astype(np.int32)
+    n_pad = int(offs_pad[-1])
+    gq, wq = ops.pad_plan(dev(order.astype(np.int32)), dev(offs), dev(offs_pad), K, n_pad)
+    gkv, _ = ops.pad_plan(dev(order_kv.astype(np.int32)), dev(offs), dev(offs_pad), K, n_pad)
+    d_qkv = dev(qkv, dtype)
+    out = torch.full((n, C), float("nan"), dtype=dtype, device="cuda")
+    ops.attention(d_qkv[:, :C], d_qkv[:, C:2 * C], d_qkv[:, 2 * C:], gq, gkv, wq, dev(cu.astype(np.int32)), H,
+                  int(np.diff(cu).max()), scale, out)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all(), "some rows were never written / non-finite"
+    return (got - ref).abs().max().item(), ref.abs().max().item()
+
+
+@pytest.mark.parametrize("lens,H,K", [([2500], 2, 1024), ([1024], 4, 1024), ([991], 32, 1024), ([26], 4, 1024),
+                                      ([1500, 1100], 2, 1024), ([700, 500, 3000], 1, 1024), ([10], 1, 4),
+                                      ([100, 37], 2, 16), ([1025], 8, 1024), ([33], 2, 1024)])
+def test_attention_fp32_vs_oracle(ops, lens, H, K):
+    err, mag = _attention_case(ops, torch.float32, lens, H, K, seed=sum(lens) + H)
+    report(f"attn fp32 lens={lens} H={H} K={K}", max_err=err, ref_max=mag)
+    assert err < 2e-5 * (1 + mag)  # exact-fp32 MFMA; differences = summation order + exp2 vs exp
+
+
+@pytest.mark.parametrize("lens,H,K", [([2500], 2, 1024), ([1024], 4, 1024), ([991], 32, 1024), ([26], 4, 1024),
+                                      ([1500, 1100], 2, 1024), ([700, 500, 3000], 1, 1024), ([10], 1, 4),
+                                      ([100, 37], 2, 16), ([1025], 8, 1024), ([33], 2, 1024)])
+def test_attention_bf16_vs_oracle(ops, lens, H, K):
+    err, mag = _attention_case(ops, torch.bfloat16, lens, H, K, seed=sum(lens) + H)
+    report(f"attn bf16 lens={lens} H={H} K={K}", max_err=err, ref_max=mag)
+    # inputs are bf16-exact; P is rounded to bf16 (2^-9 relative) and the output to bf16
+    assert err < 0.02 * (1 + mag)
+
+
+def test_cross_attention_vs_oracle(ops):
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 0.02)):
+        err, mag = _attention_case(ops, dtype, [991], 32, 1024, seed=7, cross=True)
+        assert err < tol * (1 + mag)
+        err, mag = _attention_case(ops, dtype, [1300, 1200], 4, 1024, seed=8, cross=True)
+        assert err < tol * (1 + mag)
+
+
+def test_attention_softmax_is_shift_safe(ops):
+    """Large score magnitudes (|s| ~ 60): the two-pass max must keep exp in range (no NaN / inf)."""
+    g = torch.Generator().manual_seed(0)
+    n, H = 1024, 2
+    C = 16 * H
+    qkv = torch.randn(n, 3 * C, generator=g)
+    qkv[:, :2 * C] *= 6.0
+    order = torch.randperm(n, generator=g).numpy()
+    inverse = np.empty(n, dtype=np.int64)
+    inverse[order] = np.arange(n)
+    t_order = torch.from_numpy(order)
+    ref = OM._patch_attention(qkv[:, :C][t_order], qkv[:, C:2 * C][t_order], qkv[:, 2 * C:][t_order],
+                              np.array([0, n]), H, 0.25)[torch.from_numpy(inverse)]
+    offs = dev(np.array([0, n], dtype=np.int32))
+    gq, wq = ops.pad_plan(dev(order.astype(np.int32)), offs, offs, 1024, n)
+    d = dev(qkv)
+    out = torch.empty(n, C, dtype=torch.float32, device="cuda")
+    ops.attention(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], gq, gq, wq, offs, H, n, 0.25, out)
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
