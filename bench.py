@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py - CDSegNet single-step inference throughput on MI355X (points/s/node).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-attention
+fusion) over one synthetic ScanNet-shaped scene per GPU (BASELINE.json configs[1]: ~120k voxels,
+6-ch features, 20 classes, bf16), inputs already resident in HBM.  Scenes are independent units:
+each rank runs its own scene, no data-path collective ("scaling": "weak").  RCCL is used once to
+broadcast the weights from rank 0 and for the final timing / counter reductions.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = serialized window attention,
+HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cdsegnet_amd import configs, ops, synth  # noqa: E402
+from cdsegnet_amd.param_init import fill_state_dict  # noqa: E402
+from cdsegnet_amd.registry import build_model  # noqa: E402
+import cdsegnet_amd.models  # noqa: E402,F401
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=120000)
+    ap.add_argument("--dataset", default="scannet", choices=["scannet", "scannet200", "nuscenes"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-baseline", dest="cpu_baseline", action="store_true", default=True)
+    ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
+    ap.add_argument("--cpu-points", type=int, default=12000)
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, points, dataset):
+    """The CPU oracle (our PyTorch-CPU fp32 port of the reference path) on a bounded sample."""
+    from oracle import model as OM
+    sc = synth.lidar_scene(100, points) if dataset == "nuscenes" else synth.room_scene(100, points)
+    n = len(sc["coord"])
+    inp = {k: sc[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    draws = OM.draw_rng(1, n, cfg["c_in_channels"])
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"])
+    dt = time.time() - t0
+    return dict(value=n / dt, unit="points/s", cores=threads, kind="port",
+                sample=f"1 scene x {n} points (same generator/model as the GPU run, fp32, PyTorch-CPU oracle), {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = configs.cdsegnet_config(args.dataset)
+    model = build_model(cfg)
+    sd = None
+    if rank == 0:
+        sd = fill_state_dict(model.state_dict(), seed=0)  # random-init weights of the named architecture
+        model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    if world > 1:  # weights: one RCCL broadcast from rank 0 (replaces the reference's DDP-ctor broadcast)
+        flat = torch.cat([p.detach().reshape(-1).float() for p in model.state_dict().values()])
+        dist.broadcast(flat, src=0)
+        off = 0
+        with torch.no_grad():
+            for p in model.state_dict().values():
+                p.copy_(flat[off:off + p.numel()].reshape(p.shape).to(p.dtype))
+                off += p.numel()
+        model._drop_engine()
+    model.precision = args.precision
+    model.noise_source = "device"  # noise-branch input drawn by the Philox kernel (no host RNG + PCIe in the step)
+
+    sc = synth.lidar_scene(rank, args.points) if args.dataset == "nuscenes" else synth.room_scene(rank, args.points)
+    n = len(sc["coord"])
+    inp = {k: torch.as_tensor(sc[k]).to(dev) for k in ("coord", "grid_coord", "feat", "offset")}
+    inp["offset_host"] = [int(v) for v in sc["offset"]]
+    torch.manual_seed(54421566 + rank)
+
+    def step():
+        return model.inference(dict(inp), eval=False)["seg_logits"]
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    assert torch.isfinite(out).all()
+
+    # label histogram of the last step: the per-scene record the reference gathers (test.py:374)
+    hist = torch.bincount(out.argmax(1), minlength=out.shape[1]).to(torch.int64)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    pts = torch.tensor([n], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    total_pts = int(pts.item())
+
+    if rank == 0:
+        res = {
+            "metric": "points/sec/node (ScanNet ~120k-pt scenes, 1-step)",
+            "value": total_pts * args.steps / elapsed,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision if args.precision != "fp32" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.dataset}-shape {n}-point scene per GPU, CDSegNet 1-step inference "
+                                   f"(PT-v3m1 dual backbone, 101.4M params, random-init), 1 scene/step/GPU",
+                       "points_per_scene": n, "precision": args.precision, "scenes_per_step_per_gpu": 1,
+                       "noise": "device Philox"},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            att = summ.get("attention")
+            if att and att["ms"] > 0:
+                achieved = att["work"] / (att["ms"] * 1e-3) / 1e12
+                peak = PEAK_TFLOPS[args.precision]
+                res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": achieved / peak, "traffic": None,
+                                   "kernel": "attn_bf16_kernel" if args.precision == "bf16" else "attn_f32_kernel",
+                                   "launches_per_step": att["launches"] / args.steps,
+                                   "avg_launch_us": 1e3 * att["ms"] / att["launches"],
+                                   "algorithmic_gflop_per_step": att["work"] / args.steps / 1e9}
+            res["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in summ.items()}
+        if args.cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_points, args.dataset)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

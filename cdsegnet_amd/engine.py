@@ -63,7 +63,7 @@ class Level:
         return self._nbr[key]
 
     def pad(self, patch_size, enable_flash):
-        """(K, n_pad, offs_dev, offs_pad_dev, patch_start_dev, max_len) - ref: ptv3.py:188-250."""
+        """(K, n_pad, offs_dev, offs_pad_dev, patch_start_dev, max_len, sum_L2) - ref: ptv3.py:188-250."""
         key = (patch_size, enable_flash)
         if key not in self._pad:
             counts = np.diff(np.asarray(self.offs_host, dtype=np.int64))
@@ -79,13 +79,14 @@ class Level:
             self._pad[key] = (K, int(offs_pad[-1]),
                               torch.tensor(np.asarray(self.offs_host, dtype=np.int32), device=dev),
                               torch.tensor(offs_pad.astype(np.int32), device=dev),
-                              torch.tensor(patch_start, device=dev), max_len)
+                              torch.tensor(patch_start, device=dev), max_len,
+                              float((np.diff(patch_start).astype(np.float64) ** 2).sum()))
         return self._pad[key]
 
     def slots(self, curve, patch_size, enable_flash):
         key = (curve, patch_size, enable_flash)
         if key not in self._slots:
-            K, n_pad, offs, offs_pad, _, _ = self.pad(patch_size, enable_flash)
+            K, n_pad, offs, offs_pad = self.pad(patch_size, enable_flash)[:4]
             self._slots[key] = ops.pad_plan(self.order(curve), offs, offs_pad, K, n_pad)
         return self._slots[key]
 
@@ -318,10 +319,10 @@ class Engine:
         att = mod.attn
         curve = st.curves[att.order_index]
         gidx, widx = lv.slots(curve, att.patch_size, att.enable_flash)
-        _, _, _, _, patch_start, max_len = lv.pad(att.patch_size, att.enable_flash)
+        _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
         o = self._buf(n, c, self.T)
         ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
-                      att.scale, o)
+                      att.scale, o, work=64.0 * att.num_heads * sum_l2)
         ops.gemm(o, w[pre + ".proj.w"], st.x, bias=w[pre + ".proj.b"], res=st.x)
         self._mlp(st, pre + ".norm2", pre + ".fc")
 
@@ -394,9 +395,10 @@ class Engine:
         K = att.q_patch_size
         q_gidx, widx = lv.slots(nst.curves[att.order_index], K, att.enable_flash)
         kv_gidx, _ = lv.slots(cst.curves[att.order_index], K, att.enable_flash)
-        _, _, _, _, patch_start, max_len = lv.pad(K, att.enable_flash)
+        _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(K, att.enable_flash)
         o = self._buf(n, cq, self.T)
-        ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o)
+        ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o,
+                      work=64.0 * att.num_heads * sum_l2)
         if cb.tm_feat == 1.0:
             ops.gemm(o, w["x.proj.w"], nst.x, bias=w["x.proj.b"], res=nst.x)
         else:  # q_shortcut + feat_scale * attn

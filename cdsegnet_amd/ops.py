@@ -17,6 +17,47 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _WS = {}
 
 
+class KernelTimer:
+    """HIP-event timing of selected ops on the stream they are launched on (torch's current
+    stream).  bench.py installs one over the timed region to get per-kernel durations live."""
+
+    def __init__(self, names=("attention", "gemm", "conv")):
+        self.names = set(names)
+        self.events = []
+
+    def begin(self, name):
+        if name not in self.names:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, e0)
+
+    def end(self, tok, work=0.0):
+        if tok is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events.append((tok[0], tok[1], e1, work))
+
+    def summary(self):
+        """name -> dict(launches, ms, work) ; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, e0, e1, work in self.events:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
+TIMER = None
+
+
+def set_timer(t):
+    global TIMER
+    TIMER = t
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -220,7 +261,10 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     for t in (bias, scale, shift, res, add_src):
         if t is not None and t.dtype != torch.float32:
             raise _lib.CdsegError("gemm epilogue vectors / residuals are float32")
+    tok = TIMER.begin("conv" if nbr is not None else "gemm") if TIMER is not None else None
     check(_lib.load().cdseg_gemm(ctypes.byref(a), _stream()), "gemm")
+    if tok is not None:
+        TIMER.end(tok, 2.0 * a.M * a.N * a.K * a.kvol)
     return out
 
 
@@ -248,15 +292,19 @@ def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=Non
     return out
 
 
-def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out):
-    """q/k/v: 2-D views (rows, H*16) of the projection buffers (any row stride); out (rows, H*16)."""
+def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out, work=0.0):
+    """q/k/v: 2-D views (rows, H*16) of the projection buffers (any row stride); out (rows, H*16).
+    work: algorithmic FLOPs of this launch (4 * 16 * H * sum_p L_p^2), only used by the bench timer."""
     num_patches = patch_start.numel() - 1
     if not (q.dtype == k.dtype == v.dtype == out.dtype):
         raise _lib.CdsegError("attention: q, k, v, out must share a dtype")
+    tok = TIMER.begin("attention") if TIMER is not None else None
     check(_lib.load().cdseg_attention(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),
                                       _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads),
                                       int(max_len), float(scale), _ptr(out), out.stride(0), dt(q), _stream()),
           "attention")
+    if tok is not None:
+        TIMER.end(tok, work)
     return out
 
 

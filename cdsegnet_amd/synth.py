@@ -61,14 +61,17 @@ def _dense_samples(rng, faces, step, voxel):
     return np.concatenate(cs), np.concatenate(ns), np.concatenate(ls)
 
 
-def room_scene(seed=0, target_points=120000, voxel=0.02, num_classes=20, n_boxes=10, exact=True):
-    """ScanNet-shaped scene: a room (4:3 floor plan, 2.6 m high) with box furniture, densely
-    scanned surfaces (about 9 occupied cells per 3x3x3 neighbourhood, like real 2 cm
-    ScanNet voxels), sized so that it voxelises to ~target_points (exactly if exact)."""
+def room_scene(seed=0, target_points=120000, voxel=0.02, num_classes=20, n_boxes=10, exact=True, occupancy=0.55):
+    """ScanNet-shaped scene: a room (4:3 floor plan, 2.6 m high) with box furniture; surfaces are
+    one voxel thick and `occupancy` of their 2 cm cells are hit by the scan, which reproduces the
+    stage sizes of a real ScanNet scene through the stride-2 poolings (the reference's in-code
+    trace ptv3.py:1785-1794: 265838 -> 115601 -> 32435 -> 8428 -> 2196, ratios .435/.28/.26/.26).
+    Sized so that it voxelises to ~target_points (exactly if exact)."""
     rng = np.random.default_rng(seed)
     lz = 2.6
-    # solve 2(lx*ly + (lx+ly)*lz) ~= 0.8 * target * voxel^2 for lx with ly = 0.75 lx (boxes add the rest)
-    area = 0.8 * target_points * voxel * voxel
+    dense_target = target_points / occupancy
+    # solve 2(lx*ly + (lx+ly)*lz) ~= 0.8 * dense_target * voxel^2 for lx with ly = 0.75 lx (boxes add the rest)
+    area = 0.8 * dense_target * voxel * voxel
     lx = max(0.6, (-3.5 * lz + np.sqrt((3.5 * lz) ** 2 + 4 * 1.5 * area)) / (2 * 1.5))
     if lx < 1.5:
         lz = max(0.5, lx)
@@ -80,11 +83,12 @@ def room_scene(seed=0, target_points=120000, voxel=0.02, num_classes=20, n_boxes
         coord, normal, label = _dense_samples(rng, faces, 0.6 * voxel, voxel)
         coord = coord + rng.normal(0, 0.1 * voxel, coord.shape)  # sensor noise
         idx, grid = voxelize(coord, voxel)
-        if len(idx) >= target_points and (not exact or len(idx) <= 1.12 * target_points):
+        if len(idx) >= dense_target and len(idx) <= 1.12 * dense_target:
             break
-        scale *= (1.05 * target_points / len(idx)) ** 0.5
-    if exact and len(idx) > target_points:
-        keep = np.sort(rng.choice(len(idx), size=target_points, replace=False))
+        scale *= (1.05 * dense_target / len(idx)) ** 0.5
+    n_keep = target_points if exact else int(round(len(idx) * occupancy))
+    if len(idx) > n_keep:
+        keep = np.sort(rng.choice(len(idx), size=n_keep, replace=False))
         idx, grid = idx[keep], grid[keep]
         grid = grid - grid.min(0)
     # the loader hands points over in arbitrary (hash) order, not voxel-key order

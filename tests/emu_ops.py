@@ -176,7 +176,7 @@ def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=Non
     return out
 
 
-def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out):
+def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out, work=0.0):
     ps = patch_start.numpy().astype(np.int64)
     assert int(np.diff(ps).max()) == max_len
     qq, kk, vv = q.float()[q_gidx.long()], k.float()[kv_gidx.long()], v.float()[kv_gidx.long()]

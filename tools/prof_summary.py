@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace --stats result (rocpd sqlite .db) as text:
+per-kernel totals and per launch-shape averages.  usage: prof_summary.py results.db [steps]"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    name = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", name)
+    return name if len(name) <= 110 else name[:107] + "..."
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    cur = db.cursor()
+    rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                            "from kernels group by name order by sum(duration) desc"))
+    total = sum(r[2] for r in rows)
+    print(f"# kernel totals (all dispatches in the run; {steps:g} steps incl. warm-up); total GPU kernel time "
+          f"{total / 1e6:.3f} ms = {total / 1e6 / steps:.3f} ms/step")
+    print(f"{'calls':>7} {'total_ms':>10} {'ms/step':>9} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'%':>6}  name")
+    for n, c, s, a, mn, mx in rows:
+        print(f"{c:7d} {s / 1e6:10.3f} {s / 1e6 / steps:9.3f} {a / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} "
+              f"{100 * s / total:6.2f}  {short(n)}")
+    print("\n# per launch shape (grid in threads) for the GEMM / conv / attention kernels")
+    rows = list(cur.execute(
+        "select name, grid_x, grid_y, count(*), avg(duration), sum(duration) from kernels "
+        "where name like '%gemm_kernel%' or name like '%attn_%' or name like '%stem_conv%' "
+        "group by name, grid_x, grid_y order by sum(duration) desc"))
+    for n, gx, gy, c, a, s in rows:
+        print(f"{c:7d} {s / 1e6 / steps:9.3f} ms/step {a / 1e3:9.2f} us  grid=({gx},{gy})  {short(n)}")
+
+
+if __name__ == "__main__":
+    main()
