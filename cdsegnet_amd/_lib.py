@@ -30,6 +30,7 @@ class GemmArgs(Structure):
         ("lda", c_int), ("ldo", c_int), ("ldo2", c_int), ("ldres", c_int), ("ldadd", c_int),
         ("a_dtype", c_int), ("compute_dtype", c_int), ("out_dtype", c_int), ("out2_dtype", c_int),
         ("act", c_int), ("out2_pre_add", c_int),
+        ("ws", c_void_p), ("ws_bytes", c_size_t),
     ]
 
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     "cdseg_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_randn": (c_int, [c_void_p, c_long, c_uint64, c_uint64, c_void_p]),
     "cdseg_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
+    "cdseg_gather_pad_cast": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p]),
     "cdseg_axpy": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
 }
 

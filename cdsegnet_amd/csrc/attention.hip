@@ -49,7 +49,53 @@ constexpr int KS_BYTES_F32 = 1024 * 64;
 constexpr int SMEM_F32 = KS_BYTES_F32 + 16 * VT_STRIDE_F32;
 
 // ------------------------------------------------------------------------------------ bf16
-__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
+constexpr int ATTN_THREADS = 512;  // 8 waves: 2 per SIMD per block, 2 blocks per CU (LDS 69 KB each)
+constexpr int ATTN_WAVES = ATTN_THREADS / 64;
+
+// one 32-key x 32-query tile of S^T = K Q^T
+__device__ __forceinline__ f32x16_t qk_tile(const char* Ks, int kt, int ql, int h, bf16x8_t qf) {
+  const int key = kt * 32 + ql;
+  const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + key * 32 + ((h ^ ((key >> 3) & 1)) << 4));
+  const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, z, 0, 0, 0);
+}
+
+__device__ __forceinline__ float tile_max(const f32x16_t& s, float m) {
+  const float a = fmaxf(fmaxf(s[0], s[1]), s[2]);
+  const float b = fmaxf(fmaxf(s[3], s[4]), s[5]);
+  const float c = fmaxf(fmaxf(s[6], s[7]), s[8]);
+  const float d = fmaxf(fmaxf(s[9], s[10]), s[11]);
+  const float e = fmaxf(fmaxf(s[12], s[13]), s[14]);
+  return fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), fmaxf(fmaxf(e, s[15]), m));
+}
+
+// P = exp2(S*c - m*c) for one tile, then O^T += [V^T; 1; 0] P^T (two K=16 MFMAs)
+template <bool TAIL>
+__device__ __forceinline__ void pv_tile(const f32x16_t& s, float c, float mc, int kt, int h, int L,
+                                        const char* vt_lane, f32x16_t& o) {
+  float pr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r] * c - mc);
+  if (TAIL) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) pr[r] = 0.f;
+  }
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    union { bf16x8_t v; uint32_t u[4]; } pf, vf;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
+    // k-slots 8h+j (j<4) <-> keys kbase + 4h + j ; (j>=4) <-> keys kbase + 8 + 4h + (j-4)
+    const char* vp = vt_lane + (kt * 32 + 16 * mf) * 2;
+    const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+    const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+    vf.u[0] = lo.x; vf.u[1] = lo.y; vf.u[2] = hi.x; vf.u[3] = hi.y;
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vt = smem + KS_BYTES_BF16;
@@ -66,27 +112,39 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
   const bf16_t* kb = (const bf16_t*)p.k + head * 16;
   const bf16_t* vb = (const bf16_t*)p.v + head * 16;
 
-  // ---- stage K (row-major, 16-B halves swizzled) and V^T (+ ones row, zero row)
-  for (int s = tid; s < Lp; s += 256) {
-    uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
-    if (s < L) {
-      const long g = p.kv_gidx[ps + s];
+  // ---- stage K (row-major, 16-B halves swizzled) and V^T (+ ones row, zero row).
+  // One thread per key PAIR: 8 independent 16-B gathers in flight, V^T written as packed dwords.
+  for (int pr = tid; pr < (Lp >> 1); pr += ATTN_THREADS) {
+    const int s0 = 2 * pr, s1 = s0 + 1;
+    uint4 k0[2], k1[2], v0[2], v1[2];
+    k0[0] = k0[1] = k1[0] = k1[1] = v0[0] = v0[1] = v1[0] = v1[1] = make_uint4(0, 0, 0, 0);
+    if (s0 < L) {
+      const long g = p.kv_gidx[ps + s0];
       const uint4* kr = reinterpret_cast<const uint4*>(kb + g * p.ldk);
       const uint4* vr = reinterpret_cast<const uint4*>(vb + g * p.ldv);
-      k0 = kr[0]; k1 = kr[1];
-      v0 = vr[0]; v1 = vr[1];
+      k0[0] = kr[0]; k0[1] = kr[1]; v0[0] = vr[0]; v0[1] = vr[1];
     }
-    const int sw = (s >> 3) & 1;
-    *reinterpret_cast<uint4*>(Ks + s * 32 + ((0 ^ sw) << 4)) = k0;
-    *reinterpret_cast<uint4*>(Ks + s * 32 + ((1 ^ sw) << 4)) = k1;
-    const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (s1 < L) {
+      const long g = p.kv_gidx[ps + s1];
+      const uint4* kr = reinterpret_cast<const uint4*>(kb + g * p.ldk);
+      const uint4* vr = reinterpret_cast<const uint4*>(vb + g * p.ldv);
+      k1[0] = kr[0]; k1[1] = kr[1]; v1[0] = vr[0]; v1[1] = vr[1];
+    }
+    const int sw = (s0 >> 3) & 1;  // same for s1 (s0 even)
+    *reinterpret_cast<uint4*>(Ks + s0 * 32 + ((0 ^ sw) << 4)) = k0[0];
+    *reinterpret_cast<uint4*>(Ks + s0 * 32 + ((1 ^ sw) << 4)) = k0[1];
+    *reinterpret_cast<uint4*>(Ks + s1 * 32 + ((0 ^ sw) << 4)) = k1[0];
+    *reinterpret_cast<uint4*>(Ks + s1 * 32 + ((1 ^ sw) << 4)) = k1[1];
+    const uint32_t a[8] = {v0[0].x, v0[0].y, v0[0].z, v0[0].w, v0[1].x, v0[1].y, v0[1].z, v0[1].w};
+    const uint32_t b[8] = {v1[0].x, v1[0].y, v1[0].z, v1[0].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w};
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      *reinterpret_cast<uint16_t*>(Vt + (2 * d) * VT_STRIDE_BF16 + s * 2) = (uint16_t)(vw[d] & 0xffffu);
-      *reinterpret_cast<uint16_t*>(Vt + (2 * d + 1) * VT_STRIDE_BF16 + s * 2) = (uint16_t)(vw[d] >> 16);
+      *reinterpret_cast<uint32_t*>(Vt + (2 * d) * VT_STRIDE_BF16 + s0 * 2) = (a[d] & 0xffffu) | (b[d] << 16);
+      *reinterpret_cast<uint32_t*>(Vt + (2 * d + 1) * VT_STRIDE_BF16 + s0 * 2) = (a[d] >> 16) | (b[d] & 0xffff0000u);
     }
-    *reinterpret_cast<uint16_t*>(Vt + 16 * VT_STRIDE_BF16 + s * 2) = (s < L) ? (uint16_t)0x3F80 : (uint16_t)0;
-    *reinterpret_cast<uint16_t*>(Vt + 17 * VT_STRIDE_BF16 + s * 2) = 0;
+    *reinterpret_cast<uint32_t*>(Vt + 16 * VT_STRIDE_BF16 + s0 * 2) =
+        (s0 < L ? 0x3F80u : 0u) | (s1 < L ? 0x3F800000u : 0u);
+    *reinterpret_cast<uint32_t*>(Vt + 17 * VT_STRIDE_BF16 + s0 * 2) = 0u;
   }
   __syncthreads();
 
@@ -96,8 +154,10 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
   const char* vt_lane = Vt + vrow * VT_STRIDE_BF16 + h * 8;
   const float c = p.scale_log2e;
   const int nqt = (L + 31) >> 5;
+  const bool tail = (nkt << 5) != L;
+  const int nfull = tail ? nkt - 1 : nkt;  // key tiles that need no masking
 
-  for (int qt = blockIdx.y * 4 + wave; qt < nqt; qt += gridDim.y * 4) {
+  for (int qt = blockIdx.y * ATTN_WAVES + wave; qt < nqt; qt += gridDim.y * ATTN_WAVES) {
     const int qslot = qt * 32 + ql;
     const bool qvalid = qslot < L;
     bf16x8_t qf = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -106,49 +166,39 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
       qf = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)p.q + g * p.ldq + head * 16 + h * 8);
     }
     // ---- pass 1: row max of S^T = K Q^T (lane (q,h) sees keys (r&3) + 8*(r>>2) + 4h of each tile)
-    float mloc = -INFINITY;
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int key = kt * 32 + ql;
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + key * 32 + ((h ^ ((key >> 3) & 1)) << 4));
-      f32x16_t s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, s, 0, 0, 0);
-      if (kt * 32 + 32 > L) {
+    float m0 = -INFINITY, m1 = -INFINITY;
+    int kt = 0;
+    for (; kt + 1 < nfull; kt += 2) {  // two independent tiles in flight
+      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf);
+      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf);
+      m0 = tile_max(sa, m0);
+      m1 = tile_max(sb, m1);
+    }
+    for (; kt < nkt; ++kt) {
+      f32x16_t s = qk_tile(Ks, kt, ql, h, qf);
+      if (kt >= nfull) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[r] = -INFINITY;
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+      m0 = tile_max(s, m0);
     }
-    const float m = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    float m = fmaxf(m0, m1);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float mc = m * c;
     // ---- pass 2: P = exp2(S*c - m*c), O^T (+ row sums in row 16) += [V^T; 1; 0] P^T
     f32x16_t o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int key = kt * 32 + ql;
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + key * 32 + ((h ^ ((key >> 3) & 1)) << 4));
-      f32x16_t s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, s, 0, 0, 0);
-      float pr[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r] * c - mc);
-      if (kt * 32 + 32 > L) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) pr[r] = 0.f;
-      }
-#pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
-        union { bf16x8_t v; uint32_t u[4]; } pf, vf;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
-        // k-slots 8h+j (j<4) <-> keys kbase + 4h + j ; (j>=4) <-> keys kbase + 8 + 4h + (j-4)
-        const char* vp = vt_lane + (kt * 32 + 16 * mf) * 2;
-        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
-        vf.u[0] = lo.x; vf.u[1] = lo.y; vf.u[2] = hi.x; vf.u[3] = hi.y;
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o, 0, 0, 0);
-      }
+    kt = 0;
+    for (; kt + 1 < nfull; kt += 2) {
+      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf);
+      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf);
+      pv_tile<false>(sa, c, mc, kt, h, L, vt_lane, o);
+      pv_tile<false>(sb, c, mc, kt + 1, h, L, vt_lane, o);
+    }
+    for (; kt < nkt; ++kt) {
+      const f32x16_t s = qk_tile(Ks, kt, ql, h, qf);
+      if (kt >= nfull) pv_tile<true>(s, c, mc, kt, h, L, vt_lane, o);
+      else pv_tile<false>(s, c, mc, kt, h, L, vt_lane, o);
     }
     // ---- epilogue: O^T rows (r&3) + 8*(r>>2) + 4h; row 16 (lane h=0, r=8) is the denominator
     const float lsum = __shfl(o[8], ql, 64);
@@ -170,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------ f32
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
+__global__ __launch_bounds__(ATTN_THREADS) void attn_f32_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vt = smem + KS_BYTES_F32;
@@ -187,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
   const float* kb = (const float*)p.k + head * 16;
   const float* vb = (const float*)p.v + head * 16;
 
-  for (int s = tid; s < Lp; s += 256) {
+  for (int s = tid; s < Lp; s += ATTN_THREADS) {
     uint4 kk[4], vv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) kk[i] = vv[i] = make_uint4(0, 0, 0, 0);
@@ -216,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
   const float c = p.scale_log2e;
   const int nqt = (L + 15) >> 4;
 
-  for (int qt = blockIdx.y * 4 + wave; qt < nqt; qt += gridDim.y * 4) {
+  for (int qt = blockIdx.y * ATTN_WAVES + wave; qt < nqt; qt += gridDim.y * ATTN_WAVES) {
     const int qslot = qt * 16 + ql;
     const bool qvalid = qslot < L;
     f32x4_t qf = {0.f, 0.f, 0.f, 0.f};
@@ -292,15 +342,16 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
   p.out = out; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.num_heads = num_heads;
   p.scale_log2e = scale * 1.44269504088896340736f;
   hipStream_t s = (hipStream_t)stream;
-  // split each patch-head's queries over enough blocks to fill 256 CUs several times over
+  // K/V staging is per block, so split a patch-head's queries over as few blocks as still fill
+  // the chip (2 resident blocks per CU -> ~512 block slots)
   const int tile = dtype == CDSEG_F32 ? 16 : 32;
   const int nqt = (max_len + tile - 1) / tile;
-  int qsplit = (2048 + num_patches * num_heads - 1) / (num_patches * num_heads);
-  const int max_split = (nqt + 3) / 4;
-  if (qsplit > max_split) qsplit = max_split;
-  if (qsplit < 1) qsplit = 1;
-  if (qsplit > 8) qsplit = 8;
-  dim3 grid((unsigned)(num_patches * num_heads), (unsigned)qsplit), block(256);
+  // Powers of two so that every wave of every block gets the same number of query tiles.
+  const int ph = num_patches * num_heads;
+  int qsplit = ph >= 384 ? 1 : (ph >= 160 ? 2 : 4);
+  const int max_split = (nqt + ATTN_WAVES - 1) / ATTN_WAVES;
+  while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
+  dim3 grid((unsigned)(num_patches * num_heads), (unsigned)qsplit), block(ATTN_THREADS);
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BF16) !=

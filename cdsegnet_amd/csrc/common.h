@@ -24,16 +24,20 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
 
-// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16 cast)
+// float -> bfloat16, round-to-nearest-even (= torch's cast): the compiler lowers these to
+// gfx950's v_cvt_pk_bf16_f32, one instruction per pair
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const hw_f32x2_t v = {lo, hi};
+  const hw_bf16x2_t b = __builtin_convertvector(v, hw_bf16x2_t);
+  return __builtin_bit_cast(uint32_t, b);
 }
 
 template <typename T> struct Cvt;

@@ -245,6 +245,19 @@ __global__ void cast_kernel(const void* __restrict__ src, int sd, void* __restri
   else ((bf16_t*)dst)[i] = f32_to_bf16(v);
 }
 
+// dst[i, 0:cpad] = cast(src[idx[i], 0:cin]) zero-padded to cpad columns (stem input: 6 -> 8 channels)
+__global__ void gather_pad_cast_kernel(const float* __restrict__ src, int ld_src, const int32_t* __restrict__ idx,
+                                       long n, int cin, int cpad, void* __restrict__ dst, int dd) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * cpad) return;
+  const long r = t / cpad;
+  const int c = (int)(t - r * cpad);
+  const long sr = idx ? (long)idx[r] : r;
+  const float v = c < cin ? src[sr * ld_src + c] : 0.f;
+  if (dd == CDSEG_F32) ((float*)dst)[t] = v;
+  else ((bf16_t*)dst)[t] = f32_to_bf16(v);
+}
+
 __global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha,
                             float* __restrict__ out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -364,6 +377,17 @@ int cdseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n,
   if (n <= 0) return CDSEG_OK;
   hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, src_dtype,
                      dst, dst_dtype, n);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_gather_pad_cast(const float* src, int ld_src, const int32_t* idx, long n, int cin, int cpad, void* dst,
+                          int dst_dtype, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (cin <= 0 || cpad < cin) return CDSEG_ERR_ARG;
+  const long total = n * cpad;
+  hipLaunchKernelGGL(gather_pad_cast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, ld_src, idx, n, cin, cpad, dst, dst_dtype);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

@@ -4,18 +4,21 @@
 //   out = epilogue(sum_o A[nbr[:,o]] @ W[:,o,:]^T)       spconv.SubMConv3d as a gathered-A GEMM
 //                                                        (ref call sites: ptv3.py:356-362, 1106-1124)
 //
-// Tiling: workgroup = 4 waves (2 x 2) computes a 64 x BN output tile, K in steps of 32.
-//   bf16: v_mfma_f32_16x16x32_bf16, one MFMA per 16x16 tile per K-step
-//   f32 : v_mfma_f32_16x16x4_f32 x 8 per K-step (exact fp32, the parity mode)
-// A / W K-tiles are staged through LDS in 16-byte chunks with an XOR swizzle
-// (chunk ^= (row >> 1) & (chunks_per_row - 1)) that makes every ds_read_b128 of an MFMA fragment
-// bank-conflict free (tools/lds_conflicts.py); global loads for tile k+1 are issued before
-// the MFMAs of tile k (register double buffering).  The sparse-conv form gathers A rows through
-// the stage's neighbour table and skips (block-uniformly) every kernel offset no row of the tile
-// has a neighbour at - on z-ordered points that removes most of the 27 offsets' work.
-// Small N (32..2048) and huge M: the op is HBM/L2 bound at the early stages, so the epilogue
-// (bias, folded BatchNorm, GELU, residual, un-pooling gather-add, row scatter, second typed copy)
-// is fused to keep every activation to one write.
+// Workgroup = 4 waves (2 x 2) -> one 64 x BN output tile.
+//   bf16: v_mfma_f32_16x16x32_bf16;   f32 (parity mode): v_mfma_f32_16x16x4_f32 (exact fp32).
+// K runs in steps of one LDS row (RB bytes = 64 / 128 / 256: 32..128 bf16 or 32..64 f32 per step);
+// the wide step is what makes the deep sparse-conv reductions (K = 27 * C up to 13824) and the
+// C >= 128 linears run from a handful of barrier-separated iterations instead of hundreds.
+// A / W K-tiles are staged through LDS in 16-byte chunks with an XOR swizzle that makes every
+// ds_read_b128 of an MFMA fragment bank-conflict free (tools/lds_conflicts.py); global loads of
+// step k+1 are in flight during the MFMAs of step k (register double buffering).
+// Sparse conv: the block first compacts the kernel offsets that ANY of its 64 rows has a
+// neighbour at (on z-ordered points: ~10-15 of 27) and reduces over those only; A chunks are
+// gathered through the neighbour table per 16-byte chunk, so one K step can span several offsets
+// (C = 32: four offsets per 128-wide step).
+// Epilogue: the accumulator tile goes through LDS so that bias / folded BatchNorm / GELU /
+// residual / un-pooling gather-add / second typed copy / row scatter run on row-contiguous
+// float4 groups and every store is a full 16-byte (8-byte for bf16) coalesced access.
 #include "common.h"
 
 namespace {
@@ -38,23 +41,22 @@ struct GemmP {
   int lda, ldo, ldo2, ldres, ldadd;
   int out_dtype, out2_dtype;
   int act, out2_pre_add;
+  int vec_ok;  // all row strides / N multiples of 4 -> float4 epilogue
+  float* ws;   // split-K partial sums (splits, M, N) fp32, or nullptr
+  int splits;
 };
 
-template <typename CT> struct Tile;
-template <> struct Tile<bf16_t> {
-  static constexpr int ROW_BYTES = 64;  // 32 bf16
-  static constexpr int NCHUNK = 4;
-  static constexpr int CH_PER_PART = 1;  // a loader thread's 8 elements = 1 chunk
-};
-template <> struct Tile<float> {
-  static constexpr int ROW_BYTES = 128;  // 32 f32
-  static constexpr int NCHUNK = 8;
-  static constexpr int CH_PER_PART = 2;
-};
-
-template <typename CT>
+template <int NCH>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * Tile<CT>::ROW_BYTES + ((chunk ^ ((row >> 1) & (Tile<CT>::NCHUNK - 1))) << 4);
+  constexpr int RB = NCH * 16;
+  const int sw = NCH == 16 ? (row & 15) : ((row >> 1) & (NCH - 1));
+  return row * RB + ((chunk ^ sw) << 4);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == CDSEG_ACT_GELU) return gelu_erf(v);
+  if (act == CDSEG_ACT_SWISH) return v / (1.0f + expf(-v));
+  return v;
 }
 
 __device__ __forceinline__ void store_val(void* p, int dtype, long idx, float v) {
@@ -62,20 +64,104 @@ __device__ __forceinline__ void store_val(void* p, int dtype, long idx, float v)
   else ((bf16_t*)p)[idx] = f32_to_bf16(v);
 }
 
-// CT: compute/storage type of A and W.  BN: output-tile width (32, 64, 128).
-template <typename CT, int BN, bool GATHER>
+__device__ __forceinline__ void store_vec4(void* p, int dtype, long idx, float4 v) {
+  if (dtype == CDSEG_F32) {
+    *reinterpret_cast<float4*>((float*)p + idx) = v;
+  } else {
+    uint2 u;
+    u.x = pack_bf16x2(v.x, v.y);
+    u.y = pack_bf16x2(v.z, v.w);
+    *reinterpret_cast<uint2*>((bf16_t*)p + idx) = u;
+  }
+}
+
+// fused epilogue on one group of 4 consecutive columns (row m, columns n..n+3)
+__device__ __forceinline__ void epilogue4(const GemmP& g, long m, int n, float4 v) {
+  long orow = m;
+  if (g.out_idx) {
+    orow = g.out_idx[m];
+    if (orow < 0) return;
+  }
+  if (g.vec_ok) {
+    if (g.bias) {
+      const float4 t = *reinterpret_cast<const float4*>(g.bias + n);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (g.scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(g.scale + n);
+      const float4 sh = *reinterpret_cast<const float4*>(g.shift + n);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    }
+    if (g.act != CDSEG_ACT_NONE) {
+      v.x = apply_act(v.x, g.act); v.y = apply_act(v.y, g.act);
+      v.z = apply_act(v.z, g.act); v.w = apply_act(v.w, g.act);
+    }
+    if (g.out2 && g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v);
+    if (g.res) {
+      const float4 t = *reinterpret_cast<const float4*>(g.res + m * g.ldres + n);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (g.add_src) {
+      const float4 t = *reinterpret_cast<const float4*>(g.add_src + (long)g.add_idx[m] * g.ldadd + n);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    store_vec4(g.out, g.out_dtype, orow * g.ldo + n, v);
+    if (g.out2 && !g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v);
+  } else {
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int e = 0; e < 4 && n + e < g.N; ++e) {
+      const int ne = n + e;
+      float x = vv[e];
+      if (g.bias) x += g.bias[ne];
+      if (g.scale) x = x * g.scale[ne] + g.shift[ne];
+      x = apply_act(x, g.act);
+      if (g.out2 && g.out2_pre_add) store_val(g.out2, g.out2_dtype, m * g.ldo2 + ne, x);
+      if (g.res) x += g.res[m * g.ldres + ne];
+      if (g.add_src) x += g.add_src[(long)g.add_idx[m] * g.ldadd + ne];
+      store_val(g.out, g.out_dtype, orow * g.ldo + ne, x);
+      if (g.out2 && !g.out2_pre_add) store_val(g.out2, g.out2_dtype, m * g.ldo2 + ne, x);
+    }
+  }
+}
+
+// second pass of a split-K GEMM: sum the partial tiles, then the fused epilogue
+__global__ void splitk_epilogue_kernel(GemmP g) {
+  const long groups = g.M * (long)(g.N >> 2);
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= groups) return;
+  const long m = t / (g.N >> 2);
+  const int n = (int)(t - m * (g.N >> 2)) << 2;
+  const long stride = g.M * (long)g.N;
+  const float* p = g.ws + m * g.N + n;
+  float4 v = *reinterpret_cast<const float4*>(p);
+  for (int s = 1; s < g.splits; ++s) {
+    const float4 u = *reinterpret_cast<const float4*>(p + s * stride);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  epilogue4(g, m, n, v);
+}
+
+// CT: compute/storage type of A and W.  BN: tile width.  NCH: 16-byte chunks per LDS row.
+template <typename CT, int BN, int NCH, bool GATHER>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
   constexpr int BM = 64;
-  constexpr int TN = BN / 32;  // 16-wide column tiles per wave (wave owns BN/2 columns)
-  constexpr int RB = Tile<CT>::ROW_BYTES;
-  constexpr int CPP = Tile<CT>::CH_PER_PART;
-  constexpr int B_PARTS = BN * 4;                      // 8-element parts in a W tile
-  constexpr int B_PER_THREAD = (B_PARTS + 255) / 256;  // 1 or 2 (BN=32: half the threads)
+  constexpr int TN = BN / 32;  // 16-wide column tiles per wave (a wave owns 32 rows x BN/2 columns)
+  constexpr int RB = NCH * 16;
+  constexpr int EPC = 16 / (int)sizeof(CT);  // elements per chunk
+  constexpr int BK = NCH * EPC;
+  constexpr int A_CH = BM * NCH, B_CH = BN * NCH;
+  constexpr int A_PT = (A_CH + 255) / 256, B_PT = (B_CH + 255) / 256;
+  constexpr int CLD = BN + 4;  // padded fp32 C tile row (conflict-free MFMA-layout writes)
+  constexpr int AB_BYTES = (BM + BN) * RB;
+  constexpr int C_BYTES = BM * CLD * 4;
+  constexpr int SM_BYTES = (AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES) + 1024;
 
-  __shared__ __attribute__((aligned(16))) char smem[BM * RB + BN * RB + 16];
+  __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
   char* As = smem;
   char* Bs = smem + BM * RB;
-  unsigned long long* smask = reinterpret_cast<unsigned long long*>(smem + BM * RB + BN * RB);
+  constexpr int TAILB = 1024;
+  int* live = reinterpret_cast<int*>(smem + SM_BYTES - TAILB);  // [0] = count, [1..] = live offsets (<= 128)
+  unsigned long long* smask = reinterpret_cast<unsigned long long*>(smem + SM_BYTES - TAILB + 640);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -83,91 +169,86 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
   const int wm = wave >> 1, wn = wave & 1;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const long Ktot = (long)g.kvol * g.K;
-  const int nkc = (int)((Ktot + 31) / 32);
+  const long Kw = (long)g.kvol * g.K;  // W row length
 
-  // ---- loader coordinates
-  const int a_row = tid >> 2, a_part = tid & 3;
-  const long a_m = m0 + a_row;
-  const bool a_ok = a_m < g.M;
-
+  int nlive = 1;
   if (GATHER) {
-    if (tid == 0) smask[0] = 0ull;
+    if (tid < 2) smask[tid] = 0ull;
     __syncthreads();
-    if (a_ok) {
-      unsigned long long mine = 0ull;
-      for (int o = a_part; o < g.kvol; o += 4)
-        if (g.nbr[a_m * g.kvol + o] >= 0) mine |= 1ull << o;
-      if (mine) atomicOr(smask, mine);
+    {
+      const int r = tid >> 2;
+      const long m = m0 + r;
+      if (m < g.M) {
+        unsigned long long lo = 0ull, hi = 0ull;
+        for (int o = tid & 3; o < g.kvol; o += 4)
+          if (g.nbr[m * g.kvol + o] >= 0) {
+            if (o < 64) lo |= 1ull << o; else hi |= 1ull << (o - 64);
+          }
+        if (lo) atomicOr(&smask[0], lo);
+        if (hi) atomicOr(&smask[1], hi);
+      }
     }
     __syncthreads();
+    if (tid == 0) {
+      int c = 0;
+      for (int o = 0; o < g.kvol; ++o)
+        if ((smask[o >> 6] >> (o & 63)) & 1ull) live[1 + c++] = o;
+      live[0] = c;
+    }
+    __syncthreads();
+    nlive = __builtin_amdgcn_readfirstlane(live[0]);
   }
-  unsigned long long mask = ~0ull;  // kernel offsets some row of this tile has a neighbour at
-  if (GATHER) mask = smask[0];
-  auto chunk_live = [&](int kc) -> bool {
-    if (!GATHER) return true;
-    const int o_lo = (int)(((long)kc * 32) / g.K);
-    long hi = (long)kc * 32 + 31;
-    if (hi >= Ktot) hi = Ktot - 1;
-    const int o_hi = (int)(hi / g.K);
-    for (int o = o_lo; o <= o_hi; ++o)
-      if ((mask >> o) & 1ull) return true;
-    return false;
-  };
+  const long KV = (long)nlive * g.K;  // virtual (compacted) reduction length
+  const int nkc = (int)((KV + BK - 1) / BK);
 
-  uint4 a_reg[CPP];
-  uint4 b_reg[B_PER_THREAD][CPP];
+  uint4 a_reg[A_PT];
+  uint4 b_reg[B_PT];
 
   auto load_tiles = [&](int kc) {
-    // A: 8 consecutive K elements of one row
-    const long kf = (long)kc * 32 + a_part * 8;
 #pragma unroll
-    for (int c = 0; c < CPP; ++c) a_reg[c] = make_uint4(0u, 0u, 0u, 0u);
-    if (a_ok && kf < Ktot) {
-      const CT* src;
-      bool ok = true;
-      if (GATHER) {
-        const int o = (int)(kf / g.K);
-        const int cc = (int)(kf - (long)o * g.K);
-        const int j = g.nbr[a_m * g.kvol + o];
-        ok = j >= 0;
-        src = (const CT*)g.A + (long)j * g.lda + cc;
-      } else {
-        src = (const CT*)g.A + a_m * g.lda + kf;
-      }
-      if (ok) {
-#pragma unroll
-        for (int c = 0; c < CPP; ++c) a_reg[c] = *reinterpret_cast<const uint4*>((const char*)src + 16 * c);
+    for (int i = 0; i < A_PT; ++i) {
+      const int id = i * 256 + tid;
+      const int row = id / NCH, ch = id % NCH;
+      const long m = m0 + row;
+      const long kv = (long)kc * BK + ch * EPC;
+      a_reg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (id < A_CH && m < g.M && kv < KV) {
+        if (GATHER) {
+          const int j = (int)(kv / g.K);
+          const int cc = (int)(kv - (long)j * g.K);
+          const int src = g.nbr[m * g.kvol + live[1 + j]];
+          if (src >= 0) a_reg[i] = *reinterpret_cast<const uint4*>((const CT*)g.A + (long)src * g.lda + cc);
+        } else {
+          a_reg[i] = *reinterpret_cast<const uint4*>((const CT*)g.A + m * g.lda + kv);
+        }
       }
     }
-    // W: rows n0 .. n0+BN, same K slice
 #pragma unroll
-    for (int i = 0; i < B_PER_THREAD; ++i) {
-      const int part = tid + i * 256;
-      const int brow = part >> 2, bp = part & 3;
-      const long bk = (long)kc * 32 + bp * 8;
-#pragma unroll
-      for (int c = 0; c < CPP; ++c) b_reg[i][c] = make_uint4(0u, 0u, 0u, 0u);
-      if (part < B_PARTS && (n0 + brow) < g.N && bk < Ktot) {
-        const CT* src = (const CT*)g.W + (long)(n0 + brow) * Ktot + bk;
-#pragma unroll
-        for (int c = 0; c < CPP; ++c) b_reg[i][c] = *reinterpret_cast<const uint4*>((const char*)src + 16 * c);
+    for (int i = 0; i < B_PT; ++i) {
+      const int id = i * 256 + tid;
+      const int row = id / NCH, ch = id % NCH;
+      const long kv = (long)kc * BK + ch * EPC;
+      b_reg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (id < B_CH && (n0 + row) < g.N && kv < KV) {
+        long col = kv;
+        if (GATHER) {
+          const int j = (int)(kv / g.K);
+          col = (long)live[1 + j] * g.K + (kv - (long)j * g.K);
+        }
+        b_reg[i] = *reinterpret_cast<const uint4*>((const CT*)g.W + (long)(n0 + row) * Kw + col);
       }
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int c = 0; c < CPP; ++c)
-      *reinterpret_cast<uint4*>(As + lds_off<CT>(a_row, a_part * CPP + c)) = a_reg[c];
+    for (int i = 0; i < A_PT; ++i) {
+      const int id = i * 256 + tid;
+      if (id < A_CH) *reinterpret_cast<uint4*>(As + lds_off<NCH>(id / NCH, id % NCH)) = a_reg[i];
+    }
 #pragma unroll
-    for (int i = 0; i < B_PER_THREAD; ++i) {
-      const int part = tid + i * 256;
-      if (part < B_PARTS) {
-        const int brow = part >> 2, bp = part & 3;
-#pragma unroll
-        for (int c = 0; c < CPP; ++c)
-          *reinterpret_cast<uint4*>(Bs + lds_off<CT>(brow, bp * CPP + c)) = b_reg[i][c];
-      }
+    for (int i = 0; i < B_PT; ++i) {
+      const int id = i * 256 + tid;
+      if (id < B_CH) *reinterpret_cast<uint4*>(Bs + lds_off<NCH>(id / NCH, id % NCH)) = b_reg[i];
     }
   };
 
@@ -179,102 +260,131 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
 
   const int fr = lane & 15, fg = lane >> 4;
 
-  int kc = 0;
-  while (kc < nkc && !chunk_live(kc)) ++kc;
-  if (kc < nkc) {
-    load_tiles(kc);
+  // split-K: this block reduces chunks [kc0, kc1) of the (compacted) K range
+  const int kc0 = (int)(((long)nkc * blockIdx.z) / gridDim.z);
+  const int kc1 = (int)(((long)nkc * (blockIdx.z + 1)) / gridDim.z);
+  if (kc0 < kc1) {
+    load_tiles(kc0);
     store_tiles();
   }
   __syncthreads();
-  while (kc < nkc) {
-    int kn = kc + 1;
-    while (kn < nkc && !chunk_live(kn)) ++kn;
-    if (kn < nkc) load_tiles(kn);  // global loads in flight during the MFMAs below
+  for (int kc = kc0; kc < kc1; ++kc) {
+    if (kc + 1 < kc1) load_tiles(kc + 1);  // global loads in flight during the MFMAs below
 
     if constexpr (sizeof(CT) == 2) {
-      bf16x8_t a[2], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off<CT>(wm * 32 + i * 16 + fr, fg));
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<CT>(wn * (BN / 2) + j * 16 + fr, fg));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    } else {
-      // k-slot g of MFMA step s = 4*half + ss holds k = 16*half + 4*g + ss  (same map for A and W)
-      f32x4_t a[2][2], b[TN][2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int kk = 0; kk < NCH / 4; ++kk) {
+        bf16x8_t a[2], b[TN];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          a[i][h] = *reinterpret_cast<const f32x4_t*>(As + lds_off<CT>(wm * 32 + i * 16 + fr, 4 * h + fg));
+          a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off<NCH>(wm * 32 + i * 16 + fr, 4 * kk + fg));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          b[j][h] = *reinterpret_cast<const f32x4_t*>(Bs + lds_off<CT>(wn * (BN / 2) + j * 16 + fr, 4 * h + fg));
+          b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<NCH>(wn * (BN / 2) + j * 16 + fr, 4 * kk + fg));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
+    } else {
+      // per 32-wide k block: k-slot g of MFMA step (h, ss) holds k = 16*h + 4*g + ss (same map for A and W)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int kb = 0; kb < NCH / 8; ++kb) {
+        f32x4_t a[2][2], b[TN][2];
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
+            a[i][h] = *reinterpret_cast<const f32x4_t*>(As + lds_off<NCH>(wm * 32 + i * 16 + fr, 8 * kb + 4 * h + fg));
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h][ss], b[j][h][ss], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            b[j][h] = *reinterpret_cast<const f32x4_t*>(
+                Bs + lds_off<NCH>(wn * (BN / 2) + j * 16 + fr, 8 * kb + 4 * h + fg));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h][ss], b[j][h][ss], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
-    if (kn < nkc) store_tiles();
+    if (kc + 1 < kc1) store_tiles();
     __syncthreads();
-    kc = kn;
   }
 
-  // ---- epilogue.  C layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
+  // ---- accumulators -> LDS C tile.  MFMA C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+  float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long m = m0 + wm * 32 + i * 16 + fg * 4 + r;
-      if (m >= g.M) continue;
-      long orow = m;
-      if (g.out_idx) {
-        orow = g.out_idx[m];
-        if (orow < 0) continue;
-      }
-      const long arow = g.add_src ? (long)g.add_idx[m] : 0;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + fr;
-        if (n >= g.N) continue;
-        float v = acc[i][j][r];
-        if (g.bias) v += g.bias[n];
-        if (g.scale) v = v * g.scale[n] + g.shift[n];
-        if (g.act == CDSEG_ACT_GELU) v = gelu_erf(v);
-        else if (g.act == CDSEG_ACT_SWISH) v = v / (1.0f + expf(-v));
-        if (g.out2 && g.out2_pre_add) store_val(g.out2, g.out2_dtype, m * g.ldo2 + n, v);
-        if (g.res) v += g.res[m * g.ldres + n];
-        if (g.add_src) v += g.add_src[arow * g.ldadd + n];
-        store_val(g.out, g.out_dtype, orow * g.ldo + n, v);
-        if (g.out2 && !g.out2_pre_add) store_val(g.out2, g.out2_dtype, m * g.ldo2 + n, v);
-      }
+      for (int r = 0; r < 4; ++r)
+        Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
+
+  // ---- epilogue on row-contiguous groups of 4 columns (or raw partial tile for split-K)
+  constexpr int GPR = BN / 4;  // groups per row
+  for (int item = tid; item < BM * GPR; item += 256) {
+    const int row = item / GPR, cg = item % GPR;
+    const long m = m0 + row;
+    const int n = n0 + 4 * cg;
+    if (m >= g.M || n >= g.N) continue;
+    const float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
+    if (gridDim.z > 1) {
+      *reinterpret_cast<float4*>(g.ws + ((long)blockIdx.z * g.M + m) * g.N + n) = v;
+    } else {
+      epilogue4(g, m, n, v);
     }
   }
 }
 
-template <typename CT, bool GATHER>
-int launch(const GemmP& p, hipStream_t s) {
+template <typename CT, int NCH, bool GATHER>
+int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
+  constexpr int BK = NCH * (16 / (int)sizeof(CT));
   const unsigned gm = (unsigned)((p.M + 63) / 64);
-  if (p.N <= 32) {
-    hipLaunchKernelGGL((gemm_kernel<CT, 32, GATHER>), dim3(gm, (unsigned)((p.N + 31) / 32)), dim3(256), 0, s, p);
-  } else if (p.N <= 64 || (p.M <= 8192 && p.N <= 256)) {
-    hipLaunchKernelGGL((gemm_kernel<CT, 64, GATHER>), dim3(gm, (unsigned)((p.N + 63) / 64)), dim3(256), 0, s, p);
-  } else {
-    hipLaunchKernelGGL((gemm_kernel<CT, 128, GATHER>), dim3(gm, (unsigned)((p.N + 127) / 128)), dim3(256), 0, s, p);
+  const int bn = p.N <= 32 ? 32 : ((p.N <= 64 || (p.M <= 4096 && p.N <= 256)) ? 64 : 128);
+  const unsigned gn = (unsigned)((p.N + bn - 1) / bn);
+  // split-K when the output tiles alone cannot fill the chip (deep stages: few points, long reductions)
+  int splits = 1;
+  const long nkc = ((long)p.kvol * p.K + BK - 1) / BK;
+  const long blocks = (long)gm * gn;
+  if (p.ws && p.vec_ok && blocks < 256 && nkc >= 4) {
+    splits = (int)((512 + blocks - 1) / blocks);
+    if (splits > nkc / 2) splits = (int)(nkc / 2);
+    if (splits > 16) splits = 16;
+    while (splits > 1 && (size_t)splits * p.M * p.N * sizeof(float) > ws_bytes) --splits;
+    if (splits < 1) splits = 1;
   }
-  return hipGetLastError() == hipSuccess ? CDSEG_OK : CDSEG_ERR_LAUNCH;
+  p.splits = splits;
+  const dim3 grid(gm, gn, (unsigned)splits);
+  if (bn == 32) hipLaunchKernelGGL((gemm_kernel<CT, 32, NCH, GATHER>), grid, dim3(256), 0, s, p);
+  else if (bn == 64) hipLaunchKernelGGL((gemm_kernel<CT, 64, NCH, GATHER>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<CT, 128, NCH, GATHER>), grid, dim3(256), 0, s, p);
+  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
+  if (splits > 1) {
+    const long groups = p.M * (long)(p.N >> 2);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
+    if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
+  }
+  return CDSEG_OK;
+}
+
+template <typename CT, bool GATHER>
+int launch(const GemmP& p, size_t ws_bytes, hipStream_t s) {
+  // narrow K step (one 32-wide MFMA block) only when the whole reduction is that short
+  const long ktot = (long)p.kvol * p.K;
+  if (ktot <= 64) {
+    if constexpr (sizeof(CT) == 2) return launch_bn<CT, 4, GATHER>(p, ws_bytes, s);
+    else return launch_bn<CT, 8, GATHER>(p, ws_bytes, s);
+  }
+  return launch_bn<CT, 16, GATHER>(p, ws_bytes, s);
 }
 
 }  // namespace
@@ -282,7 +392,7 @@ int launch(const GemmP& p, hipStream_t s) {
 extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W || !a->out) return CDSEG_ERR_ARG;
   if (a->M <= 0 || a->N <= 0) return CDSEG_OK;
-  if (a->K <= 0 || (a->K & 7) || a->kvol <= 0 || a->kvol > 64) return CDSEG_ERR_ARG;
+  if (a->K <= 0 || (a->K & 7) || a->kvol <= 0 || a->kvol > 128) return CDSEG_ERR_ARG;
   if (a->a_dtype != a->compute_dtype) return CDSEG_ERR_UNSUPPORTED;
   if (a->scale && !a->shift) return CDSEG_ERR_ARG;
   if (a->add_src && !a->add_idx) return CDSEG_ERR_ARG;
@@ -295,8 +405,16 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   p.out = a->out; p.out2 = a->out2; p.M = a->M; p.N = a->N; p.K = a->K; p.kvol = a->kvol;
   p.lda = a->lda; p.ldo = a->ldo; p.ldo2 = a->ldo2; p.ldres = a->ldres; p.ldadd = a->ldadd;
   p.out_dtype = a->out_dtype; p.out2_dtype = a->out2_dtype; p.act = a->act; p.out2_pre_add = a->out2_pre_add;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  p.vec_ok = (a->N % 4 == 0) && (a->ldo % 4 == 0) && al16(a->out) && (!a->out2 || (a->ldo2 % 4 == 0 && al16(a->out2))) &&
+             (!a->res || (a->ldres % 4 == 0 && al16(a->res))) &&
+             (!a->add_src || (a->ldadd % 4 == 0 && al16(a->add_src))) && (!a->bias || al16(a->bias)) &&
+             (!a->scale || (al16(a->scale) && al16(a->shift)));
+  p.ws = (a->ws && ((((uintptr_t)a->ws) & 15) == 0)) ? (float*)a->ws : nullptr;
+  p.splits = 1;
+  const size_t wsb = p.ws ? a->ws_bytes : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (a->compute_dtype == CDSEG_BF16) return a->nbr ? launch<bf16_t, true>(p, s) : launch<bf16_t, false>(p, s);
-  if (a->compute_dtype == CDSEG_F32) return a->nbr ? launch<float, true>(p, s) : launch<float, false>(p, s);
+  if (a->compute_dtype == CDSEG_BF16) return a->nbr ? launch<bf16_t, true>(p, wsb, s) : launch<bf16_t, false>(p, wsb, s);
+  if (a->compute_dtype == CDSEG_F32) return a->nbr ? launch<float, true>(p, wsb, s) : launch<float, false>(p, wsb, s);
   return CDSEG_ERR_ARG;
 }

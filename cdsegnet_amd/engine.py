@@ -162,8 +162,15 @@ class Engine:
             lin(mod.mlp[0].fc2, pre + ".fc2")
 
         def stem(mod, pre):
-            cw = mod.stem.conv.weight.detach()  # (out, k,k,k, in) -> (kvol, in, out) fp32
-            w[pre + ".w"] = f32(cw.reshape(cw.shape[0], -1, cw.shape[-1]).permute(1, 2, 0))
+            # (out, k,k,k, in) -> (out, kvol * in_pad): input channels zero-padded to a 16-byte multiple so
+            # the k=5 stem runs on the gathered-A MFMA GEMM like every other sparse conv
+            cw = mod.stem.conv.weight.detach()
+            cout, cin = cw.shape[0], cw.shape[-1]
+            cpad = (cin + 7) // 8 * 8
+            wp = torch.zeros(cout, cw.shape[1] ** 3, cpad, dtype=torch.float32)
+            wp[:, :, :cin] = cw.reshape(cout, -1, cin).float().cpu()
+            w[pre + ".w"] = wp.reshape(cout, -1).to(device=device, dtype=T).contiguous()
+            w[pre + ".cpad"] = cpad
             bn(mod.stem.norm, pre + ".bn")
 
         def pool(mod, pre):
@@ -326,13 +333,15 @@ class Engine:
         ops.gemm(o, w[pre + ".proj.w"], st.x, bias=w[pre + ".proj.b"], res=st.x)
         self._mlp(st, pre + ".norm2", pre + ".fc")
 
-    def run_embedding(self, plan, feat_phys, pre, curves):
+    def run_embedding(self, plan, feat, perm, pre, curves):
+        """ref: ptv3.py:633-663.  feat (N, cin) fp32 in the caller's order (perm None: already physical)."""
         w, lv = self.w, plan.levels[0]
-        cout = w[pre + ".w"].shape[2]
+        cout = w[pre + ".w"].shape[0]
+        a = ops.gather_pad_cast(feat, perm, w[pre + ".cpad"], self.T)
         x = self._buf(lv.n, cout, torch.float32)
         xc = x if self.T == torch.float32 else self._buf(lv.n, cout, self.T)
-        ops.stem_conv(feat_phys, lv.nbr(5, kmajor=True), w[pre + ".w"], w[pre + ".bn.scale"], w[pre + ".bn.shift"], x,
-                      None if xc is x else xc)
+        ops.gemm(a, w[pre + ".w"], x, scale=w[pre + ".bn.scale"], shift=w[pre + ".bn.shift"], act=ops.ACT_GELU,
+                 nbr=lv.nbr(5), kvol=125, out2=None if xc is x else xc)
         return State(lv, x, xc, curves)
 
     def run_pooling(self, plan, st, pre, cum_to, perm):
@@ -466,19 +475,18 @@ class Engine:
             c_curves = shuffled(next(pi))
         n_curves = shuffled(next(pi))
 
-        featp = ops.gather_rows(feat, plan.perm0)
         tb = {}
         if cond:
             if m.dm and m.dm_input == "xt":  # ref: default.py:392-394
                 nz = draws.get("noise")
                 if nz is None:
-                    c_feat = self._device_randn((n, c_ch))  # any order is equally random
+                    c_feat, c_perm = self._device_randn((n, c_ch)), None  # any order is equally random
                 else:
-                    c_feat = ops.gather_rows(nz.to(dev, torch.float32).contiguous(), plan.perm0)
+                    c_feat, c_perm = nz.to(dev, torch.float32).contiguous(), plan.perm0
                 t = m.T - 1
             else:
-                tgt = feat if c_ch == feat.shape[1] else input_dict["coord"].float().contiguous()
-                c_feat = ops.gather_rows(tgt, plan.perm0)
+                c_feat = feat if c_ch == feat.shape[1] else input_dict["coord"].float().contiguous()
+                c_perm = plan.perm0
                 t = 0
             if bb.T_dim != -1:  # ref: ptv3.py:1772-1778 on the (uniform) embedding row
                 v = ops.gemv(w["t.fc1.w"], w["t.fc1.b"], w["t.table"][t], ops.ACT_SWISH)
@@ -498,8 +506,8 @@ class Engine:
 
         # ref: ptv3.py:1781-1794 (the c/n interleave only matters for the order of the randperm draws)
         if cond:
-            cst = self.run_embedding(plan, c_feat, "c_emb", c_curves)
-        nst = self.run_embedding(plan, featp, "n_emb", n_curves)
+            cst = self.run_embedding(plan, c_feat, c_perm, "c_emb", c_curves)
+        nst = self.run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
         if cond:
             assert bb.c_num_stages == 3 and bb.n_num_stages == 5, "interleave hard-wired as in ptv3.py:1785-1794"
             cst = enc_stage(cst, "c", 0, c_cum, None)

@@ -258,6 +258,9 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     a.out2_dtype = dt(out2) if out2 is not None else 0
     a.act = int(act)
     a.out2_pre_add = 1 if out2_pre_add else 0
+    if ((a.M + 63) // 64) * ((a.N + 63) // 64) < 512:  # split-K partials: only when the output has few tiles
+        ws = workspace(min(16 * a.M * a.N * 4, 64 << 20), out.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     for t in (bias, scale, shift, res, add_src):
         if t is not None and t.dtype != torch.float32:
             raise _lib.CdsegError("gemm epilogue vectors / residuals are float32")
@@ -341,6 +344,16 @@ def cast(src, dtype):
     src = src.contiguous()
     out = torch.empty(src.shape, dtype=dtype, device=src.device)
     check(_lib.load().cdseg_cast(_ptr(src), dt(src), _ptr(out), _DT[dtype], src.numel(), _stream()), "cast")
+    return out
+
+
+def gather_pad_cast(src, idx, cpad, dtype):
+    """(n, cin) fp32 rows gathered by idx (None = identity), zero-padded to cpad columns, cast to dtype."""
+    src = src.contiguous()
+    n = idx.numel() if idx is not None else src.shape[0]
+    out = torch.empty((n, cpad), dtype=dtype, device=src.device)
+    check(_lib.load().cdseg_gather_pad_cast(_ptr(src), src.stride(0), _ptr(idx), n, src.shape[1], int(cpad), _ptr(out),
+                                            _DT[dtype], _stream()), "gather_pad_cast")
     return out
 
 

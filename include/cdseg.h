@@ -116,7 +116,8 @@ int cdseg_pad_plan(const int32_t* order, const int32_t* offs, const int32_t* off
  * (W is the conv weight (N, kvol, K) flattened = (out, k0, k1, k2, in)).
  * epilogue: v = acc + bias; v = v*scale + shift (folded eval BatchNorm1d, ref: ptv3.py:1440);
  *           v = act(v); [out2 = v if out2_pre_add]; v += res; v += add_src[add_idx[m]];
- *           out[out_idx ? out_idx[m] : m] = v; [out2 = v otherwise] */
+ *           out[out_idx ? out_idx[m] : m] = v; [out2 = v otherwise]
+ * kvol <= 128 (k=5 stem: 125), K % 8 == 0. */
 typedef struct cdseg_gemm_args {
   const void* A;          /* (M, lda) a_dtype; with nbr: the gather source (rows indexed by nbr) */
   const void* W;          /* (N, kvol*K) compute dtype, K contiguous */
@@ -136,6 +137,8 @@ typedef struct cdseg_gemm_args {
   int a_dtype, compute_dtype, out_dtype, out2_dtype;
   int act;
   int out2_pre_add;
+  void* ws;        /* optional split-K workspace (fp32 partial tiles) or NULL: used when M is small */
+  size_t ws_bytes; /*   and K long (deep stages); results are deterministic either way */
 } cdseg_gemm_args;
 int cdseg_gemm(const cdseg_gemm_args* args_host, void* stream);
 
@@ -180,6 +183,10 @@ int cdseg_gemv(const float* w, const float* b, const float* x, int n, int k, int
 /* standard normal draws (Philox4x32-10 + Box-Muller), the noise-branch input.  ref: default.py:393 */
 int cdseg_randn(float* out, long n, uint64_t seed, uint64_t offset, void* stream);
 int cdseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* dst[i, 0:cpad] = cast(src[idx[i], 0:cin]), zero padded (idx NULL = identity): stem input rows in the
+ * engine's point order, padded to a 16-byte multiple so the stem conv runs on the gathered GEMM */
+int cdseg_gather_pad_cast(const float* src, int ld_src, const int32_t* idx, long n, int cin, int cpad, void* dst,
+                          int dst_dtype, void* stream);
 /* out = a + alpha * b (fp32).  ref: default.py:228-236 (add_gaussian_noise) */
 int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, void* stream);
 

@@ -218,5 +218,12 @@ def cast(src, dtype):
     return src.to(dtype)
 
 
+def gather_pad_cast(src, idx, cpad, dtype):
+    rows = src if idx is None else src[idx.long()]
+    out = torch.zeros(rows.shape[0], cpad)
+    out[:, :src.shape[1]] = rows
+    return out.to(dtype)
+
+
 def axpy(a, b, alpha):
     return a + alpha * b

@@ -181,7 +181,7 @@ def test_full_size_properties_120k(full_model):
 def test_batch_equals_singles(full_model):
     """Scenes are independent units: a batch of two equals the two single runs when they
     see the same order shuffles and noise (flash semantics: fixed K, per-element patches)."""
-    s1, s2 = synth.room_scene(5, 30000), synth.room_scene(6, 20000)
+    s1, s2 = synth.room_scene(5, 30000), synth.room_scene(6, 30000)
     # equal serialization depth, else the batch (depth = max) and the single runs walk different
     # Hilbert curves (the curve's orientation depends on the bit count) and legitimately differ
     assert int(s1["grid_coord"].max()).bit_length() == int(s2["grid_coord"].max()).bit_length()

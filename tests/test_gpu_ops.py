@@ -225,6 +225,82 @@ def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
     assert err < 2e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(448, 512, 2048), (832, 1536, 512), (100, 256, 4096), (3392, 256, 256)])
+def test_gemm_split_k(ops, dtype, M, N, K):
+    """Few output tiles + long K -> the split-K path (partials in the workspace, second-pass epilogue)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    if dtype == torch.bfloat16:
+        A, W = _bf16_round(A), _bf16_round(W)
+    ref = F.gelu((A.double() @ W.double().t() + b.double()).float()).double() + res.double()
+    out = dev(res)
+    out2 = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm(dev(A, dtype), dev(W, dtype), out, bias=dev(b), act=ops.ACT_GELU, res=out, out2=out2)
+    err = (out.cpu().double() - ref).abs().max().item()
+    report(f"split-k gemm {dtype} {M}x{N}x{K}", max_err=err)
+    assert err < 2e-5 * K ** 0.5 + 1e-4
+    again = dev(res)
+    ops.gemm(dev(A, dtype), dev(W, dtype), again, bias=dev(b), act=ops.ACT_GELU, res=again)
+    assert torch.equal(again, out), "split-K must be deterministic"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sparse_conv_split_k_deep_stage(ops, dtype):
+    """Stage-4-like conv: a few hundred points, C = 512 (K = 27 * 512)."""
+    fx = load_fixture("serialization_lidar5000.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    cl, seg, cnt = ops.pool_level(zs, 9)
+    m = int(cnt.item())
+    gc, bc, cc = ops.pool_gather(seg, m, len(p), 3, g0, b0, ops.encode4(g0, b0, depth))
+    nbr = ops.nbr_table(cc[0].contiguous(), gc, bc, depth - 3, 3)
+    C = 512
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(m, C, generator=g)
+    w = torch.randn(C, 27, C, generator=g) / (27 * C) ** 0.5
+    b = torch.randn(C, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = _bf16_round(x), _bf16_round(w)
+    ref = OM.subm_conv3d(x, nbr.cpu().numpy().astype(np.int64), w.reshape(C, 3, 3, 3, C), b)
+    out = torch.empty(m, C, dtype=torch.float32, device="cuda")
+    ops.gemm(dev(x, dtype), dev(w.reshape(C, -1), dtype), out, bias=dev(b), nbr=nbr, kvol=27)
+    err = (out.cpu() - ref).abs().max().item()
+    report(f"deep conv {dtype} M={m} C={C}", max_err=err)
+    assert err < 5e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name,cin,cout", [("room1500", 6, 32), ("lidar5000", 4, 16), ("batch2", 6, 64)])
+def test_stem_as_gathered_gemm_vs_oracle(ops, dtype, name, cin, cout):
+    """The engine's stem: input rows gathered/padded to 8 channels, k=5 conv (125 offsets) on the MFMA GEMM,
+    folded BN + GELU in the epilogue."""
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    nbr = ops.nbr_table(zs, g0, b0, depth, 5)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, generator=g)  # caller order
+    w = torch.randn(cout, 5, 5, 5, cin, generator=g) / (125 * cin) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = _bf16_round(x), _bf16_round(w)
+    xp = x[torch.from_numpy(p)]
+    ref = F.gelu(OM.subm_conv3d(xp, nbr.cpu().numpy().astype(np.int64), w, None) * sc + sh)
+    a = ops.gather_pad_cast(dev(x), perm0, 8, dtype)
+    assert torch.equal(a[:, :cin].float().cpu(), xp) and float(a[:, cin:].abs().max()) == 0.0
+    wp = torch.zeros(cout, 125, 8)
+    wp[:, :, :cin] = w.reshape(cout, 125, cin)
+    out = torch.empty(n, cout, dtype=torch.float32, device="cuda")
+    out2 = torch.empty(n, cout, dtype=dtype, device="cuda")
+    ops.gemm(a, dev(wp.reshape(cout, -1), dtype), out, scale=dev(sc), shift=dev(sh), act=ops.ACT_GELU, nbr=nbr,
+             kvol=125, out2=out2)
+    err = (out.cpu() - ref).abs().max().item()
+    report(f"stem gemm {dtype} {name}", max_err=err)
+    assert err < 1e-4
+
+
 @pytest.mark.parametrize("name,cin,cout", [("room1500", 6, 32), ("lidar5000", 4, 16), ("batch2", 6, 64)])
 def test_stem_conv_vs_oracle(ops, name, cin, cout):
     fx = load_fixture(f"serialization_{name}.npz")
