@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from cdsegnet_amd import configs, ops, synth  # noqa: E402
+from cdsegnet_amd import dist as cdist  # noqa: E402
 from cdsegnet_amd.param_init import fill_state_dict  # noqa: E402
 from cdsegnet_amd.registry import build_model  # noqa: E402
 import cdsegnet_amd.models  # noqa: E402,F401
@@ -86,14 +87,7 @@ def main():
         model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     if world > 1:  # weights: one RCCL broadcast from rank 0 (replaces the reference's DDP-ctor broadcast)
-        flat = torch.cat([p.detach().reshape(-1).float() for p in model.state_dict().values()])
-        dist.broadcast(flat, src=0)
-        off = 0
-        with torch.no_grad():
-            for p in model.state_dict().values():
-                p.copy_(flat[off:off + p.numel()].reshape(p.shape).to(p.dtype))
-                off += p.numel()
-        model._drop_engine()
+        cdist.broadcast_model(model, src=0)
     model.precision = args.precision
     model.noise_source = "device"  # noise-branch input drawn by the Philox kernel (no host RNG + PCIe in the step)
 
@@ -125,14 +119,15 @@ def main():
     ops.set_timer(None)
     assert torch.isfinite(out).all()
 
-    # label histogram of the last step: the per-scene record the reference gathers (test.py:374)
-    hist = torch.bincount(out.argmax(1), minlength=out.shape[1]).to(torch.int64)
+    # per-class intersection/union/target counters of the last step: the per-scene record the reference
+    # gathers over gloo (test.py:374) - here one RCCL all-reduce (random-init weights: the value is meaningless)
+    counts = cdist.confusion_counts(out.argmax(1), torch.as_tensor(sc["segment"]).to(dev), out.shape[1])
+    cdist.reduce_counts(counts)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     pts = torch.tensor([n], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     total_pts = int(pts.item())
 

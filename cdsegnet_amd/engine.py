@@ -438,10 +438,19 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def inference(self, input_dict, noise_level=None, draws=None):
+        try:
+            return self._inference(input_dict, noise_level, draws)
+        finally:
+            if hasattr(ops, "unbind_stream"):
+                ops.unbind_stream()
+
+    def _inference(self, input_dict, noise_level=None, draws=None):
         m, bb = self.model, self.model.backbone
         feat = input_dict["feat"]
         dev = feat.device  # CPU tensors are rejected by every op (cdsegnet_amd.ops): no CPU fallback
         self.prepare(dev)
+        if dev.type == "cuda" and hasattr(ops, "bind_stream"):
+            ops.bind_stream()
         w = self.w
         grid = input_dict["grid_coord"]
         offset = input_dict["offset"]

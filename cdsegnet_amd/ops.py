@@ -15,13 +15,24 @@ __all__ = ["ACT_NONE", "ACT_GELU", "ACT_SWISH", "F32", "BF16"]
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _WS = {}
+_GEMM_CACHE = {}
+
+
+class _LazyLib:
+    """Attribute access loads the library on first use (and raises loudly if it is missing)."""
+
+    def __getattr__(self, name):
+        return getattr(_lib.load(), name)
+
+
+_LIB = _LazyLib()
 
 
 class KernelTimer:
     """HIP-event timing of selected ops on the stream they are launched on (torch's current
     stream).  bench.py installs one over the timed region to get per-kernel durations live."""
 
-    def __init__(self, names=("attention", "gemm", "conv")):
+    def __init__(self, names=("attention",)):
         self.names = set(names)
         self.events = []
 
@@ -62,8 +73,26 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_STREAM = None
+
+
+def bind_stream(stream=None):
+    """Cache the HIP stream every op launches on (torch.cuda.current_stream() costs ~8 us per query, and an
+    inference issues ~500 launches).  The engine binds the current stream once per inference call."""
+    global _STREAM
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    _STREAM = ctypes.c_void_p(stream)
+    return _STREAM
+
+
+def unbind_stream():
+    global _STREAM
+    _STREAM = None
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM if _STREAM is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _need_gpu(*ts):
@@ -238,34 +267,50 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
          nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1):
     """out = epilogue(A @ W^T) (or the gathered-A sparse-conv form when nbr is given).
     A (M,K) [or the gather source], W (N, kvol*K), both of the compute dtype."""
-    _need_gpu(A, W, out)
-    a = GemmArgs()
-    a.A, a.W, a.bias, a.scale, a.shift = A.data_ptr(), W.data_ptr(), _dp(bias), _dp(scale), _dp(shift)
+    if not A.is_cuda:
+        _need_gpu(A, W, out)
+    # the weight-side half of the argument block is static per layer: cache it keyed by the weight tensor
+    key = (W.data_ptr(), _dp(bias), _dp(scale), _dp(shift), int(kvol), int(act))
+    ent = _GEMM_CACHE.get(key)
+    if ent is None:
+        for t in (bias, scale, shift):
+            if t is not None and t.dtype != torch.float32:
+                raise _lib.CdsegError("gemm epilogue vectors are float32")
+        a = GemmArgs()
+        a.W, a.bias, a.scale, a.shift = key[0], key[1], key[2], key[3]
+        a.N = W.shape[0]
+        a.kvol = int(kvol)
+        a.K = W.shape[1] // a.kvol
+        a.compute_dtype = dt(W)
+        a.act = int(act)
+        ent = (a, ctypes.byref(a), W)  # keep W alive with the cache entry
+        if len(_GEMM_CACHE) > 4096:
+            _GEMM_CACHE.clear()
+        _GEMM_CACHE[key] = ent
+    a = ent[0]
+    if (res is not None and res.dtype != torch.float32) or (add_src is not None and add_src.dtype != torch.float32):
+        raise _lib.CdsegError("gemm residuals are float32")
+    a.A = A.data_ptr()
     a.res, a.add_src, a.add_idx, a.nbr, a.out_idx = _dp(res), _dp(add_src), _dp(add_idx), _dp(nbr), _dp(out_idx)
     a.out, a.out2 = out.data_ptr(), _dp(out2)
-    a.M = int(M if M is not None else (nbr.shape[0] if nbr is not None else A.shape[0]))
-    a.N = W.shape[0]
-    a.kvol = int(kvol)
-    a.K = W.shape[1] // a.kvol
+    m = int(M if M is not None else (nbr.shape[0] if nbr is not None else A.shape[0]))
+    a.M = m
     a.lda = A.stride(0)
     a.ldo = out.stride(0)
     a.ldo2 = out2.stride(0) if out2 is not None else 0
     a.ldres = res.stride(0) if res is not None else 0
     a.ldadd = add_src.stride(0) if add_src is not None else 0
-    a.a_dtype = dt(A)
-    a.compute_dtype = dt(W)
-    a.out_dtype = dt(out)
-    a.out2_dtype = dt(out2) if out2 is not None else 0
-    a.act = int(act)
+    a.a_dtype = _DT[A.dtype]
+    a.out_dtype = _DT[out.dtype]
+    a.out2_dtype = _DT[out2.dtype] if out2 is not None else 0
     a.out2_pre_add = 1 if out2_pre_add else 0
-    if ((a.M + 63) // 64) * ((a.N + 63) // 64) < 512:  # split-K partials: only when the output has few tiles
-        ws = workspace(min(16 * a.M * a.N * 4, 64 << 20), out.device)
+    if ((m + 63) >> 6) * ((a.N + 63) >> 6) < 512:  # split-K partials: only when the output has few tiles
+        ws = workspace(min(16 * m * a.N * 4, 64 << 20), out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
-    for t in (bias, scale, shift, res, add_src):
-        if t is not None and t.dtype != torch.float32:
-            raise _lib.CdsegError("gemm epilogue vectors / residuals are float32")
+    else:
+        a.ws, a.ws_bytes = None, 0
     tok = TIMER.begin("conv" if nbr is not None else "gemm") if TIMER is not None else None
-    check(_lib.load().cdseg_gemm(ctypes.byref(a), _stream()), "gemm")
+    check(_LIB.cdseg_gemm(ent[1], _stream()), "gemm")
     if tok is not None:
         TIMER.end(tok, 2.0 * a.M * a.N * a.K * a.kvol)
     return out

@@ -1,0 +1,103 @@
+"""CPU, world_size = 2, gloo: the N > 1 path (scene sharding, weight broadcast, counter all-reduce).
+The compute inside each rank runs on the PyTorch-CPU emulation of the C-ABI ops (tests/emu_ops.py,
+test infrastructure) because the product's HIP path needs a GPU; what is under test here is
+cdsegnet_amd.dist and the bit-equality of the replicas after the broadcast."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cdsegnet_amd import dist as cdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cdsegnet_amd.engine as engine_mod
+        import cdsegnet_amd.models  # noqa: F401
+        from cdsegnet_amd import configs, synth
+        from cdsegnet_amd.param_init import fill_state_dict
+        from cdsegnet_amd.registry import build_model
+        from oracle import model as OM
+        from tests import emu_ops
+        engine_mod.ops = emu_ops
+        torch.set_num_threads(2)
+        cfg = configs.mini_config()
+        model = build_model(cfg).eval()
+        if rank == 0:
+            model.load_state_dict(fill_state_dict(model.state_dict(), seed=9))
+        cdist.broadcast_model(model, src=0)  # rank 1 starts from its own random init
+        model.precision = "fp32"
+        sizes = [900, 400, 700, 300, 650]
+        mine = cdist.shard_scenes(sizes)
+        counts = torch.zeros(3, cfg["num_classes"], dtype=torch.int64)
+        logits = {}
+        for i in mine:
+            sc = synth.room_scene(100 + i, sizes[i], num_classes=cfg["num_classes"])
+            inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")}
+            draws = OM.draw_rng(i, sizes[i], cfg["c_in_channels"])
+            out = model.inference(inp, eval=False, draws=draws)["seg_logits"]
+            logits[i] = out.numpy()
+            counts += cdist.confusion_counts(out.argmax(1), torch.as_tensor(sc["segment"]), cfg["num_classes"])
+        cdist.reduce_counts(counts)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), counts=counts.numpy(), mine=np.array(mine),
+                 **{f"logits{i}": v for i, v in logits.items()},
+                 w=model.state_dict()["backbone._n_head.weight"].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scene_sharding_is_a_partition():
+    sizes = [120000, 40000, 80000, 80000, 10000, 95000, 3000]
+    for world in (1, 2, 3, 8):
+        seen = sorted(i for r in range(world) for i in cdist.shard_scenes(sizes, r, world))
+        assert seen == list(range(len(sizes)))
+    loads = [sum(sizes[i] for i in cdist.shard_scenes(sizes, r, 2)) for r in range(2)]
+    assert abs(loads[0] - loads[1]) <= max(sizes)
+
+
+def test_two_ranks_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["w"], r1["w"]), "weights differ after the broadcast"
+    assert sorted(list(r0["mine"]) + list(r1["mine"])) == [0, 1, 2, 3, 4]
+    assert np.array_equal(r0["counts"], r1["counts"])  # all-reduced totals on every rank
+    assert int(r0["counts"][2].sum()) == 900 + 400 + 700 + 300 + 650  # every point counted once
+    # single-process reference of the same scenes with rank-0 weights
+    import cdsegnet_amd.engine as engine_mod
+    import cdsegnet_amd.models  # noqa: F401
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    from oracle import model as OM
+    from tests import emu_ops
+    old = engine_mod.ops
+    engine_mod.ops = emu_ops
+    try:
+        cfg = configs.mini_config()
+        model = build_model(cfg).eval()
+        model.load_state_dict(fill_state_dict(model.state_dict(), seed=9))
+        model.precision = "fp32"
+        sizes = [900, 400, 700, 300, 650]
+        for r in (r0, r1):
+            for i in r["mine"]:
+                sc = synth.room_scene(100 + int(i), sizes[int(i)], num_classes=cfg["num_classes"])
+                inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")}
+                out = model.inference(inp, eval=False, draws=OM.draw_rng(int(i), sizes[int(i)], 6))["seg_logits"].numpy()
+                assert np.array_equal(out, r[f"logits{int(i)}"])
+    finally:
+        engine_mod.ops = old
