@@ -31,6 +31,8 @@ class GemmArgs(Structure):
         ("a_dtype", c_int), ("compute_dtype", c_int), ("out_dtype", c_int), ("out2_dtype", c_int),
         ("act", c_int), ("out2_pre_add", c_int),
         ("ws", c_void_p), ("ws_bytes", c_size_t),
+        ("colbias", c_void_p), ("ln_pre_g", c_void_p), ("ln_pre_b", c_void_p), ("ln_post_g", c_void_p),
+        ("ln_post_b", c_void_p), ("ln_out", c_void_p), ("ldln", c_int), ("ln_out_dtype", c_int), ("ln_eps", c_float),
     ]
 
 

@@ -44,6 +44,16 @@ struct GemmP {
   int vec_ok;  // all row strides / N multiples of 4 -> float4 epilogue
   float* ws;   // split-K partial sums (splits, M, N) fp32, or nullptr
   int splits;
+  int kshift;
+  // row-wise LayerNorm fusion (only when one block holds complete rows: N <= BN, no split-K)
+  const float* colbias;   // (N) added with the residual (timestep-embedding bias)
+  const float* ln_pre_g;  // LayerNorm of the GEMM result BEFORE the residual add (CPE: x += LN(Linear(conv)))
+  const float* ln_pre_b;
+  const float* ln_post_g;  // LayerNorm of the final row -> ln_out (the pre-norm of the next sub-block)
+  const float* ln_post_b;
+  void* ln_out;
+  int ldln, ln_out_dtype;
+  float ln_eps;
 };
 
 template <int NCH>
@@ -101,6 +111,10 @@ __device__ __forceinline__ void epilogue4(const GemmP& g, long m, int n, float4 
       const float4 t = *reinterpret_cast<const float4*>(g.res + m * g.ldres + n);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
+    if (g.colbias) {
+      const float4 t = *reinterpret_cast<const float4*>(g.colbias + n);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
     if (g.add_src) {
       const float4 t = *reinterpret_cast<const float4*>(g.add_src + (long)g.add_idx[m] * g.ldadd + n);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
@@ -117,6 +131,7 @@ __device__ __forceinline__ void epilogue4(const GemmP& g, long m, int n, float4 
       x = apply_act(x, g.act);
       if (g.out2 && g.out2_pre_add) store_val(g.out2, g.out2_dtype, m * g.ldo2 + ne, x);
       if (g.res) x += g.res[m * g.ldres + ne];
+      if (g.colbias) x += g.colbias[ne];
       if (g.add_src) x += g.add_src[(long)g.add_idx[m] * g.ldadd + ne];
       store_val(g.out, g.out_dtype, orow * g.ldo + ne, x);
       if (g.out2 && !g.out2_pre_add) store_val(g.out2, g.out2_dtype, m * g.ldo2 + ne, x);
@@ -198,8 +213,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
     __syncthreads();
     nlive = __builtin_amdgcn_readfirstlane(live[0]);
   }
-  const long KV = (long)nlive * g.K;  // virtual (compacted) reduction length
-  const int nkc = (int)((KV + BK - 1) / BK);
+  const int KV = nlive * g.K;  // virtual (compacted) reduction length (< 2^31: kvol <= 128, K <= 2^16)
+  const int nkc = (KV + BK - 1) / BK;
+  const int kshift = g.kshift;  // log2(K) when K is a power of two (every shipped config), else -1
 
   uint4 a_reg[A_PT];
   uint4 b_reg[B_PT];
@@ -210,12 +226,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
       const int id = i * 256 + tid;
       const int row = id / NCH, ch = id % NCH;
       const long m = m0 + row;
-      const long kv = (long)kc * BK + ch * EPC;
+      const int kv = kc * BK + ch * EPC;
       a_reg[i] = make_uint4(0u, 0u, 0u, 0u);
       if (id < A_CH && m < g.M && kv < KV) {
         if (GATHER) {
-          const int j = (int)(kv / g.K);
-          const int cc = (int)(kv - (long)j * g.K);
+          const int j = kshift >= 0 ? (kv >> kshift) : (int)((unsigned)kv / (unsigned)g.K);
+          const int cc = kv - j * g.K;
           const int src = g.nbr[m * g.kvol + live[1 + j]];
           if (src >= 0) a_reg[i] = *reinterpret_cast<const uint4*>((const CT*)g.A + (long)src * g.lda + cc);
         } else {
@@ -227,13 +243,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
     for (int i = 0; i < B_PT; ++i) {
       const int id = i * 256 + tid;
       const int row = id / NCH, ch = id % NCH;
-      const long kv = (long)kc * BK + ch * EPC;
+      const int kv = kc * BK + ch * EPC;
       b_reg[i] = make_uint4(0u, 0u, 0u, 0u);
       if (id < B_CH && (n0 + row) < g.N && kv < KV) {
-        long col = kv;
+        int col = kv;
         if (GATHER) {
-          const int j = (int)(kv / g.K);
-          col = (long)live[1 + j] * g.K + (kv - (long)j * g.K);
+          const int j = kshift >= 0 ? (kv >> kshift) : (int)((unsigned)kv / (unsigned)g.K);
+          col = live[1 + j] * g.K + (kv - j * g.K);
         }
         b_reg[i] = *reinterpret_cast<const uint4*>((const CT*)g.W + (long)(n0 + row) * Kw + col);
       }
@@ -329,6 +345,110 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
         Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
+  // ---- fused LayerNorm epilogue: 4 lanes own one row (complete in this block), values stay in registers
+  if (g.ln_pre_g || g.ln_post_g) {
+    constexpr int MAXG = BN / 16;  // float4 groups per lane
+    const int row = tid >> 2, part = tid & 3;
+    const long m = m0 + row;
+    const bool act_row = m < g.M;
+    const int ng = g.N >> 2;
+    const float inv_n = 1.0f / (float)g.N;
+    float4 v[MAXG];
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int cg = part + 4 * i;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cg < ng) {
+        const int n = 4 * cg;
+        v[i] = *reinterpret_cast<const float4*>(Cs + row * CLD + n);
+        if (g.bias) {
+          const float4 t = *reinterpret_cast<const float4*>(g.bias + n);
+          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        }
+        if (g.scale) {
+          const float4 sc = *reinterpret_cast<const float4*>(g.scale + n);
+          const float4 sh = *reinterpret_cast<const float4*>(g.shift + n);
+          v[i].x = v[i].x * sc.x + sh.x; v[i].y = v[i].y * sc.y + sh.y;
+          v[i].z = v[i].z * sc.z + sh.z; v[i].w = v[i].w * sc.w + sh.w;
+        }
+        if (g.act != CDSEG_ACT_NONE) {
+          v[i].x = apply_act(v[i].x, g.act); v[i].y = apply_act(v[i].y, g.act);
+          v[i].z = apply_act(v[i].z, g.act); v[i].w = apply_act(v[i].w, g.act);
+        }
+      }
+    }
+    auto row_layernorm = [&](const float* gam, const float* bet, float4 (&o)[MAXG]) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i)
+        if (part + 4 * i < ng) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      const float mean = s * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i)
+        if (part + 4 * i < ng) {
+          const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+          q += (a * a + b * b) + (c * c + d * d);
+        }
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      const float rstd = 1.0f / sqrtf(q * inv_n + g.ln_eps);
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i)
+        if (part + 4 * i < ng) {
+          const int n = 4 * (part + 4 * i);
+          const float4 ga = *reinterpret_cast<const float4*>(gam + n);
+          const float4 be = *reinterpret_cast<const float4*>(bet + n);
+          o[i].x = (v[i].x - mean) * rstd * ga.x + be.x;
+          o[i].y = (v[i].y - mean) * rstd * ga.y + be.y;
+          o[i].z = (v[i].z - mean) * rstd * ga.z + be.z;
+          o[i].w = (v[i].w - mean) * rstd * ga.w + be.w;
+        }
+    };
+    if (g.ln_pre_g) row_layernorm(g.ln_pre_g, g.ln_pre_b, v);
+    if (act_row) {
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) {
+        const int cg = part + 4 * i;
+        if (cg >= ng) continue;
+        const int n = 4 * cg;
+        if (g.out2 && g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v[i]);
+        if (g.res) {
+          const float4 t = *reinterpret_cast<const float4*>(g.res + m * g.ldres + n);
+          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        }
+        if (g.colbias) {
+          const float4 t = *reinterpret_cast<const float4*>(g.colbias + n);
+          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        }
+        if (g.add_src) {
+          const float4 t = *reinterpret_cast<const float4*>(g.add_src + (long)g.add_idx[m] * g.ldadd + n);
+          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        }
+        store_vec4(g.out, g.out_dtype, m * g.ldo + n, v[i]);
+        if (g.out2 && !g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v[i]);
+      }
+    } else {
+      // keep the shuffles of inactive rows well defined
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (g.ln_post_g) {
+      float4 h[MAXG];
+      row_layernorm(g.ln_post_g, g.ln_post_b, h);
+      if (act_row) {
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) {
+          const int cg = part + 4 * i;
+          if (cg < ng) store_vec4(g.ln_out, g.ln_out_dtype, m * g.ldln + 4 * cg, h[i]);
+        }
+      }
+    }
+    return;
+  }
+
   // ---- epilogue on row-contiguous groups of 4 columns (or raw partial tile for split-K)
   constexpr int GPR = BN / 4;  // groups per row
   for (int item = tid; item < BM * GPR; item += 256) {
@@ -349,13 +469,14 @@ template <typename CT, int NCH, bool GATHER>
 int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   constexpr int BK = NCH * (16 / (int)sizeof(CT));
   const unsigned gm = (unsigned)((p.M + 63) / 64);
-  const int bn = p.N <= 32 ? 32 : ((p.N <= 64 || (p.M <= 4096 && p.N <= 256)) ? 64 : 128);
+  const bool ln = p.ln_pre_g || p.ln_post_g;
+  const int bn = p.N <= 32 ? 32 : ((p.N <= 64 || (!ln && p.M <= 4096 && p.N <= 256)) ? 64 : 128);
   const unsigned gn = (unsigned)((p.N + bn - 1) / bn);
   // split-K when the output tiles alone cannot fill the chip (deep stages: few points, long reductions)
   int splits = 1;
   const long nkc = ((long)p.kvol * p.K + BK - 1) / BK;
   const long blocks = (long)gm * gn;
-  if (p.ws && p.vec_ok && blocks < 256 && nkc >= 4) {
+  if (p.ws && p.vec_ok && !ln && blocks < 256 && nkc >= 4) {
     splits = (int)((512 + blocks - 1) / blocks);
     if (splits > nkc / 2) splits = (int)(nkc / 2);
     if (splits > 16) splits = 16;
@@ -392,7 +513,7 @@ int launch(const GemmP& p, size_t ws_bytes, hipStream_t s) {
 extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W || !a->out) return CDSEG_ERR_ARG;
   if (a->M <= 0 || a->N <= 0) return CDSEG_OK;
-  if (a->K <= 0 || (a->K & 7) || a->kvol <= 0 || a->kvol > 128) return CDSEG_ERR_ARG;
+  if (a->K <= 0 || (a->K & 7) || a->K > 65536 || a->kvol <= 0 || a->kvol > 128) return CDSEG_ERR_ARG;
   if (a->a_dtype != a->compute_dtype) return CDSEG_ERR_UNSUPPORTED;
   if (a->scale && !a->shift) return CDSEG_ERR_ARG;
   if (a->add_src && !a->add_idx) return CDSEG_ERR_ARG;
@@ -410,8 +531,24 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
              (!a->res || (a->ldres % 4 == 0 && al16(a->res))) &&
              (!a->add_src || (a->ldadd % 4 == 0 && al16(a->add_src))) && (!a->bias || al16(a->bias)) &&
              (!a->scale || (al16(a->scale) && al16(a->shift)));
+  p.colbias = a->colbias; p.ln_pre_g = a->ln_pre_g; p.ln_pre_b = a->ln_pre_b; p.ln_post_g = a->ln_post_g;
+  p.ln_post_b = a->ln_post_b; p.ln_out = a->ln_out; p.ldln = a->ldln; p.ln_out_dtype = a->ln_out_dtype;
+  p.ln_eps = a->ln_eps;
+  if (p.ln_pre_g || p.ln_post_g) {
+    // a block must hold complete rows; rows are processed as float4 groups; no row scatter
+    if (a->N > 128 || !p.vec_ok || a->out_idx || (p.ln_pre_g && !p.ln_pre_b) || (p.ln_post_g && (!p.ln_post_b || !a->ln_out)) ||
+        (a->ln_out && (a->ldln % 4)))
+      return CDSEG_ERR_UNSUPPORTED;
+  }
+  if (p.colbias && !al16(p.colbias)) p.vec_ok = 0;
   p.ws = (a->ws && ((((uintptr_t)a->ws) & 15) == 0)) ? (float*)a->ws : nullptr;
   p.splits = 1;
+  p.kshift = -1;
+  if ((a->K & (a->K - 1)) == 0) {
+    int sh = 0;
+    while ((1 << sh) < a->K) ++sh;
+    p.kshift = sh;
+  }
   const size_t wsb = p.ws ? a->ws_bytes : 0;
   hipStream_t s = (hipStream_t)stream;
   if (a->compute_dtype == CDSEG_BF16) return a->nbr ? launch<bf16_t, true>(p, wsb, s) : launch<bf16_t, false>(p, wsb, s);

@@ -289,21 +289,35 @@ class Engine:
     def _buf(self, rows, cols, dtype):
         return torch.empty((rows, cols), dtype=dtype, device=self.device)
 
-    def _cpe(self, st, pre, xc, tbias=None):
-        """x += LN(Linear(SubMConv3d(xc)))  [+ t bias]   (ref: ptv3.py:401-411)."""
+    FUSE_LN_MAX_C = 128  # a GEMM block holds complete rows up to this width -> LayerNorm in the epilogue
+
+    def _cpe(self, st, pre, xc, tbias=None, next_norm=None):
+        """x += LN(Linear(SubMConv3d(xc)))  [+ t bias]   (ref: ptv3.py:401-411).
+        next_norm: weight prefix of the LayerNorm that follows on x; returns its output h (dtype T)."""
         w, lv = self.w, st.level
         c = st.x.shape[1]
         y = self._buf(lv.n, c, self.T)
         ops.gemm(xc, w[pre + "0.w"], y, bias=w[pre + "0.b"], nbr=lv.nbr(3), kvol=27)
+        h = self._buf(lv.n, c, self.T) if next_norm else None
+        if c <= self.FUSE_LN_MAX_C:
+            ops.gemm(y, w[pre + "1.w"], st.x, bias=w[pre + "1.b"], ln_pre=(w[pre + "2.g"], w[pre + "2.b"]), res=st.x,
+                     colbias=tbias, ln_post=(w[next_norm + ".g"], w[next_norm + ".b"]) if next_norm else None,
+                     ln_out=h)
+            return h
         y2 = self._buf(lv.n, c, torch.float32)
         ops.gemm(y, w[pre + "1.w"], y2, bias=w[pre + "1.b"])
         ops.layernorm(y2, w[pre + "2.g"], w[pre + "2.b"], st.x, res=st.x, colbias=tbias)
+        if next_norm:
+            ops.layernorm(st.x, w[next_norm + ".g"], w[next_norm + ".b"], h)
+        return h
 
-    def _mlp(self, st, pre_norm, pre_fc, shadow=True):
+    def _mlp(self, st, pre_norm, pre_fc, h=None):
+        """x += fc2(GELU(fc1(LN(x)))); h: the LayerNorm output if a previous epilogue already produced it."""
         w = self.w
         n, c = st.x.shape
-        h = self._buf(n, c, self.T)
-        ops.layernorm(st.x, w[pre_norm + ".g"], w[pre_norm + ".b"], h)
+        if h is None:
+            h = self._buf(n, c, self.T)
+            ops.layernorm(st.x, w[pre_norm + ".g"], w[pre_norm + ".b"], h)
         hid = w[pre_fc + "1.w"].shape[0]
         u = self._buf(n, hid, self.T)
         ops.gemm(h, w[pre_fc + "1.w"], u, bias=w[pre_fc + "1.b"], act=ops.ACT_GELU)
@@ -318,9 +332,7 @@ class Engine:
         """ref: ptv3.py:399-428."""
         w, lv = self.w, st.level
         n, c = st.x.shape
-        self._cpe(st, pre + ".cpe", st.xc, tbias)
-        h = self._buf(n, c, self.T)
-        ops.layernorm(st.x, w[pre + ".norm1.g"], w[pre + ".norm1.b"], h)
+        h = self._cpe(st, pre + ".cpe", st.xc, tbias, next_norm=pre + ".norm1")
         qkv = self._buf(n, 3 * c, self.T)
         ops.gemm(h, w[pre + ".qkv.w"], qkv, bias=w[pre + ".qkv.b"])
         att = mod.attn
@@ -330,8 +342,14 @@ class Engine:
         o = self._buf(n, c, self.T)
         ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
                       att.scale, o, work=64.0 * att.num_heads * sum_l2)
-        ops.gemm(o, w[pre + ".proj.w"], st.x, bias=w[pre + ".proj.b"], res=st.x)
-        self._mlp(st, pre + ".norm2", pre + ".fc")
+        if c <= self.FUSE_LN_MAX_C:
+            h2 = self._buf(n, c, self.T)
+            ops.gemm(o, w[pre + ".proj.w"], st.x, bias=w[pre + ".proj.b"], res=st.x,
+                     ln_post=(w[pre + ".norm2.g"], w[pre + ".norm2.b"]), ln_out=h2)
+        else:
+            h2 = None
+            ops.gemm(o, w[pre + ".proj.w"], st.x, bias=w[pre + ".proj.b"], res=st.x)
+        self._mlp(st, pre + ".norm2", pre + ".fc", h2)
 
     def run_embedding(self, plan, feat, perm, pre, curves):
         """ref: ptv3.py:633-663.  feat (N, cin) fp32 in the caller's order (perm None: already physical)."""

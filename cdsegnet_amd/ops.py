@@ -264,7 +264,8 @@ def pad_plan(order, offs, offs_pad, patch, n_pad):
 
 # ------------------------------------------------------------------ float ops
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
-         nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1):
+         nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
+         ln_post=None, ln_out=None, ln_eps=1e-5):
     """out = epilogue(A @ W^T) (or the gathered-A sparse-conv form when nbr is given).
     A (M,K) [or the gather source], W (N, kvol*K), both of the compute dtype."""
     if not A.is_cuda:
@@ -304,6 +305,17 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     a.out_dtype = _DT[out.dtype]
     a.out2_dtype = _DT[out2.dtype] if out2 is not None else 0
     a.out2_pre_add = 1 if out2_pre_add else 0
+    a.colbias = _dp(colbias)
+    if ln_pre is not None:
+        a.ln_pre_g, a.ln_pre_b = ln_pre[0].data_ptr(), ln_pre[1].data_ptr()
+    else:
+        a.ln_pre_g = a.ln_pre_b = None
+    if ln_post is not None:
+        a.ln_post_g, a.ln_post_b = ln_post[0].data_ptr(), ln_post[1].data_ptr()
+        a.ln_out, a.ldln, a.ln_out_dtype = ln_out.data_ptr(), ln_out.stride(0), _DT[ln_out.dtype]
+    else:
+        a.ln_post_g = a.ln_post_b = a.ln_out = None
+    a.ln_eps = float(ln_eps)
     if ((m + 63) >> 6) * ((a.N + 63) >> 6) < 512:  # split-K partials: only when the output has few tiles
         ws = workspace(min(16 * m * a.N * 4, 64 << 20), out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()

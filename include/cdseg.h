@@ -139,6 +139,17 @@ typedef struct cdseg_gemm_args {
   int out2_pre_add;
   void* ws;        /* optional split-K workspace (fp32 partial tiles) or NULL: used when M is small */
   size_t ws_bytes; /*   and K long (deep stages); results are deterministic either way */
+  /* fused row LayerNorm (N <= 128; ref: nn.LayerNorm eps 1e-5 at ptv3.py:365,367,381):
+   *   v = act(acc + bias);  if ln_pre:  v = LN(v) * ln_pre_g + ln_pre_b      (CPE, ptv3.py:401-404)
+   *   v += res + colbias (+ add_src);  out = v;  if ln_post: ln_out = LN(v) * ln_post_g + ln_post_b */
+  const float* colbias;   /* (N) or NULL: timestep-embedding bias, ptv3.py:406-411 */
+  const float* ln_pre_g;
+  const float* ln_pre_b;
+  const float* ln_post_g;
+  const float* ln_post_b;
+  void* ln_out;           /* (M, ldln) ln_out_dtype */
+  int ldln, ln_out_dtype;
+  float ln_eps;
 } cdseg_gemm_args;
 int cdseg_gemm(const cdseg_gemm_args* args_host, void* stream);
 

@@ -118,7 +118,8 @@ def _act(v, act):
 
 
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
-         nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1):
+         nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
+         ln_post=None, ln_out=None, ln_eps=1e-5):
     assert A.dtype == W.dtype
     Af, Wf = A.float(), W.float()
     if nbr is None:
@@ -135,10 +136,14 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     if scale is not None:
         v = v * scale + shift
     v = _act(v, act)
+    if ln_pre is not None:
+        v = F.layer_norm(v, (v.shape[1],), ln_pre[0], ln_pre[1], ln_eps)
     if out2 is not None and out2_pre_add:
         out2.copy_(v.to(out2.dtype))
     if res is not None:
         v = v + res
+    if colbias is not None:
+        v = v + colbias
     if add_src is not None:
         v = v + add_src[add_idx.long()]
     if out_idx is not None:
@@ -147,6 +152,8 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
         out.copy_(v.to(out.dtype))
     if out2 is not None and not out2_pre_add:
         out2.copy_(v.to(out2.dtype))
+    if ln_post is not None:
+        ln_out.copy_(F.layer_norm(v, (v.shape[1],), ln_post[0], ln_post[1], ln_eps).to(ln_out.dtype))
     return out
 
 

@@ -226,6 +226,37 @@ def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 32, 32), (4097, 64, 64), (130, 128, 128), (70, 16, 16), (515, 48, 48)])
+def test_gemm_fused_layernorm_epilogue(ops, dtype, M, N, K):
+    """x = x + LN_a(A W^T + b) + colbias ; h = LN_b(x)   (the CPE + pre-norm chain, ptv3.py:401-413)
+    and x = x + (A W^T + b) ; h = LN_b(x)                (attention proj + norm2, ptv3.py:416-421)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    if dtype == torch.bfloat16:
+        A, W = _bf16_round(A), _bf16_round(W)
+    b, res, cb = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(N, generator=g)
+    g1, b1 = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    g2, b2 = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    y = (A.double() @ W.double().t() + b.double()).float()
+    x_ref = res + F.layer_norm(y, (N,), g1, b1, 1e-5) + cb
+    h_ref = F.layer_norm(x_ref, (N,), g2, b2, 1e-5)
+    x = dev(res)
+    h = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm(dev(A, dtype), dev(W, dtype), x, bias=dev(b), ln_pre=(dev(g1), dev(b1)), res=x, colbias=dev(cb),
+             ln_post=(dev(g2), dev(b2)), ln_out=h)
+    tol_h = 2e-4 if dtype == torch.float32 else 0.03
+    assert (x.cpu() - x_ref).abs().max().item() < 2e-4
+    assert (h.float().cpu() - h_ref).abs().max().item() < tol_h * (1 + h_ref.abs().max().item())
+    x2_ref = res + y
+    h2_ref = F.layer_norm(x2_ref, (N,), g2, b2, 1e-5)
+    x2 = dev(res)
+    ops.gemm(dev(A, dtype), dev(W, dtype), x2, bias=dev(b), res=x2, ln_post=(dev(g2), dev(b2)), ln_out=h)
+    assert (x2.cpu() - x2_ref).abs().max().item() < 2e-4
+    assert (h.float().cpu() - h2_ref).abs().max().item() < tol_h * (1 + h2_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(448, 512, 2048), (832, 1536, 512), (100, 256, 4096), (3392, 256, 256)])
 def test_gemm_split_k(ops, dtype, M, N, K):
     """Few output tiles + long K -> the split-K path (partials in the workspace, second-pass epilogue)."""
