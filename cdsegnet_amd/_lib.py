@@ -36,6 +36,26 @@ class GemmArgs(Structure):
     ]
 
 
+class BlockDesc(Structure):
+    _fields_ = [
+        ("dtype", c_int), ("channels", c_int), ("heads", c_int), ("hidden", c_int),
+        ("attn_scale", c_float), ("ln_eps", c_float),
+        ("cpe_conv_w", c_void_p), ("cpe_conv_b", c_void_p), ("cpe_lin_w", c_void_p), ("cpe_lin_b", c_void_p),
+        ("cpe_ln_g", c_void_p), ("cpe_ln_b", c_void_p), ("norm1_g", c_void_p), ("norm1_b", c_void_p),
+        ("qkv_w", c_void_p), ("qkv_b", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p),
+        ("norm2_g", c_void_p), ("norm2_b", c_void_p), ("fc1_w", c_void_p), ("fc1_b", c_void_p),
+        ("fc2_w", c_void_p), ("fc2_b", c_void_p),
+    ]
+
+
+class BlockIO(Structure):
+    _fields_ = [
+        ("n", c_long), ("x", c_void_p), ("xc_in", c_void_p), ("xc_out", c_void_p), ("tbias", c_void_p),
+        ("nbr", c_void_p), ("gidx", c_void_p), ("widx", c_void_p), ("patch_start", c_void_p),
+        ("num_patches", c_int), ("max_len", c_int), ("scratch", c_void_p), ("scratch_bytes", c_size_t),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/cdseg.h declares
 SIGNATURES = {
     "cdseg_abi_version": (c_int, []),
@@ -58,12 +78,16 @@ SIGNATURES = {
     "cdseg_nbr_table": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "cdseg_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
+    "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
     "cdseg_stem_conv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
                                 c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "cdseg_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
                                 c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "cdseg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "cdseg_prof_enable": (c_int, [c_int]),
+    "cdseg_prof_summary": (c_int, [POINTER(ctypes.c_double), POINTER(c_long)]),
     "cdseg_segment_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_int,
                                   c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "cdseg_segment_mean": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),

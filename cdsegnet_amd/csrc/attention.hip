@@ -21,9 +21,15 @@
 //    makes the softmax denominator fall out of the same MFMA (row 16 of the result);
 //  * f32 (the 1e-3 parity mode): v_mfma_f32_16x16x4_f32 for both products, exact fp32.
 // LDS layouts are bank-conflict free for every fragment read (tools/lds_conflicts.py).
+#include <vector>
+
 #include "common.h"
 
 namespace {
+
+// optional HIP-event timing of every attention launch on its own stream (bench.py's roofline leg)
+bool g_prof_on = false;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 
 struct AttnP {
   const void* q;
@@ -361,12 +367,44 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
       return CDSEG_ERR_LAUNCH;
     attr_done = true;
   }
+  if (dtype != CDSEG_BF16 && dtype != CDSEG_F32) return CDSEG_ERR_ARG;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof_on) {
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CDSEG_ERR_LAUNCH;
+    (void)hipEventRecord(e0, s);
+  }
   if (dtype == CDSEG_BF16)
     hipLaunchKernelGGL(attn_bf16_kernel, grid, block, SMEM_BF16, s, p);
-  else if (dtype == CDSEG_F32)
-    hipLaunchKernelGGL(attn_f32_kernel, grid, block, SMEM_F32, s, p);
   else
-    return CDSEG_ERR_ARG;
+    hipLaunchKernelGGL(attn_f32_kernel, grid, block, SMEM_F32, s, p);
+  if (g_prof_on) {
+    (void)hipEventRecord(e1, s);
+    g_prof_events.emplace_back(e0, e1);
+  }
   CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// enable / disable event timing of the attention launches (drops earlier records)
+extern "C" int cdseg_prof_enable(int on) {
+  for (auto& ev : g_prof_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  g_prof_events.clear();
+  g_prof_on = on != 0;
+  return CDSEG_OK;
+}
+
+// after a device synchronisation: total milliseconds and number of attention launches recorded
+extern "C" int cdseg_prof_summary(double* total_ms, long* launches) {
+  double t = 0.0;
+  for (auto& ev : g_prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) != hipSuccess) return CDSEG_ERR_LAUNCH;
+    t += ms;
+  }
+  if (total_ms) *total_ms = t;
+  if (launches) *launches = (long)g_prof_events.size();
   return CDSEG_OK;
 }

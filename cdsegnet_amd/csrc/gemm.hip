@@ -470,7 +470,9 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   constexpr int BK = NCH * (16 / (int)sizeof(CT));
   const unsigned gm = (unsigned)((p.M + 63) / 64);
   const bool ln = p.ln_pre_g || p.ln_post_g;
-  const int bn = p.N <= 32 ? 32 : ((p.N <= 64 || (!ln && p.M <= 4096 && p.N <= 256)) ? 64 : 128);
+  // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
+  const int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+  (void)ln;
   const unsigned gn = (unsigned)((p.N + bn - 1) / bn);
   // split-K when the output tiles alone cannot fill the chip (deep stages: few points, long reductions)
   int splits = 1;

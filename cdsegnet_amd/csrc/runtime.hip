@@ -1,0 +1,155 @@
+// Native executor for one PTv3 Block (ref: ptv3.py:399-428): issues all launches of the block
+// from C++ so the Python binding pays one call instead of ~10 (the per-launch host cost of the
+// binding, ~10 us, was the step's critical path once the kernels were fast).
+#include <cstring>
+
+#include "common.h"
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off, cap;
+  void* take(size_t bytes) {
+    off = align_up(off, 256);
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+constexpr int FUSE_LN_MAX_C = 128;
+constexpr size_t SPLITK_WS_CAP = (size_t)64 << 20;
+
+inline size_t esz(int dtype) { return dtype == CDSEG_F32 ? 4 : 2; }
+
+struct Layout {
+  void *y, *h, *qkv, *o, *u, *y2, *ws;
+  size_t ws_bytes, total;
+};
+
+Layout carve(const cdseg_block_desc* d, long n, void* scratch) {
+  Carver c{(char*)scratch, 0, 0};
+  const size_t e = esz(d->dtype);
+  const size_t C = d->channels;
+  Layout L;
+  L.y = c.take(n * C * e);
+  L.h = c.take(n * C * e);
+  L.qkv = c.take(n * 3 * C * e);
+  L.o = c.take(n * C * e);
+  L.u = c.take(n * (size_t)d->hidden * e);
+  L.y2 = d->channels > FUSE_LN_MAX_C ? c.take(n * C * 4) : nullptr;
+  // split-K partial tiles: needed by any GEMM of the block whose output has few tiles (the narrowest is N = C)
+  const long tiles = ((n + 63) / 64) * (((long)C + 127) / 128);
+  L.ws_bytes = tiles < 256 ? (size_t)16 * n * (size_t)(3 * C > (size_t)d->hidden ? 3 * C : d->hidden) * 4 : 0;
+  if (L.ws_bytes > SPLITK_WS_CAP) L.ws_bytes = SPLITK_WS_CAP;
+  L.ws = L.ws_bytes ? c.take(L.ws_bytes) : nullptr;
+  L.total = align_up(c.off, 256);
+  return L;
+}
+
+cdseg_gemm_args base_args(const cdseg_block_desc* d, const Layout& L, long n) {
+  cdseg_gemm_args a;
+  std::memset(&a, 0, sizeof(a));
+  a.M = n;
+  a.kvol = 1;
+  a.a_dtype = a.compute_dtype = d->dtype;
+  a.ws = L.ws;
+  a.ws_bytes = L.ws_bytes;
+  a.ln_eps = d->ln_eps;
+  return a;
+}
+
+}  // namespace
+
+extern "C" size_t cdseg_block_scratch_bytes(const cdseg_block_desc* d, long n) {
+  if (!d || n <= 0) return 0;
+  return carve(d, n, nullptr).total;
+}
+
+extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_io* io, void* stream) {
+  if (!d || !io || !io->x || !io->xc_in || !io->xc_out || !io->nbr || !io->gidx || !io->widx || !io->patch_start)
+    return CDSEG_ERR_ARG;
+  const long n = io->n;
+  if (n <= 0) return CDSEG_OK;
+  const int C = d->channels, T = d->dtype;
+  if (C != d->heads * CDSEG_HEAD_DIM) return CDSEG_ERR_UNSUPPORTED;
+  const Layout L = carve(d, n, io->scratch);
+  if (!io->scratch || io->scratch_bytes < L.total) return CDSEG_ERR_WORKSPACE;
+  const bool fuse = C <= FUSE_LN_MAX_C;
+  int rc;
+
+  // ---- CPE: x += LN(Linear(SubMConv3d(xc)))  [+ t bias];  h = LN1(x)      (ptv3.py:401-413)
+  {
+    cdseg_gemm_args a = base_args(d, L, n);
+    a.A = io->xc_in; a.lda = C; a.W = d->cpe_conv_w; a.bias = d->cpe_conv_b; a.nbr = io->nbr; a.kvol = 27;
+    a.N = C; a.K = C; a.out = L.y; a.ldo = C; a.out_dtype = T;
+    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+  }
+  if (fuse) {
+    cdseg_gemm_args a = base_args(d, L, n);
+    a.A = L.y; a.lda = C; a.W = d->cpe_lin_w; a.bias = d->cpe_lin_b; a.N = C; a.K = C;
+    a.ln_pre_g = d->cpe_ln_g; a.ln_pre_b = d->cpe_ln_b; a.res = io->x; a.ldres = C; a.colbias = io->tbias;
+    a.out = io->x; a.ldo = C; a.out_dtype = CDSEG_F32;
+    a.ln_post_g = d->norm1_g; a.ln_post_b = d->norm1_b; a.ln_out = L.h; a.ldln = C; a.ln_out_dtype = T;
+    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+  } else {
+    cdseg_gemm_args a = base_args(d, L, n);
+    a.A = L.y; a.lda = C; a.W = d->cpe_lin_w; a.bias = d->cpe_lin_b; a.N = C; a.K = C;
+    a.out = L.y2; a.ldo = C; a.out_dtype = CDSEG_F32;
+    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+    if ((rc = cdseg_layernorm(L.y2, CDSEG_F32, C, d->cpe_ln_g, d->cpe_ln_b, d->ln_eps, io->x, C, io->tbias, io->x,
+                              CDSEG_F32, C, nullptr, 0, 0, n, C, stream)) != CDSEG_OK)
+      return rc;
+    if ((rc = cdseg_layernorm(io->x, CDSEG_F32, C, d->norm1_g, d->norm1_b, d->ln_eps, nullptr, 0, nullptr, L.h, T, C,
+                              nullptr, 0, 0, n, C, stream)) != CDSEG_OK)
+      return rc;
+  }
+  // ---- attention: x += proj(attn(qkv(h)));  h = LN2(x)                    (ptv3.py:413-421)
+  {
+    cdseg_gemm_args a = base_args(d, L, n);
+    a.A = L.h; a.lda = C; a.W = d->qkv_w; a.bias = d->qkv_b; a.N = 3 * C; a.K = C;
+    a.out = L.qkv; a.ldo = 3 * C; a.out_dtype = T;
+    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+  }
+  {
+    const size_t e = esz(T);
+    const char* q = (const char*)L.qkv;
+    if ((rc = cdseg_attention(q, q + (size_t)C * e, q + (size_t)2 * C * e, 3 * C, 3 * C, 3 * C, io->gidx, io->gidx,
+                              io->widx, io->patch_start, io->num_patches, d->heads, io->max_len, d->attn_scale, L.o, C,
+                              T, stream)) != CDSEG_OK)
+      return rc;
+  }
+  {
+    cdseg_gemm_args a = base_args(d, L, n);
+    a.A = L.o; a.lda = C; a.W = d->proj_w; a.bias = d->proj_b; a.N = C; a.K = C;
+    a.res = io->x; a.ldres = C; a.out = io->x; a.ldo = C; a.out_dtype = CDSEG_F32;
+    if (fuse) {
+      a.ln_post_g = d->norm2_g; a.ln_post_b = d->norm2_b; a.ln_out = L.h; a.ldln = C; a.ln_out_dtype = T;
+    }
+    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+    if (!fuse &&
+        (rc = cdseg_layernorm(io->x, CDSEG_F32, C, d->norm2_g, d->norm2_b, d->ln_eps, nullptr, 0, nullptr, L.h, T, C,
+                              nullptr, 0, 0, n, C, stream)) != CDSEG_OK)
+      return rc;
+  }
+  // ---- MLP: x += fc2(GELU(fc1(h)));  xc = T(x)                            (ptv3.py:423-427)
+  {
+    cdseg_gemm_args a = base_args(d, L, n);
+    a.A = L.h; a.lda = C; a.W = d->fc1_w; a.bias = d->fc1_b; a.N = d->hidden; a.K = C; a.act = CDSEG_ACT_GELU;
+    a.out = L.u; a.ldo = d->hidden; a.out_dtype = T;
+    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+  }
+  {
+    cdseg_gemm_args a = base_args(d, L, n);
+    a.A = L.u; a.lda = d->hidden; a.W = d->fc2_w; a.bias = d->fc2_b; a.N = C; a.K = d->hidden;
+    a.res = io->x; a.ldres = C; a.out = io->x; a.ldo = C; a.out_dtype = CDSEG_F32;
+    if ((const void*)io->xc_out != (const void*)io->x) {
+      a.out2 = io->xc_out; a.ldo2 = C; a.out2_dtype = T;
+    }
+    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+  }
+  return CDSEG_OK;
+}

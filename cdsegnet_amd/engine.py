@@ -62,25 +62,30 @@ class Level:
             self._nbr[key] = ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
         return self._nbr[key]
 
+    def pad_host(self, patch_size, enable_flash):
+        """Host side of the padding plan (ref: ptv3.py:188-250): K, offs, offs_pad, patch_start (int32 arrays)."""
+        counts = np.diff(np.asarray(self.offs_host, dtype=np.int64))
+        K = int(patch_size) if enable_flash else int(min(int(counts.min()), patch_size))
+        pad_counts = np.where(counts > K, (counts + K - 1) // K * K, counts)
+        offs_pad = np.concatenate([[0], np.cumsum(pad_counts)])
+        starts = [np.arange(offs_pad[b], offs_pad[b + 1], K) for b in range(len(counts))]
+        patch_start = np.concatenate(starts + [offs_pad[-1:]]).astype(np.int32)
+        return K, np.asarray(self.offs_host, dtype=np.int32), offs_pad.astype(np.int32), patch_start
+
+    def set_pad(self, key, K, offs_pad_np, patch_start_np, offs_dev, offs_pad_dev, patch_start_dev):
+        self._pad[key] = (K, int(offs_pad_np[-1]), offs_dev, offs_pad_dev, patch_start_dev,
+                          int(np.diff(patch_start_np).max()),
+                          float((np.diff(patch_start_np).astype(np.float64) ** 2).sum()))
+
     def pad(self, patch_size, enable_flash):
         """(K, n_pad, offs_dev, offs_pad_dev, patch_start_dev, max_len, sum_L2) - ref: ptv3.py:188-250."""
         key = (patch_size, enable_flash)
-        if key not in self._pad:
-            counts = np.diff(np.asarray(self.offs_host, dtype=np.int64))
-            K = int(patch_size) if enable_flash else int(min(int(counts.min()), patch_size))
-            pad_counts = np.where(counts > K, (counts + K - 1) // K * K, counts)
-            offs_pad = np.concatenate([[0], np.cumsum(pad_counts)])
-            starts = []
-            for b in range(len(counts)):
-                starts.append(np.arange(offs_pad[b], offs_pad[b + 1], K))
-            patch_start = np.concatenate(starts + [offs_pad[-1:]]).astype(np.int32)
-            max_len = int(np.diff(patch_start).max())
+        if key not in self._pad:  # not pre-uploaded by Engine.build_plan: upload now
+            K, offs, offs_pad, patch_start = self.pad_host(patch_size, enable_flash)
             dev = self.grid.device
-            self._pad[key] = (K, int(offs_pad[-1]),
-                              torch.tensor(np.asarray(self.offs_host, dtype=np.int32), device=dev),
-                              torch.tensor(offs_pad.astype(np.int32), device=dev),
-                              torch.tensor(patch_start, device=dev), max_len,
-                              float((np.diff(patch_start).astype(np.float64) ** 2).sum()))
+            up = torch.tensor(np.concatenate([offs, offs_pad, patch_start]), device=dev)
+            a, b = len(offs), len(offs) + len(offs_pad)
+            self.set_pad(key, K, offs_pad, patch_start, up[:a], up[a:b], up[b:])
         return self._pad[key]
 
     def slots(self, curve, patch_size, enable_flash):
@@ -122,6 +127,9 @@ class Engine:
         self.device = None
         self.w = None
         self.rng_offset = 0
+        self.use_native_blocks = True  # one library call per Block instead of ~8 binding calls
+        self._pad_keys = None
+        self.attn_work = 0.0  # algorithmic attention FLOPs issued so far (4 * 16 * H * sum_p L_p^2 per launch)
 
     # ------------------------------------------------------------------ weights
     def prepare(self, device):
@@ -130,6 +138,7 @@ class Engine:
         self.device = device
         T = self.T
         w = {}
+        self._blocks_to_describe = []
 
         def f32(t):
             return t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -150,7 +159,10 @@ class Engine:
             shift = mod.bias.detach().double() - mod.running_mean.detach().double() * scale
             w[pre + ".scale"], w[pre + ".shift"] = f32(scale), f32(shift)
 
+        self.block_desc = {}
+
         def block(mod, pre):
+            self._blocks_to_describe.append((mod, pre))
             conv(mod.cpe[0], pre + ".cpe0")
             lin(mod.cpe[1], pre + ".cpe1")
             ln(mod.cpe[2], pre + ".cpe2")
@@ -233,6 +245,24 @@ class Engine:
                 w["x.feat_scale"] = torch.full((c,), cb.tm_feat, dtype=torch.float32, device=device)
                 w["x.feat_zero"] = torch.zeros(c, dtype=torch.float32, device=device)
         self.w = w
+        # native Block executor: one descriptor per Block (weights never move after prepare)
+        self.native_blocks = hasattr(ops, "block_forward") and self.use_native_blocks
+        if self.native_blocks:
+            for mod, pre in self._blocks_to_describe:
+                t = dict(cpe_conv_w=w[pre + ".cpe0.w"], cpe_conv_b=w[pre + ".cpe0.b"], cpe_lin_w=w[pre + ".cpe1.w"],
+                         cpe_lin_b=w[pre + ".cpe1.b"], cpe_ln_g=w[pre + ".cpe2.g"], cpe_ln_b=w[pre + ".cpe2.b"],
+                         norm1_g=w[pre + ".norm1.g"], norm1_b=w[pre + ".norm1.b"], qkv_w=w[pre + ".qkv.w"],
+                         qkv_b=w[pre + ".qkv.b"], proj_w=w[pre + ".proj.w"], proj_b=w[pre + ".proj.b"],
+                         norm2_g=w[pre + ".norm2.g"], norm2_b=w[pre + ".norm2.b"], fc1_w=w[pre + ".fc1.w"],
+                         fc1_b=w[pre + ".fc1.b"], fc2_w=w[pre + ".fc2.w"], fc2_b=w[pre + ".fc2.b"])
+                self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
+                                                           mod.attn.scale, 1e-5, t)
+        self._scratch = None
+
+    def scratch(self, nbytes):
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8, device=self.device)
+        return self._scratch
 
     # ------------------------------------------------------------------ plan
     def build_plan(self, grid, offset_dev, offset_host, n):
@@ -283,6 +313,25 @@ class Engine:
                 g, b, c4 = ops.pool_gather(tmp[i][1], m, n, cum, grid0, bat0, code0)
                 plan.levels[cum] = Level(cum, depth - cum, m, g, b, c4, [0] + [v + 1 for v in e])
                 plan.links[(0, cum)] = (tmp[i][0], tmp[i][1])
+        # every padding plan the model will ask for, uploaded with ONE host->device copy
+        if self._pad_keys is None:  # static per model: walk the module tree once
+            self._pad_keys = sorted({(int(m_.patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
+                                     if hasattr(m_, "patch_size") and hasattr(m_, "enable_flash")} |
+                                    {(int(m_.q_patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
+                                     if hasattr(m_, "q_patch_size")})
+        pad_keys = self._pad_keys
+        chunks, meta = [], []
+        for cum, lv in plan.levels.items():
+            for key in pad_keys:
+                K, offs, offs_pad, patch_start = lv.pad_host(*key)
+                meta.append((lv, key, K, offs_pad, patch_start, len(offs), len(offs_pad), len(patch_start)))
+                chunks += [offs, offs_pad, patch_start]
+        up = torch.tensor(np.concatenate(chunks), device=grid.device)
+        pos = 0
+        for lv, key, K, offs_pad, patch_start, la, lb, lc in meta:
+            lv.set_pad(key, K, offs_pad, patch_start, up[pos:pos + la], up[pos + la:pos + la + lb],
+                       up[pos + la + lb:pos + la + lb + lc])
+            pos += la + lb + lc
         return plan
 
     # ------------------------------------------------------------------ layers
@@ -332,6 +381,17 @@ class Engine:
         """ref: ptv3.py:399-428."""
         w, lv = self.w, st.level
         n, c = st.x.shape
+        if self.native_blocks:
+            att = mod.attn
+            gidx, widx = lv.slots(st.curves[att.order_index], att.patch_size, att.enable_flash)
+            _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
+            self.attn_work += 64.0 * att.num_heads * sum_l2
+            desc = self.block_desc[pre]
+            xc_out = st.x if self.T == torch.float32 else self._buf(n, c, self.T)
+            ops.block_forward(desc, n, st.x, st.xc, xc_out, tbias, lv.nbr(3), gidx, widx, patch_start,
+                              patch_start.numel() - 1, max_len, self.scratch(ops.block_scratch_bytes(desc, n)))
+            st.xc = xc_out
+            return
         h = self._cpe(st, pre + ".cpe", st.xc, tbias, next_norm=pre + ".norm1")
         qkv = self._buf(n, 3 * c, self.T)
         ops.gemm(h, w[pre + ".qkv.w"], qkv, bias=w[pre + ".qkv.b"])
@@ -339,6 +399,7 @@ class Engine:
         curve = st.curves[att.order_index]
         gidx, widx = lv.slots(curve, att.patch_size, att.enable_flash)
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
+        self.attn_work += 64.0 * att.num_heads * sum_l2
         o = self._buf(n, c, self.T)
         ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
                       att.scale, o, work=64.0 * att.num_heads * sum_l2)
@@ -423,6 +484,7 @@ class Engine:
         q_gidx, widx = lv.slots(nst.curves[att.order_index], K, att.enable_flash)
         kv_gidx, _ = lv.slots(cst.curves[att.order_index], K, att.enable_flash)
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(K, att.enable_flash)
+        self.attn_work += 64.0 * att.num_heads * sum_l2
         o = self._buf(n, cq, self.T)
         ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o,
                       work=64.0 * att.num_heads * sum_l2)

@@ -64,6 +64,18 @@ class KernelTimer:
 TIMER = None
 
 
+def attention_prof_enable(on=True):
+    """Event-time every attention launch inside the library (works for the native Block executor too)."""
+    check(_LIB.cdseg_prof_enable(1 if on else 0), "prof_enable")
+
+
+def attention_prof_summary():
+    """(total_ms, launches) since attention_prof_enable(True); call after torch.cuda.synchronize()."""
+    ms, cnt = ctypes.c_double(0.0), ctypes.c_long(0)
+    check(_LIB.cdseg_prof_summary(ctypes.byref(ms), ctypes.byref(cnt)), "prof_summary")
+    return ms.value, cnt.value
+
+
 def set_timer(t):
     global TIMER
     TIMER = t
@@ -316,7 +328,7 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     else:
         a.ln_post_g = a.ln_post_b = a.ln_out = None
     a.ln_eps = float(ln_eps)
-    if ((m + 63) >> 6) * ((a.N + 63) >> 6) < 512:  # split-K partials: only when the output has few tiles
+    if ((m + 63) >> 6) * ((a.N + 127) >> 7) < 256:  # split-K partials: only when the output has few tiles
         ws = workspace(min(16 * m * a.N * 4, 64 << 20), out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     else:
@@ -330,6 +342,39 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
 
 def _dp(t):
     return None if t is None else t.data_ptr()
+
+
+def make_block_desc(dtype, channels, heads, hidden, attn_scale, ln_eps, tensors):
+    """Describe one Block's weights once (tensors: dict field -> tensor); returns an object to pass to
+    block_forward.  The tensors are kept alive by the returned handle."""
+    d = _lib.BlockDesc()
+    d.dtype, d.channels, d.heads, d.hidden = _DT[dtype], int(channels), int(heads), int(hidden)
+    d.attn_scale, d.ln_eps = float(attn_scale), float(ln_eps)
+    for k, t in tensors.items():
+        setattr(d, k, t.data_ptr())
+    return (d, ctypes.byref(d), dict(tensors))
+
+
+def block_scratch_bytes(desc, n):
+    return _LIB.cdseg_block_scratch_bytes(desc[1], int(n))
+
+
+_BLOCK_IO = None
+
+
+def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start, num_patches, max_len, scratch):
+    """One PTv3 Block on the native executor (all launches issued by the library, one host call)."""
+    global _BLOCK_IO
+    if _BLOCK_IO is None:
+        io = _lib.BlockIO()
+        _BLOCK_IO = (io, ctypes.byref(io))
+    io, ref = _BLOCK_IO
+    io.n = int(n)
+    io.x, io.xc_in, io.xc_out, io.tbias = x.data_ptr(), xc_in.data_ptr(), xc_out.data_ptr(), _dp(tbias)
+    io.nbr, io.gidx, io.widx, io.patch_start = nbr.data_ptr(), gidx.data_ptr(), widx.data_ptr(), patch_start.data_ptr()
+    io.num_patches, io.max_len = int(num_patches), int(max_len)
+    io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
+    check(_LIB.cdseg_block_forward(desc[1], ref, _stream()), "block_forward")
 
 
 def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):

@@ -178,6 +178,11 @@ int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ld
                     const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
                     int num_heads, int max_len, float scale, void* out, int ldo, int dtype, void* stream);
 
+/* HIP-event timing of the attention launches on their own stream (bench.py's live roofline measurement):
+ * enable(1) starts recording, summary() (after a device sync) returns the summed durations. */
+int cdseg_prof_enable(int on);
+int cdseg_prof_summary(double* total_ms, long* launches);
+
 /* ------------------------------------------------------------------ pooling reduce
  * out[j] = act(max_{i in run j} y[i] * scale + shift), runs = seg_start (m+1).
  * ref: ptv3.py:510-515 (torch_scatter.segment_csr(..., "max")) + norm/act :548-551 */
@@ -200,6 +205,58 @@ int cdseg_gather_pad_cast(const float* src, int ld_src, const int32_t* idx, long
                           int dst_dtype, void* stream);
 /* out = a + alpha * b (fp32).  ref: default.py:228-236 (add_gaussian_noise) */
 int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, void* stream);
+
+/* ------------------------------------------------------------------ native Block executor
+ * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
+ * block itself (sparse-conv CPE, Linear+LayerNorms, QKV, window attention, proj, MLP), carving its
+ * temporaries from the caller's scratch buffer.  Replaces ~10 host round trips through the binding
+ * by one.  Weights are described once (cdseg_block_desc), the per-scene tensors per call
+ * (cdseg_block_io). */
+typedef struct cdseg_block_desc {
+  int dtype;       /* compute dtype T of weights / operand activations */
+  int channels;    /* C */
+  int heads;       /* C / 16 */
+  int hidden;      /* MLP hidden width */
+  float attn_scale;
+  float ln_eps;
+  const void* cpe_conv_w;  /* (C, 27*C) T */
+  const float* cpe_conv_b;
+  const void* cpe_lin_w;   /* (C, C) T */
+  const float* cpe_lin_b;
+  const float* cpe_ln_g;
+  const float* cpe_ln_b;
+  const float* norm1_g;
+  const float* norm1_b;
+  const void* qkv_w;       /* (3C, C) T */
+  const float* qkv_b;
+  const void* proj_w;      /* (C, C) T */
+  const float* proj_b;
+  const float* norm2_g;
+  const float* norm2_b;
+  const void* fc1_w;       /* (hidden, C) T */
+  const float* fc1_b;
+  const void* fc2_w;       /* (C, hidden) T */
+  const float* fc2_b;
+} cdseg_block_desc;
+
+typedef struct cdseg_block_io {
+  long n;                  /* points at this stage */
+  float* x;                /* (n, C) fp32 residual stream, updated in place */
+  const void* xc_in;       /* (n, C) T: CPE conv input (sparse_conv_feat of the reference) */
+  void* xc_out;            /* (n, C) T: shadow copy of the block output (may alias x when T is fp32) */
+  const float* tbias;      /* (C) timestep bias or NULL */
+  const int32_t* nbr;      /* (n, 27) kernel map of the stage */
+  const int32_t* gidx;     /* attention slot plan of the block's curve */
+  const int32_t* widx;
+  const int32_t* patch_start;
+  int num_patches;
+  int max_len;
+  void* scratch;           /* >= cdseg_block_scratch_bytes(desc, n) */
+  size_t scratch_bytes;
+} cdseg_block_io;
+
+size_t cdseg_block_scratch_bytes(const cdseg_block_desc* desc, long n);
+int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, void* stream);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,21 @@ def test_seeded_default_draws_replay_the_reference():
     assert err < 1e-3
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_native_block_executor_equals_binding_sequence(precision):
+    """The C++ Block executor (cdseg_block_forward) issues the same kernels as the per-op binding path."""
+    fx = load_fixture("full_e2e_8k.npz")
+    model = build(fixture_cfg(fx), fixture_state_dict(fx), precision)
+    assert model.engine().use_native_blocks
+    a = run(model, fixture_input(fx), fixture_draws(fx))
+    assert model.engine().native_blocks
+    model._drop_engine()
+    model.engine().use_native_blocks = False
+    b = run(model, fixture_input(fx), fixture_draws(fx))
+    assert not model.engine().native_blocks
+    assert np.array_equal(a, b)
+
+
 def test_full_width_fp32_matches_reference_golden():
     fx = load_fixture("full_e2e_8k.npz")
     model = build(fixture_cfg(fx), fixture_state_dict(fx), "fp32")
