@@ -95,6 +95,8 @@ SIGNATURES = {
     "cdseg_randn": (c_int, [c_void_p, c_long, c_uint64, c_uint64, c_void_p]),
     "cdseg_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
     "cdseg_gather_pad_cast": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "cdseg_ddim_update": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p, c_long,
+                                  c_void_p]),
     "cdseg_axpy": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
 }
 

@@ -258,6 +258,17 @@ __global__ void gather_pad_cast_kernel(const float* __restrict__ src, int ld_src
   else ((bf16_t*)dst)[t] = f32_to_bf16(v);
 }
 
+// DDIM step on a uniform timestep (ref: default.py:192-214), same operation order as the reference
+__global__ void ddim_update_kernel(const float* __restrict__ xt, const float* __restrict__ eps, float s_ab1,
+                                   float s_1ab, float s_ab, float s_1ab1, int final_step, float* __restrict__ out,
+                                   long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = eps[i];
+  const float x0 = (xt[i] - s_1ab * e) / s_ab;
+  out[i] = final_step ? x0 : (s_ab1 * x0 + s_1ab1 * e);
+}
+
 __global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha,
                             float* __restrict__ out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,6 +399,15 @@ int cdseg_gather_pad_cast(const float* src, int ld_src, const int32_t* idx, long
   const long total = n * cpad;
   hipLaunchKernelGGL(gather_pad_cast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      src, ld_src, idx, n, cin, cpad, dst, dst_dtype);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_ddim_update(const float* xt, const float* eps, float sqrt_ab_prev, float sqrt_1m_ab, float sqrt_ab,
+                      float sqrt_1m_ab_prev, int final_step, float* out, long n, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xt, eps,
+                     sqrt_ab_prev, sqrt_1m_ab, sqrt_ab, sqrt_1m_ab_prev, final_step, out, n);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

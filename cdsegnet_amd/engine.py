@@ -194,6 +194,15 @@ class Engine:
             bn(mod.proj[1], pre + ".proj_bn")
             lin(mod.proj_skip[0], pre + ".skip")
             bn(mod.proj_skip[1], pre + ".skip_bn")
+            if mod.skip_connection_mode == "cat":
+                f = (2 ** -0.5 if mod.skip_connection_scale else 1.0)
+                if mod.skip_connection_scale_i is not None:
+                    f *= 0.8 ** (int(mod.skip_connection_scale_i) - 1)
+                wc = mod.proj_cat[0].weight.detach().float()
+                c = wc.shape[0]
+                w[pre + ".cat_a.w"] = (wc[:, :c] * f).to(device=device, dtype=T).contiguous()
+                w[pre + ".cat_b.w"] = wc[:, c:].to(device=device, dtype=T).contiguous()
+                w[pre + ".cat.b"] = f32(mod.proj_cat[0].bias)
 
         bb = self.model.backbone
         stem(bb._n_embedding, "n_emb")
@@ -228,6 +237,19 @@ class Engine:
                             tb.append(f32(mod.t_mlp.bias))
                             toff[f"c_enc{s}.{name}"] = (off, off + mod.channels)
                             off += mod.channels
+            for s in range(bb.c_num_stages - 1):
+                dec = getattr(bb._c_dec, f"dec{s}")
+                unpool(dec.up, f"c_dec{s}.up")
+                for name, mod in dec._modules.items():
+                    if name.startswith("block"):
+                        block(mod, f"c_dec{s}.{name}")
+                        if bb.T_dim != -1:
+                            tw.append(f32(mod.t_mlp.weight))
+                            tb.append(f32(mod.t_mlp.bias))
+                            toff[f"c_dec{s}.{name}"] = (off, off + mod.channels)
+                            off += mod.channels
+            if isinstance(bb._c_head, torch.nn.Linear):
+                lin(bb._c_head, "c_head")
             if bb.T_dim != -1:
                 w["t.fc1.w"], w["t.fc1.b"] = f32(bb.fc_t1.weight), f32(bb.fc_t1.bias)
                 w["t.fc2.w"], w["t.fc2.b"] = f32(bb.fc_t2.weight), f32(bb.fc_t2.bias)
@@ -440,22 +462,40 @@ class Engine:
         out.parent = st
         return out
 
-    def run_unpooling(self, plan, st, pre):
-        """n-branch un-pooling, 'add' mode (ref: ptv3.py:597-630).  xc keeps the PRE-add skip
-        feature: the reference leaves sparse_conv_feat stale there and the next CPE conv reads it."""
+    def run_unpooling(self, plan, st, pre, mod):
+        """ref: ptv3.py:597-630.  xc keeps the PRE-merge, unscaled skip feature: the reference leaves
+        sparse_conv_feat stale there and the next CPE conv reads it.
+        'add' (n-branch): x = f * skip + child[cluster];  'cat' (c-branch): x = proj_cat([f * skip, child[cluster]])
+        with f = 2^-0.5 (skip_connection_scale) * 0.8^(i-1) (skip_connection_scale_i, False -> 1.25)."""
         w = self.w
         parent = st.parent
         fine, coarse = parent.level, st.level
         cluster, _ = plan.link(fine.cum, coarse.cum)
         cout = w[pre + ".proj.w"].shape[0]
-        child = self._buf(coarse.n, cout, torch.float32)
-        ops.gemm(st.xc, w[pre + ".proj.w"], child, bias=w[pre + ".proj.b"], scale=w[pre + ".proj_bn.scale"],
-                 shift=w[pre + ".proj_bn.shift"], act=ops.ACT_GELU)
+        f = (2 ** -0.5 if mod.skip_connection_scale else 1.0)
+        if mod.skip_connection_scale_i is not None:
+            f *= 0.8 ** (int(mod.skip_connection_scale_i) - 1)
         x = self._buf(fine.n, cout, torch.float32)
         xc = self._buf(fine.n, cout, self.T)
-        ops.gemm(parent.xc, w[pre + ".skip.w"], x, bias=w[pre + ".skip.b"], scale=w[pre + ".skip_bn.scale"],
-                 shift=w[pre + ".skip_bn.shift"], act=ops.ACT_GELU, add_src=child, add_idx=cluster, out2=xc,
-                 out2_pre_add=True)
+        if mod.skip_connection_mode == "add":
+            if f != 1.0:
+                raise NotImplementedError("scaled skip connection in 'add' mode (off in every shipped config)")
+            child = self._buf(coarse.n, cout, torch.float32)
+            ops.gemm(st.xc, w[pre + ".proj.w"], child, bias=w[pre + ".proj.b"], scale=w[pre + ".proj_bn.scale"],
+                     shift=w[pre + ".proj_bn.shift"], act=ops.ACT_GELU)
+            ops.gemm(parent.xc, w[pre + ".skip.w"], x, bias=w[pre + ".skip.b"], scale=w[pre + ".skip_bn.scale"],
+                     shift=w[pre + ".skip_bn.shift"], act=ops.ACT_GELU, add_src=child, add_idx=cluster, out2=xc,
+                     out2_pre_add=True)
+        else:
+            # proj_cat([f*par, child[inv]]) = par @ (f*Wa)^T + (child @ Wb^T)[inv] + b
+            child = self._buf(coarse.n, cout, self.T)
+            ops.gemm(st.xc, w[pre + ".proj.w"], child, bias=w[pre + ".proj.b"], scale=w[pre + ".proj_bn.scale"],
+                     shift=w[pre + ".proj_bn.shift"], act=ops.ACT_GELU)
+            z = self._buf(coarse.n, cout, torch.float32)
+            ops.gemm(child, w[pre + ".cat_b.w"], z)
+            ops.gemm(parent.xc, w[pre + ".skip.w"], xc, bias=w[pre + ".skip.b"], scale=w[pre + ".skip_bn.scale"],
+                     shift=w[pre + ".skip_bn.shift"], act=ops.ACT_GELU)
+            ops.gemm(xc, w[pre + ".cat_a.w"], x, bias=w[pre + ".cat.b"], add_src=z, add_idx=cluster)
         out = State(fine, x, xc, parent.curves)
         out.parent = parent.parent
         return out
@@ -496,13 +536,13 @@ class Engine:
         self._mlp(nst, "x.q_norm2", "x.fc")
 
     # ------------------------------------------------------------------ randomness
-    def draw(self, n, feat_shape, c_ch, noise_level, n_perms):
+    def draw(self, n, feat_shape, c_ch, noise_level, n_perms, always_noise=False):
         """The reference's CPU-generator consumption order (SURVEY.md finding 3)."""
         m = self.model
         d = {}
         if noise_level is not None:
             d["feat_noise"] = torch.randn(feat_shape) if m.noise_source == "torch_cpu" else None
-        if m.condition and m.dm and m.dm_input == "xt":
+        if m.condition and (always_noise or (m.dm and m.dm_input == "xt")):
             d["noise"] = (torch.normal(0, 1, size=(n, c_ch), dtype=torch.float32)
                           if m.noise_source == "torch_cpu" else None)
         if m.backbone.shuffle_orders:
@@ -518,20 +558,29 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def inference(self, input_dict, noise_level=None, draws=None):
+        """Single-step inference (ref: default.py:371-422)."""
         try:
             return self._inference(input_dict, noise_level, draws)
         finally:
             if hasattr(ops, "unbind_stream"):
                 ops.unbind_stream()
 
-    def _inference(self, input_dict, noise_level=None, draws=None):
+    def inference_ddim(self, input_dict, step=1, mode="avg", noise_level=None, draws=None):
+        """Multi-step inference MSAI (mode="avg") / MSFI ("final") (ref: default.py:278-369)."""
+        try:
+            return self._inference_ddim(input_dict, step, mode, noise_level, draws)
+        finally:
+            if hasattr(ops, "unbind_stream"):
+                ops.unbind_stream()
+
+    # -- shared set-up -------------------------------------------------------------------------------
+    def _setup(self, input_dict, noise_level, draws, n_backbone_calls, always_noise=False):
         m, bb = self.model, self.model.backbone
         feat = input_dict["feat"]
         dev = feat.device  # CPU tensors are rejected by every op (cdsegnet_amd.ops): no CPU fallback
         self.prepare(dev)
         if dev.type == "cuda" and hasattr(ops, "bind_stream"):
             ops.bind_stream()
-        w = self.w
         grid = input_dict["grid_coord"]
         offset = input_dict["offset"]
         n = feat.shape[0]
@@ -539,33 +588,38 @@ class Engine:
         offset_host = [int(v) for v in offset_host]
         cond = bb.condition
         c_ch = m.c_in_channels
-        n_perms = (2 + len(bb.c_stride) + len(bb.n_stride)) if cond else (1 + len(bb.n_stride))
+        per_call = (2 + len(bb.c_stride) + len(bb.n_stride)) if cond else (1 + len(bb.n_stride))
         if draws is None:
-            draws = self.draw(n, tuple(feat.shape), c_ch, noise_level, n_perms)
+            draws = self.draw(n, tuple(feat.shape), c_ch, noise_level, per_call * n_backbone_calls, always_noise)
         feat = feat.float().contiguous()
         if noise_level is not None:  # ref: default.py:373-374 (perturbs feat and rebinds it in input_dict)
             fn = draws.get("feat_noise")
             fn = self._device_randn(tuple(feat.shape)) if fn is None else fn.to(dev, torch.float32)
             feat = ops.axpy(feat, fn.contiguous(), noise_level)
             input_dict["feat"] = feat
-        perms = list(draws["perms"]) if bb.shuffle_orders else [None] * n_perms
-        pi = iter(perms)
-        no = len(bb.order)
-        base_curves = [CURVES.index(o) for o in bb.order]
-
+        perms = list(draws["perms"]) if bb.shuffle_orders else [None] * (per_call * n_backbone_calls)
         plan = self.build_plan(grid, offset.to(torch.int64), offset_host, n)
         self.last_plan = plan
+        return feat, draws, perms, plan, per_call
 
-        def shuffled(perm):
-            return list(base_curves) if perm is None else [base_curves[int(j)] for j in perm]
+    def _t_bias(self, t):
+        """Per-block timestep bias from the (uniform) embedding row (ref: ptv3.py:1772-1778, :406-411)."""
+        w = self.w
+        if self.model.backbone.T_dim == -1 or "t.table" not in w:
+            return {}
+        v = ops.gemv(w["t.fc1.w"], w["t.fc1.b"], w["t.table"][t + 1], ops.ACT_SWISH)  # table row 0 is t = -1
+        v = ops.gemv(w["t.fc2.w"], w["t.fc2.b"], v, ops.ACT_SWISH)
+        tall = ops.gemv(w["t.mlp.w"], w["t.mlp.b"], v, ops.ACT_NONE)
+        return {k: tall[a:b] for k, (a, b) in self.t_slices.items()}
 
-        n_cum, c_cum = plan.n_cum, plan.c_cum
-        if cond:
-            c_curves = shuffled(next(pi))
-        n_curves = shuffled(next(pi))
-
-        tb = {}
-        if cond:
+    def _inference(self, input_dict, noise_level=None, draws=None):
+        m, bb = self.model, self.model.backbone
+        feat, draws, perms, plan, _ = self._setup(input_dict, noise_level, draws, 1)
+        n, dev = feat.shape[0], feat.device
+        c_ch = m.c_in_channels
+        c_feat = c_perm = None
+        t = 0
+        if bb.condition:
             if m.dm and m.dm_input == "xt":  # ref: default.py:392-394
                 nz = draws.get("noise")
                 if nz is None:
@@ -576,12 +630,65 @@ class Engine:
             else:
                 c_feat = feat if c_ch == feat.shape[1] else input_dict["coord"].float().contiguous()
                 c_perm = plan.perm0
-                t = 0
-            if bb.T_dim != -1:  # ref: ptv3.py:1772-1778 on the (uniform) embedding row
-                v = ops.gemv(w["t.fc1.w"], w["t.fc1.b"], w["t.table"][t], ops.ACT_SWISH)
-                v = ops.gemv(w["t.fc2.w"], w["t.fc2.b"], v, ops.ACT_SWISH)
-                tall = ops.gemv(w["t.mlp.w"], w["t.mlp.b"], v, ops.ACT_NONE)
-                tb = {k: tall[a:b] for k, (a, b) in self.t_slices.items()}
+        logits, _ = self.backbone(plan, feat, c_feat, c_perm, t, perms, want_c=False)
+        return logits
+
+    def _inference_ddim(self, input_dict, step, mode, noise_level, draws):
+        m, bb = self.model, self.model.backbone
+        if not bb.condition:
+            return self._inference(input_dict, noise_level, draws)
+        if m.dm_target != "noise":
+            raise NotImplementedError("dm_target other than 'noise'")
+        schedule = np.linspace(-1, m.T - 1, num=step + 1, dtype=int)[::-1]  # ref: default.py:224-226
+        feat, draws, perms, plan, per_call = self._setup(input_dict, noise_level, draws, len(schedule), always_noise=True)
+        n, dev = feat.shape[0], feat.device
+        nz = draws.get("noise")
+        # the plan (codes, orders, kernel maps, slot plans) is step-invariant: built once, unlike the reference
+        c_xt = self._device_randn((n, m.c_in_channels)) if nz is None else \
+            ops.gather_rows(nz.to(dev, torch.float32).contiguous(), plan.perm0)
+        ab = m.Alpha_bar
+        n_pred = None
+        for k, t in enumerate(schedule):
+            t = int(t)
+            logits, eps = self.backbone(plan, feat, c_xt, None, t, perms[per_call * k:per_call * (k + 1)], want_c=True)
+            # DDIM update on the uniform timestep (ref: default.py:192-214); scalars in fp32 like the reference
+            s_ab, s_1ab = float(torch.sqrt(ab[t])), float(torch.sqrt(1 - ab[t]))
+            if t == 0:
+                c_xt = ops.ddim_update(c_xt, eps, 0.0, s_1ab, s_ab, 0.0, final=True)
+            else:
+                c_xt = ops.ddim_update(c_xt, eps, float(torch.sqrt(ab[t - 1])), s_1ab, s_ab,
+                                       float(torch.sqrt(1 - ab[t - 1])), final=False)
+            if mode == "avg":
+                n_pred = logits if n_pred is None else ops.axpy(n_pred, logits, 1.0)
+            else:
+                n_pred = logits
+            if t <= 0:
+                break
+        if mode == "avg":
+            n_pred = ops.axpy(torch.zeros_like(n_pred), n_pred, 1.0 / len(schedule))
+        return n_pred
+
+    # -- backbone ------------------------------------------------------------------------------------
+    def backbone(self, plan, feat, c_feat, c_perm, t, perms, want_c):
+        """PT-v3m1 forward (ref: ptv3.py:1757-1846).  feat (N,C) in the caller's order; c_feat with c_perm
+        (None: already in physical order).  Returns logits in the caller's order and, if want_c, the
+        c-head output (noise estimate) in physical order."""
+        bb = self.model.backbone
+        w = self.w
+        cond = bb.condition
+        n = feat.shape[0]
+        dev = feat.device
+        pi = iter(perms)
+        base_curves = [CURVES.index(o) for o in bb.order]
+
+        def shuffled(perm):
+            return list(base_curves) if perm is None else [base_curves[int(j)] for j in perm]
+
+        n_cum, c_cum = plan.n_cum, plan.c_cum
+        if cond:
+            c_curves = shuffled(next(pi))
+        n_curves = shuffled(next(pi))
+        tb = self._t_bias(t) if cond else {}
 
         def enc_stage(st, branch, s, cum, perm):
             enc = getattr(getattr(bb, f"_{branch}_enc"), f"enc{s}")
@@ -590,6 +697,15 @@ class Engine:
             for name, mod in enc._modules.items():
                 if name.startswith("block"):
                     key = f"{branch}_enc{s}.{name}"
+                    self.run_block(st, mod, key, tb.get(key))
+            return st
+
+        def dec_stage(st, branch, s):
+            dec = getattr(getattr(bb, f"_{branch}_dec"), f"dec{s}")
+            st = self.run_unpooling(plan, st, f"{branch}_dec{s}.up", dec.up)
+            for name, mod in dec._modules.items():
+                if name.startswith("block"):
+                    key = f"{branch}_dec{s}.{name}"
                     self.run_block(st, mod, key, tb.get(key))
             return st
 
@@ -612,15 +728,15 @@ class Engine:
             for s in range(bb.n_num_stages):
                 nst = enc_stage(nst, "n", s, n_cum, next(pi) if s > 0 else None)
         self.trace = {"n_bottleneck": nst.x}
-        # decoder (c-decoder and c-head are dead code in SSI: skipped)
+        # decoders.  In single-step inference the c-decoder / c-head never reach seg_logits (dead code).
+        c_out = None
+        if cond and want_c:
+            for s in reversed(range(bb.c_num_stages - 1)):
+                cst = dec_stage(cst, "c", s)
+            c_out = torch.empty((n, w["c_head.w"].shape[0]), dtype=torch.float32, device=dev)
+            ops.gemm(cst.xc, w["c_head.w"], c_out, bias=w["c_head.b"])
         for s in reversed(range(bb.n_num_stages - 1)):
-            dec = getattr(bb._n_dec, f"dec{s}")
-            if dec.up.skip_connection_mode != "add" or dec.up.skip_connection_scale_i is not None:
-                raise NotImplementedError("n-branch un-pooling other than 'add' without scaling")
-            nst = self.run_unpooling(plan, nst, f"n_dec{s}.up")
-            for name, mod in dec._modules.items():
-                if name.startswith("block"):
-                    self.run_block(nst, mod, f"n_dec{s}.{name}")
+            nst = dec_stage(nst, "n", s)
         # head, scattered back to the caller's point order (ref: ptv3.py:1813)
         if "n_head.w" in w:
             logits = torch.empty((n, w["n_head.w"].shape[0]), dtype=torch.float32, device=dev)
@@ -628,4 +744,4 @@ class Engine:
         else:
             logits = torch.empty((n, nst.x.shape[1]), dtype=torch.float32, device=dev)
             ops.scatter_rows(nst.x, plan.perm0, logits)
-        return logits
+        return logits, c_out

@@ -319,14 +319,14 @@ class PointTransformerV3(nn.Module):
 
 
 def calc_t_emb_table(T, t_emb_dim):
-    """Rows t = 0..T-1 of the sinusoidal timestep embedding, built once on the host with the very
-    ops the reference uses per call (ref: pointcept/utils/comm.py:21-39), so a row is bit-identical
+    """Rows t = -1..T-1 (row index t + 1) of the sinusoidal timestep embedding, built once on the host with
+    the very ops the reference uses per call (ref: pointcept/utils/comm.py:21-39), so a row is bit-identical
     to ``calc_t_emb(t * ones((N,1)), dim)[0]``."""
     assert t_emb_dim % 2 == 0
     half = t_emb_dim // 2
     c = np.log(10000) / (half - 1)
     f = torch.exp(torch.arange(half) * -c)
-    ts = torch.arange(T, dtype=torch.int64)[:, None]
+    ts = torch.arange(-1, T, dtype=torch.int64)[:, None]  # row 0 is t = -1 (last DDIM step, default.py:224-226)
     e = ts * f
     return torch.cat((torch.sin(e), torch.cos(e)), 1)
 
@@ -402,6 +402,19 @@ class DefaultSegmentorV2(nn.Module):
             raise NotImplementedError("eval=True (loss computation) is outside the inference hot path; "
                                       "the reference tester calls inference(eval=False) (engines/test.py:216)")
         return dict(seg_logits=self.engine().inference(input_dict, noise_level=noise_level, draws=draws))
+
+    @torch.no_grad()
+    def inference_ddim(self, input_dict, T=1000, step=1, report=10, eval=True, mode="avg", noise_level=None, draws=None):
+        """Multi-step inference (ref: default.py:278-369): MSAI mode="avg", MSFI mode="final".  The step-invariant
+        plan (serialization, kernel maps, slot plans) is built once and reused by all step+1 backbone calls."""
+        if eval:
+            raise NotImplementedError("eval=True (loss computation) is outside the inference hot path")
+        if T != self.T:
+            raise ValueError("T differs from the model's diffusion length")
+        if mode not in ("avg", "final"):
+            raise ValueError(mode)
+        return dict(seg_logits=self.engine().inference_ddim(input_dict, step=step, mode=mode, noise_level=noise_level,
+                                                            draws=draws))
 
     def forward(self, input_dict):
         raise NotImplementedError("training forward (default.py:424-493) is outside the single-step-inference hot path")

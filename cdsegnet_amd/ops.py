@@ -459,6 +459,14 @@ def gather_pad_cast(src, idx, cpad, dtype):
     return out
 
 
+def ddim_update(xt, eps, sqrt_ab_prev, sqrt_1m_ab, sqrt_ab, sqrt_1m_ab_prev, final=False):
+    out = torch.empty_like(xt)
+    check(_LIB.cdseg_ddim_update(_ptr(xt), _ptr(eps), float(sqrt_ab_prev), float(sqrt_1m_ab), float(sqrt_ab),
+                                 float(sqrt_1m_ab_prev), 1 if final else 0, _ptr(out), xt.numel(), _stream()),
+          "ddim_update")
+    return out
+
+
 def axpy(a, b, alpha):
     out = torch.empty_like(a)
     check(_lib.load().cdseg_axpy(_ptr(a), _ptr(b), float(alpha), _ptr(out), a.numel(), _stream()), "axpy")

@@ -203,6 +203,10 @@ int cdseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n,
  * engine's point order, padded to a 16-byte multiple so the stem conv runs on the gathered GEMM */
 int cdseg_gather_pad_cast(const float* src, int ld_src, const int32_t* idx, long n, int cin, int cpad, void* dst,
                           int dst_dtype, void* stream);
+/* DDIM update of the noise-branch input on a uniform timestep t (ref: default.py:192-214, dm_target="noise"):
+ * x0 = (xt - sqrt(1-ab_t) eps) / sqrt(ab_t); out = final ? x0 : sqrt(ab_{t-1}) x0 + sqrt(1-ab_{t-1}) eps */
+int cdseg_ddim_update(const float* xt, const float* eps, float sqrt_ab_prev, float sqrt_1m_ab, float sqrt_ab,
+                      float sqrt_1m_ab_prev, int final_step, float* out, long n, void* stream);
 /* out = a + alpha * b (fp32).  ref: default.py:228-236 (add_gaussian_noise) */
 int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, void* stream);
 

@@ -256,12 +256,64 @@ def gen_e2e(ref):
             json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, f, indent=0)
 
 
+def gen_ddim(ref):
+    """Multi-step inference (MSAI mode="avg", MSFI mode="final"), default.py:278-369."""
+    for tag, step, mode, seed in (("mini_ddim_avg2", 2, "avg", 17), ("mini_ddim_final1", 1, "final", 18)):
+        cfg = configs.mini_config()
+        model, sd = ref_model(ref, cfg, seed=6)
+        scene = synth.room_scene(27, 1800)
+        torch.manual_seed(seed)
+        with DrawRecorder() as rec, torch.no_grad():
+            out = model.inference_ddim(to_torch_input(scene), T=cfg["T"], step=step, eval=False, mode=mode)
+        kinds = [k for k, _ in rec.log]
+        assert kinds == ["normal"] + ["randperm"] * (8 * (step + 1)), kinds
+        fx = dict(coord=scene["coord"], grid_coord=scene["grid_coord"], feat=scene["feat"], offset=scene["offset"],
+                  logits=out["seg_logits"].numpy(), seed=np.int64(seed), sd_seed=np.int64(6), step=np.int64(step),
+                  mode=np.array(mode), noise=rec.log[0][1].numpy(),
+                  perms=np.stack([v.numpy() for k, v in rec.log if k == "randperm"]),
+                  cfg_json=np.array(json.dumps(cfg)),
+                  sd_checksum=np.float64(sum(float(v.double().abs().sum()) for v in sd.values())),
+                  sd_keys=np.array(list(sd.keys())),
+                  sd_shapes=np.array([json.dumps(list(v.shape)) for v in sd.values()]))
+        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **fx)
+        print(tag, out["seg_logits"].shape, float(out["seg_logits"].abs().mean()))
+
+
+def gen_ptv3(ref):
+    """condition=False: plain PTv3 through the same wrapper (configs/*/PTv3.py, ptv3.py:1818-1845)."""
+    cfg = configs.mini_config()
+    cfg["condition"] = cfg["backbone"]["condition"] = False
+    cfg["dm"] = False
+    run_e2e_nocond(ref, cfg, synth.room_scene(28, 2100), 21, 7, "mini_ptv3_room")
+
+
+def run_e2e_nocond(ref, cfg, scene, seed, sd_seed, tag):
+    model, sd = ref_model(ref, cfg, seed=sd_seed)
+    torch.manual_seed(seed)
+    with DrawRecorder() as rec, torch.no_grad():
+        out = model.inference(to_torch_input(scene), eval=False)
+    kinds = [k for k, _ in rec.log]
+    assert kinds == ["randperm"] * 5, kinds
+    fx = dict(coord=scene["coord"], grid_coord=scene["grid_coord"], feat=scene["feat"], offset=scene["offset"],
+              logits=out["seg_logits"].numpy(), seed=np.int64(seed), sd_seed=np.int64(sd_seed),
+              perms=np.stack([v.numpy() for k, v in rec.log if k == "randperm"]),
+              noise=np.zeros((0, 0), dtype=np.float32), cfg_json=np.array(json.dumps(cfg)),
+              sd_checksum=np.float64(sum(float(v.double().abs().sum()) for v in sd.values())),
+              sd_keys=np.array(list(sd.keys())), sd_shapes=np.array([json.dumps(list(v.shape)) for v in sd.values()]))
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **fx)
+    print(tag, out["seg_logits"].shape, float(out["seg_logits"].abs().mean()), "params", len(sd))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["ser", "e2e"]
+    which = sys.argv[1:] or ["ser", "e2e", "ddim", "ptv3"]
     if "ser" in which:
         gen_serialization(ref)
     if "e2e" in which:
         gen_e2e(ref)
+    if "ddim" in which:
+        gen_ddim(ref)
+    if "ptv3" in which:
+        gen_ptv3(ref)

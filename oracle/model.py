@@ -480,3 +480,106 @@ def inference(cfg, sd, input_dict, draws, T=1000, noise_level=None, run_dead=Fal
     with torch.no_grad():
         _, n_out = backbone_forward(cfg, sd, c_in, n_in, draws["perms"], run_dead=run_dead, trace=trace)
     return n_out
+
+
+# ------------------------------------------------------------------ multi-step inference (MSAI / MSFI)
+def diffusion_alpha_bar(kind, start, stop, T):
+    """default.py:75-189 restricted to the schedules the shipped configs use; returns Alpha_bar fp32 (T,)."""
+    if kind == "linear":
+        scale = 1000 / T
+        beta = torch.linspace(scale * start, scale * stop, T, dtype=torch.float64)
+    elif kind == "cosine":
+        s = 0.008
+        t = torch.linspace(start, stop, T + 1, dtype=torch.float64) / T
+        ac = torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** 2
+        ac = ac / ac[0]
+        beta = torch.clip(1 - ac[1:] / ac[:-1], 0, 0.999)
+    else:
+        raise NotImplementedError(kind)
+    alpha = 1 - beta
+    ab = alpha + 0
+    for t in range(1, T):
+        ab[t] *= ab[t - 1]
+    return ab.float()
+
+
+def ddim_sample(alpha_bar, x_t, t, eps, dm_target="noise"):
+    """default.py:192-214 (t uniform over points)."""
+    ab = alpha_bar[t]
+    if dm_target == "noise":
+        x0 = (x_t - torch.sqrt(1 - ab) * eps) / torch.sqrt(ab)
+    else:
+        x0 = eps
+        eps = (x_t - torch.sqrt(ab) * x0) / torch.sqrt(1 - ab)
+    if t == 0:
+        return x0
+    ab1 = alpha_bar[t - 1]
+    return torch.sqrt(ab1) * x0 + torch.sqrt(1 - ab1) * eps
+
+
+def inference_ddim(cfg, model_cfg, sd, input_dict, draws, step=1, mode="avg", noise_level=None, flash_semantics=True):
+    """DefaultSegmentorV2.inference_ddim (default.py:278-369), condition=True.  draws: noise (N,c_in) and
+    8*(step+1) perms in consumption order.  model_cfg: the DefaultSegmentorV2 kwargs (T, schedule, ...)."""
+    global FLASH_SEMANTICS
+    FLASH_SEMANTICS = flash_semantics
+    T = model_cfg["T"]
+    feat = torch.as_tensor(input_dict["feat"], dtype=torch.float32)
+    coord = torch.as_tensor(input_dict["coord"], dtype=torch.float32)
+    grid = np.asarray(input_dict["grid_coord"], dtype=np.int64)
+    offset = np.asarray(input_dict["offset"], dtype=np.int64)
+    if noise_level is not None:
+        feat = feat + noise_level * draws["feat_noise"]
+    N = len(feat)
+    ab = diffusion_alpha_bar(model_cfg["noise_schedule"], model_cfg["beta_start"], model_cfg["beta_end"], T)
+    c_xt = draws["noise"]
+    n_pred = torch.zeros(N, cfg["num_classes"])
+    schedule = np.linspace(-1, T - 1, num=step + 1, dtype=int)[::-1]  # default.py:224-226
+    perms = list(draws["perms"])
+    T_dim = cfg.get("T_dim", 128)
+    with torch.no_grad():
+        for k, t in enumerate(schedule):
+            t = int(t)
+            ts = t * torch.ones((N, 1), dtype=torch.int64)
+            c_in = dict(coord=coord, grid=grid, offset=offset, feat=c_xt)
+            if T_dim != -1:
+                c_in["t_emb"] = calc_t_emb(ts, T_dim)
+            n_in = dict(coord=coord, grid=grid, offset=offset, feat=feat)
+            c_out, n_out = backbone_forward(cfg, sd, c_in, n_in, perms[8 * k:8 * k + 8], run_dead=True)
+            c_xt = ddim_sample(ab, c_xt, t, c_out, model_cfg.get("dm_target", "noise")).float()
+            if mode == "avg":
+                n_pred = n_pred + n_out
+            else:
+                n_pred = n_out
+            if t <= 0:
+                break
+    return n_pred / len(schedule) if mode == "avg" else n_pred
+
+
+def inference_ptv3(cfg, sd, input_dict, perms, flash_semantics=True):
+    """condition=False: plain PTv3 through DefaultSegmentorV2.inference (default.py:409-412,
+    ptv3.py:1818-1845).  perms: 5 randperm draws (serialization + 4 poolings)."""
+    global FLASH_SEMANTICS
+    FLASH_SEMANTICS = flash_semantics
+    B = "backbone"
+    orders = cfg.get("order", DEFAULT_ORDERS)
+    no = len(orders)
+    pi = iter(list(perms) if cfg.get("shuffle_orders", True) else [None] * 5)
+    feat = torch.as_tensor(input_dict["feat"], dtype=torch.float32)
+    coord = torch.as_tensor(input_dict["coord"], dtype=torch.float32)
+    n = make_point(coord, np.asarray(input_dict["grid_coord"], dtype=np.int64),
+                   np.asarray(input_dict["offset"], dtype=np.int64), feat)
+    with torch.no_grad():
+        serialize_point(n, orders, next(pi))
+        n = embedding(n, sd, B + "._n_embedding")
+        nd, nh, nK, ns = cfg["n_enc_depths"], cfg["n_enc_num_head"], cfg["n_enc_patch_size"], cfg["n_stride"]
+        for s in range(len(nd)):
+            n = _stage(n, sd, B + "._n_enc", s, nd[s], nh[s], nK[s], ns[s - 1] if s else None,
+                       next(pi) if s else None, False, no)
+        ndd, ndh, ndK = cfg["n_dec_depths"], cfg["n_dec_num_head"], cfg["n_dec_patch_size"]
+        n_mode = "cat" if cfg.get("skip_connection_mode", "add") == "cat_all" else "add"
+        for s in reversed(range(len(nd) - 1)):
+            n = unpooling(n, sd, f"{B}._n_dec.dec{s}.up", n_mode, False,
+                          (s + 1) if cfg.get("skip_connection_scale_i", False) else None)
+            for i in range(ndd[s]):
+                n = block(n, sd, f"{B}._n_dec.dec{s}.block{i}", ndh[s], i % no, ndK[s], False)
+        return linear(n.feat, sd, B + "._n_head")

@@ -232,5 +232,10 @@ def gather_pad_cast(src, idx, cpad, dtype):
     return out.to(dtype)
 
 
+def ddim_update(xt, eps, sqrt_ab_prev, sqrt_1m_ab, sqrt_ab, sqrt_1m_ab_prev, final=False):
+    x0 = (xt - sqrt_1m_ab * eps) / sqrt_ab
+    return x0 if final else sqrt_ab_prev * x0 + sqrt_1m_ab_prev * eps
+
+
 def axpy(a, b, alpha):
     return a + alpha * b

@@ -68,3 +68,38 @@ def test_seed_replay_without_injected_draws(emulated):
     inp = {k: torch.as_tensor(v) for k, v in fixture_input(fx).items()}
     out = model.inference(inp, eval=False)["seg_logits"].numpy()
     assert np.abs(out - fx["logits"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("name", ["mini_ddim_avg2", "mini_ddim_final1"])
+def test_engine_inference_ddim(emulated, name):
+    """multi-step inference with the plan built once (c-decoder + c-head live here)."""
+    fx = load_fixture(name + ".npz")
+    cfg = copy.deepcopy(fixture_cfg(fx))
+    cfg["backbone"]["enable_flash"] = False
+    model = build_model(cfg)
+    model.load_state_dict(fixture_state_dict(fx), strict=True)
+    model.eval()
+    model.precision = "fp32"
+    inp = {k: torch.as_tensor(v) for k, v in fixture_input(fx).items()}
+    draws = dict(noise=torch.from_numpy(fx["noise"]), perms=[p for p in fx["perms"]])
+    out = model.inference_ddim(inp, T=cfg["T"], step=int(fx["step"]), eval=False, mode=str(fx["mode"]),
+                               draws=draws)["seg_logits"].numpy()
+    assert np.abs(out - fx["logits"]).max() < 5e-4
+    # seeded default draws replay the reference's (normal, then 8 randperm per backbone call)
+    torch.manual_seed(int(fx["seed"]))
+    out2 = model.inference_ddim(inp, T=cfg["T"], step=int(fx["step"]), eval=False, mode=str(fx["mode"]))["seg_logits"]
+    assert np.abs(out2.numpy() - fx["logits"]).max() < 5e-4
+
+
+def test_engine_ptv3_without_condition(emulated):
+    """condition=False (plain PTv3 configs) through the same registry names."""
+    fx = load_fixture("mini_ptv3_room.npz")
+    cfg = copy.deepcopy(fixture_cfg(fx))
+    cfg["backbone"]["enable_flash"] = False
+    model = build_model(cfg)
+    model.load_state_dict(fixture_state_dict(fx), strict=True)
+    model.eval()
+    model.precision = "fp32"
+    inp = {k: torch.as_tensor(v) for k, v in fixture_input(fx).items()}
+    out = model.inference(inp, eval=False, draws=dict(perms=[p for p in fx["perms"]]))["seg_logits"].numpy()
+    assert np.abs(out - fx["logits"]).max() < 2e-4

@@ -118,6 +118,31 @@ def test_native_block_executor_equals_binding_sequence(precision):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["mini_ddim_avg2", "mini_ddim_final1"])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.12)])
+def test_inference_ddim_matches_reference_golden(name, precision, tol):
+    """SURVEY.md 8f row 2 (MSAI / MSFI, default.py:278-369): c-decoder + c-head + DDIM update on device,
+    step-invariant plan built once."""
+    fx = load_fixture(name + ".npz")
+    cfg = fixture_cfg(fx)
+    model = build(cfg, fixture_state_dict(fx), precision, enable_flash=False)
+    draws = dict(noise=torch.from_numpy(fx["noise"]), perms=[p for p in fx["perms"]])
+    out = model.inference_ddim(to_dev(fixture_input(fx)), T=cfg["T"], step=int(fx["step"]), eval=False,
+                               mode=str(fx["mode"]), draws=draws)["seg_logits"].cpu().numpy()
+    err, agree = report(f"{name} {precision} vs reference", out, fx["logits"])
+    assert err < tol
+
+
+def test_ptv3_without_condition_matches_reference_golden():
+    """condition=False (plain PTv3) behind the same registry names."""
+    fx = load_fixture("mini_ptv3_room.npz")
+    model = build(fixture_cfg(fx), fixture_state_dict(fx), "fp32", enable_flash=False)
+    out = model.inference(to_dev(fixture_input(fx)), eval=False,
+                          draws=dict(perms=[p for p in fx["perms"]]))["seg_logits"].cpu().numpy()
+    err, agree = report("ptv3 (condition=False) fp32 vs reference", out, fx["logits"])
+    assert err < 1e-3 and agree > 0.999
+
+
 def test_full_width_fp32_matches_reference_golden():
     fx = load_fixture("full_e2e_8k.npz")
     model = build(fixture_cfg(fx), fixture_state_dict(fx), "fp32")

@@ -400,13 +400,13 @@ def test_timestep_embedding_chain(ops):
     from cdsegnet_amd.models import calc_t_emb_table
     ka = load_fixture("known_answers.npz")
     table = calc_t_emb_table(1000, 128)
-    assert np.array_equal(table[999].numpy(), ka["t_emb_999_128"][0])
-    assert np.array_equal(table[[0, 1, 500, 999]].numpy(), ka["t_emb_multi_128"])
+    assert np.array_equal(table[999 + 1].numpy(), ka["t_emb_999_128"][0])  # row index = t + 1 (row 0 is t = -1)
+    assert np.array_equal(table[[1, 2, 501, 1000]].numpy(), ka["t_emb_multi_128"])
     g = torch.Generator().manual_seed(0)
     w1, b1 = torch.randn(512, 128, generator=g) / 11, torch.randn(512, generator=g)
     w2, b2 = torch.randn(128, 512, generator=g) / 22, torch.randn(128, generator=g)
-    ref = OM.swish(F.linear(OM.swish(F.linear(table[999], w1, b1)), w2, b2))
-    v = ops.gemv(dev(w1), dev(b1), dev(table[999]), ops.ACT_SWISH)
+    ref = OM.swish(F.linear(OM.swish(F.linear(table[1000], w1, b1)), w2, b2))
+    v = ops.gemv(dev(w1), dev(b1), dev(table[1000]), ops.ACT_SWISH)
     v = ops.gemv(dev(w2), dev(b2), v, ops.ACT_SWISH)
     assert (v.cpu() - ref).abs().max().item() < 1e-5
 

@@ -154,3 +154,25 @@ def test_e2e_full_width_matches_reference():
     err = np.abs(logits - fx["logits"]).max()
     assert err < 5e-4, err
     assert (logits.argmax(1) == fx["logits"].argmax(1)).mean() > 0.999
+
+
+@pytest.mark.parametrize("name", ["mini_ddim_avg2", "mini_ddim_final1"])
+def test_inference_ddim_matches_reference(name):
+    """Multi-step inference (MSAI / MSFI, default.py:278-369): SURVEY.md 8f row 2."""
+    fx = load_fixture(name + ".npz")
+    cfg = fixture_cfg(fx)
+    sd = fixture_state_dict(fx)
+    draws = dict(noise=torch.from_numpy(fx["noise"]), perms=[p for p in fx["perms"]])
+    out = OM.inference_ddim(cfg["backbone"], cfg, sd, fixture_input(fx), draws, step=int(fx["step"]),
+                            mode=str(fx["mode"]), flash_semantics=False).numpy()
+    err = np.abs(out - fx["logits"]).max()
+    assert err < 5e-4, err
+
+
+def test_ptv3_without_condition_matches_reference():
+    """condition=False (plain PTv3 configs): SURVEY.md 8f row 4."""
+    fx = load_fixture("mini_ptv3_room.npz")
+    cfg = fixture_cfg(fx)
+    sd = fixture_state_dict(fx)
+    out = OM.inference_ptv3(cfg["backbone"], sd, fixture_input(fx), [p for p in fx["perms"]]).numpy()
+    assert np.abs(out - fx["logits"]).max() < 2e-4
