@@ -42,8 +42,32 @@ struct AttnP {
   void* out;
   int ldq, ldk, ldv, ldo;
   int num_heads;
+  int num_patches;
+  int qsplit;
+  int hgroups;  // head groups per patch: the unit pinned to one XCD is (patch, head group)
   float scale_log2e;
 };
+
+// XCD-aware block -> (patch, head, query-slice) map.  Workgroups are dispatched round-robin over the 8 XCDs
+// (block b -> XCD b % 8, a performance-only assumption); all blocks of one patch (its heads and query slices
+// read the same gathered rows) get ids that are equal mod 8 and adjacent in time, so the rows are fetched into
+// ONE L2 once instead of up to 8 times.  With fewer than 8 patches (deep stages) the heads of a patch are
+// split into `hgroups` groups so that all XCDs still get work.  Grid = ceil(G / 8) * 8 * (H / hgroups) * Q
+// blocks with G = P * hgroups; surplus ids exit.
+__device__ __forceinline__ bool decode_block(const AttnP& p, int& patch, int& head, int& qslice) {
+  const int hpg = p.num_heads / p.hgroups;  // heads per group
+  const int per_group = hpg * p.qsplit;
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int t = L >> 3;
+  const int r = t % per_group;
+  const int g = (t / per_group) * 8 + xcd;
+  patch = g / p.hgroups;
+  const int hg = g - patch * p.hgroups;
+  head = hg * hpg + r / p.qsplit;
+  qslice = r % p.qsplit;
+  return patch < p.num_patches;
+}
 
 constexpr int VT_STRIDE_BF16 = 2056;  // bytes per V^T row (1024 bf16 + 8 B pad -> conflict-free b64 reads)
 constexpr int VT_ROWS_BF16 = 18;      // 16 head dims + ones row + zero row
@@ -58,12 +82,11 @@ constexpr int SMEM_F32 = KS_BYTES_F32 + 16 * VT_STRIDE_F32;
 constexpr int ATTN_THREADS = 512;  // 8 waves: 2 per SIMD per block, 2 blocks per CU (LDS 69 KB each)
 constexpr int ATTN_WAVES = ATTN_THREADS / 64;
 
-// one 32-key x 32-query tile of S^T = K Q^T
-__device__ __forceinline__ f32x16_t qk_tile(const char* Ks, int kt, int ql, int h, bf16x8_t qf) {
+// one 32-key x 32-query tile of S^T = K Q'^T + C  (Q' = Q * scale * log2 e, C = 0 or -max: see below)
+__device__ __forceinline__ f32x16_t qk_tile(const char* Ks, int kt, int ql, int h, bf16x8_t qf, const f32x16_t& c0) {
   const int key = kt * 32 + ql;
   const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + key * 32 + ((h ^ ((key >> 3) & 1)) << 4));
-  const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, z, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, c0, 0, 0, 0);
 }
 
 __device__ __forceinline__ float tile_max(const f32x16_t& s, float m) {
@@ -75,13 +98,21 @@ __device__ __forceinline__ float tile_max(const f32x16_t& s, float m) {
   return fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), fmaxf(fmaxf(e, s[15]), m));
 }
 
-// P = exp2(S*c - m*c) for one tile, then O^T += [V^T; 1; 0] P^T (two K=16 MFMAs)
+// two fp32 -> packed bf16 by truncation: ONE v_perm_b32 (measured 2.8x cheaper than v_cvt_pk_bf16_f32 on
+// gfx950, tools/ubench/valu_rates.hip).  The softmax denominator is accumulated from the SAME truncated
+// values (row of ones in V^T), so the truncation bias cancels in the normalisation.
+__device__ __forceinline__ uint32_t pack_bf16x2_trunc(float lo, float hi) {
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+
+// P = exp2(S') for one tile (S' already holds s*c - m*c: scale folded into Q', -max into the MFMA's C
+// operand, so the softmax costs one v_exp_f32 per score and nothing else), then
+// O^T += [V^T; 1; 0] P^T (two K=16 MFMAs)
 template <bool TAIL>
-__device__ __forceinline__ void pv_tile(const f32x16_t& s, float c, float mc, int kt, int h, int L,
-                                        const char* vt_lane, f32x16_t& o) {
+__device__ __forceinline__ void pv_tile(const f32x16_t& s, int kt, int h, int L, const char* vt_lane, f32x16_t& o) {
   float pr[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r] * c - mc);
+  for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r]);
   if (TAIL) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -91,7 +122,7 @@ __device__ __forceinline__ void pv_tile(const f32x16_t& s, float c, float mc, in
   for (int mf = 0; mf < 2; ++mf) {
     union { bf16x8_t v; uint32_t u[4]; } pf, vf;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
+    for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2_trunc(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
     // k-slots 8h+j (j<4) <-> keys kbase + 4h + j ; (j>=4) <-> keys kbase + 8 + 4h + (j-4)
     const char* vp = vt_lane + (kt * 32 + 16 * mf) * 2;
     const uint2 lo = *reinterpret_cast<const uint2*>(vp);
@@ -109,8 +140,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int patch = blockIdx.x / p.num_heads;
-  const int head = blockIdx.x - patch * p.num_heads;
+  int patch, head, qslice;
+  if (!decode_block(p, patch, head, qslice)) return;
   const int ps = p.patch_start[patch];
   const int L = p.patch_start[patch + 1] - ps;
   const int nkt = (L + 31) >> 5;  // 32-key tiles
@@ -163,25 +194,32 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
   const bool tail = (nkt << 5) != L;
   const int nfull = tail ? nkt - 1 : nkt;  // key tiles that need no masking
 
-  for (int qt = blockIdx.y * ATTN_WAVES + wave; qt < nqt; qt += gridDim.y * ATTN_WAVES) {
+  for (int qt = qslice * ATTN_WAVES + wave; qt < nqt; qt += p.qsplit * ATTN_WAVES) {
     const int qslot = qt * 32 + ql;
     const bool qvalid = qslot < L;
     bf16x8_t qf = {0, 0, 0, 0, 0, 0, 0, 0};
     if (qvalid) {
+      // Q' = Q * (softmax scale * log2 e), rounded to bf16 once: scores come out of the MFMA in exp2 units
       const long g = p.q_gidx[ps + qslot];
-      qf = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)p.q + g * p.ldq + head * 16 + h * 8);
+      union { bf16x8_t v; uint32_t u[4]; } qr, qs;
+      qr.v = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)p.q + g * p.ldq + head * 16 + h * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        qs.u[j] = pack_bf16x2(__uint_as_float(qr.u[j] << 16) * c, __uint_as_float(qr.u[j] & 0xffff0000u) * c);
+      qf = qs.v;
     }
-    // ---- pass 1: row max of S^T = K Q^T (lane (q,h) sees keys (r&3) + 8*(r>>2) + 4h of each tile)
+    const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- pass 1: row max of S'^T = K Q'^T (lane (q,h) sees keys (r&3) + 8*(r>>2) + 4h of each tile)
     float m0 = -INFINITY, m1 = -INFINITY;
     int kt = 0;
     for (; kt + 1 < nfull; kt += 2) {  // two independent tiles in flight
-      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf);
-      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf);
+      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf, zero16);
+      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf, zero16);
       m0 = tile_max(sa, m0);
       m1 = tile_max(sb, m1);
     }
     for (; kt < nkt; ++kt) {
-      f32x16_t s = qk_tile(Ks, kt, ql, h, qf);
+      f32x16_t s = qk_tile(Ks, kt, ql, h, qf, zero16);
       if (kt >= nfull) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -191,20 +229,22 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
     }
     float m = fmaxf(m0, m1);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float mc = m * c;
-    // ---- pass 2: P = exp2(S*c - m*c), O^T (+ row sums in row 16) += [V^T; 1; 0] P^T
+    // ---- pass 2: S' - m comes straight out of the MFMA (C operand = -m, loop invariant), P = exp2(.),
+    //      O^T (+ row sums in row 16) += [V^T; 1; 0] P^T
+    const float nm = -m;
+    const f32x16_t negm = {nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm};
     f32x16_t o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     kt = 0;
     for (; kt + 1 < nfull; kt += 2) {
-      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf);
-      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf);
-      pv_tile<false>(sa, c, mc, kt, h, L, vt_lane, o);
-      pv_tile<false>(sb, c, mc, kt + 1, h, L, vt_lane, o);
+      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf, negm);
+      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf, negm);
+      pv_tile<false>(sa, kt, h, L, vt_lane, o);
+      pv_tile<false>(sb, kt + 1, h, L, vt_lane, o);
     }
     for (; kt < nkt; ++kt) {
-      const f32x16_t s = qk_tile(Ks, kt, ql, h, qf);
-      if (kt >= nfull) pv_tile<true>(s, c, mc, kt, h, L, vt_lane, o);
-      else pv_tile<false>(s, c, mc, kt, h, L, vt_lane, o);
+      const f32x16_t s = qk_tile(Ks, kt, ql, h, qf, negm);
+      if (kt >= nfull) pv_tile<true>(s, kt, h, L, vt_lane, o);
+      else pv_tile<false>(s, kt, h, L, vt_lane, o);
     }
     // ---- epilogue: O^T rows (r&3) + 8*(r>>2) + 4h; row 16 (lane h=0, r=8) is the denominator
     const float lsum = __shfl(o[8], ql, 64);
@@ -234,8 +274,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_f32_kernel(AttnP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int patch = blockIdx.x / p.num_heads;
-  const int head = blockIdx.x - patch * p.num_heads;
+  int patch, head, qslice;
+  if (!decode_block(p, patch, head, qslice)) return;
   const int ps = p.patch_start[patch];
   const int L = p.patch_start[patch + 1] - ps;
   const int nkt = (L + 15) >> 4;  // 16-key tiles
@@ -272,7 +312,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_f32_kernel(AttnP p) {
   const float c = p.scale_log2e;
   const int nqt = (L + 15) >> 4;
 
-  for (int qt = blockIdx.y * ATTN_WAVES + wave; qt < nqt; qt += gridDim.y * ATTN_WAVES) {
+  for (int qt = qslice * ATTN_WAVES + wave; qt < nqt; qt += p.qsplit * ATTN_WAVES) {
     const int qslot = qt * 16 + ql;
     const bool qvalid = qslot < L;
     f32x4_t qf = {0.f, 0.f, 0.f, 0.f};
@@ -357,7 +397,13 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
   int qsplit = ph >= 384 ? 1 : (ph >= 160 ? 2 : 4);
   const int max_split = (nqt + ATTN_WAVES - 1) / ATTN_WAVES;
   while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
-  dim3 grid((unsigned)(num_patches * num_heads), (unsigned)qsplit), block(ATTN_THREADS);
+  p.num_patches = num_patches;
+  p.qsplit = qsplit;
+  int hgroups = 1;  // smallest divisor of H giving every XCD a group (or H itself)
+  while (hgroups < num_heads && (num_patches * hgroups < 8 || num_heads % hgroups)) ++hgroups;
+  p.hgroups = hgroups;
+  const int groups = num_patches * hgroups;
+  dim3 grid((unsigned)(((groups + 7) / 8) * 8 * (num_heads / hgroups) * qsplit)), block(ATTN_THREADS);
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BF16) !=
