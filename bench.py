@@ -165,6 +165,12 @@ def main():
                                "algorithmic_gflop_per_step": attn_work / args.steps / 1e9,
                                "note": "VALU/transcendental-issue bound at head dim 16 (DESIGN.md 5)"}
             res["kernel_ms_per_step"] = {"attention": attn_ms / args.steps}
+            tpath = os.path.join(ROOT, "profiles", "r01_attention_traffic.json")
+            if args.precision == "bf16" and os.path.exists(tpath):
+                # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+                # WRITE_SIZE) on the stage-0-shaped launch; the live run cannot collect PMCs itself
+                with open(tpath) as f:
+                    res["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
         if args.cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_points, args.dataset)
         print(json.dumps(res))

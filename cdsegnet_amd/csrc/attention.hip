@@ -21,6 +21,7 @@
 //    makes the softmax denominator fall out of the same MFMA (row 16 of the result);
 //  * f32 (the 1e-3 parity mode): v_mfma_f32_16x16x4_f32 for both products, exact fp32.
 // LDS layouts are bank-conflict free for every fragment read (tools/lds_conflicts.py).
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -395,6 +396,7 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
   // Powers of two so that every wave of every block gets the same number of query tiles.
   const int ph = num_patches * num_heads;
   int qsplit = ph >= 384 ? 1 : (ph >= 160 ? 2 : 4);
+  if (const char* e = getenv("CDSEG_ATTN_QSPLIT")) qsplit = atoi(e);  // tuning knob (power of two)
   const int max_split = (nqt + ATTN_WAVES - 1) / ATTN_WAVES;
   while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
   p.num_patches = num_patches;
