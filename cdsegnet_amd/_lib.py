@@ -77,6 +77,11 @@ SIGNATURES = {
                                   c_void_p, c_void_p]),
     "cdseg_nbr_table": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "cdseg_voxelize": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cdseg_max_run": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "cdseg_fragment_select": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "cdseg_softmax_vote": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
+    "cdseg_argmax_rows": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
     "cdseg_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),

@@ -66,13 +66,13 @@ TIMER = None
 
 def attention_prof_enable(on=True):
     """Event-time every attention launch inside the library (works for the native Block executor too)."""
-    check(_LIB.cdseg_prof_enable(1 if on else 0), "prof_enable")
+    check(_lib.load().cdseg_prof_enable(1 if on else 0), "prof_enable")
 
 
 def attention_prof_summary():
     """(total_ms, launches) since attention_prof_enable(True); call after torch.cuda.synchronize()."""
     ms, cnt = ctypes.c_double(0.0), ctypes.c_long(0)
-    check(_LIB.cdseg_prof_summary(ctypes.byref(ms), ctypes.byref(cnt)), "prof_summary")
+    check(_lib.load().cdseg_prof_summary(ctypes.byref(ms), ctypes.byref(cnt)), "prof_summary")
     return ms.value, cnt.value
 
 
@@ -334,7 +334,7 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     else:
         a.ws, a.ws_bytes = None, 0
     tok = TIMER.begin("conv" if nbr is not None else "gemm") if TIMER is not None else None
-    check(_LIB.cdseg_gemm(ent[1], _stream()), "gemm")
+    check(_lib.load().cdseg_gemm(ent[1], _stream()), "gemm")
     if tok is not None:
         TIMER.end(tok, 2.0 * a.M * a.N * a.K * a.kvol)
     return out
@@ -356,7 +356,7 @@ def make_block_desc(dtype, channels, heads, hidden, attn_scale, ln_eps, tensors)
 
 
 def block_scratch_bytes(desc, n):
-    return _LIB.cdseg_block_scratch_bytes(desc[1], int(n))
+    return _lib.load().cdseg_block_scratch_bytes(desc[1], int(n))
 
 
 _BLOCK_IO = None
@@ -374,7 +374,7 @@ def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start
     io.nbr, io.gidx, io.widx, io.patch_start = nbr.data_ptr(), gidx.data_ptr(), widx.data_ptr(), patch_start.data_ptr()
     io.num_patches, io.max_len = int(num_patches), int(max_len)
     io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
-    check(_LIB.cdseg_block_forward(desc[1], ref, _stream()), "block_forward")
+    check(_lib.load().cdseg_block_forward(desc[1], ref, _stream()), "block_forward")
 
 
 def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):
@@ -461,7 +461,7 @@ def gather_pad_cast(src, idx, cpad, dtype):
 
 def ddim_update(xt, eps, sqrt_ab_prev, sqrt_1m_ab, sqrt_ab, sqrt_1m_ab_prev, final=False):
     out = torch.empty_like(xt)
-    check(_LIB.cdseg_ddim_update(_ptr(xt), _ptr(eps), float(sqrt_ab_prev), float(sqrt_1m_ab), float(sqrt_ab),
+    check(_lib.load().cdseg_ddim_update(_ptr(xt), _ptr(eps), float(sqrt_ab_prev), float(sqrt_1m_ab), float(sqrt_ab),
                                  float(sqrt_1m_ab_prev), 1 if final else 0, _ptr(out), xt.numel(), _stream()),
           "ddim_update")
     return out
@@ -470,6 +470,44 @@ def ddim_update(xt, eps, sqrt_ab_prev, sqrt_1m_ab, sqrt_ab, sqrt_1m_ab_prev, fin
 def axpy(a, b, alpha):
     out = torch.empty_like(a)
     check(_lib.load().cdseg_axpy(_ptr(a), _ptr(b), float(alpha), _ptr(out), a.numel(), _stream()), "axpy")
+    return out
+
+
+# ------------------------------------------------------------------ test-time pipeline ops
+def voxelize(coord, grid_size):
+    """GridSample's voxel coordinates: (grid int32 (n,3) shifted to start at 0, key int64 (n), min int32 (3))."""
+    _need_gpu(coord)
+    coord = coord.float().contiguous()
+    n = coord.shape[0]
+    grid = torch.empty((n, 3), dtype=torch.int32, device=coord.device)
+    key = torch.empty(n, dtype=torch.int64, device=coord.device)
+    mn = torch.empty(3, dtype=torch.int32, device=coord.device)
+    check(_lib.load().cdseg_voxelize(_ptr(coord), float(grid_size), n, _ptr(grid), _ptr(key), _ptr(mn), _stream()), "voxelize")
+    return grid, key, mn
+
+
+def max_run(seg_start, m):
+    out = torch.empty(1, dtype=torch.int32, device=seg_start.device)
+    check(_lib.load().cdseg_max_run(_ptr(seg_start), int(m), _ptr(out), _stream()), "max_run")
+    return out
+
+
+def fragment_select(idx_sort, seg_start, m, frag):
+    out = torch.empty(int(m), dtype=torch.int32, device=idx_sort.device)
+    check(_lib.load().cdseg_fragment_select(_ptr(idx_sort), _ptr(seg_start), int(m), int(frag), _ptr(out), _stream()),
+          "fragment_select")
+    return out
+
+
+def softmax_vote(logits, idx, pred):
+    check(_lib.load().cdseg_softmax_vote(_ptr(logits), logits.stride(0), _ptr(idx), logits.shape[0], logits.shape[1], _ptr(pred),
+                                  pred.stride(0), _stream()), "softmax_vote")
+    return pred
+
+
+def argmax_rows(x):
+    out = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+    check(_lib.load().cdseg_argmax_rows(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), _stream()), "argmax_rows")
     return out
 
 

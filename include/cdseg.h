@@ -210,6 +210,22 @@ int cdseg_ddim_update(const float* xt, const float* eps, float sqrt_ab_prev, flo
 /* out = a + alpha * b (fp32).  ref: default.py:228-236 (add_gaussian_noise) */
 int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, void* stream);
 
+/* ------------------------------------------------------------------ test-time pipeline
+ * ref: datasets/transform.py:821-897 (GridSample mode="test"), engines/test.py:261-278 (softmax vote, arg-max) */
+/* grid = floor(coord / grid_size) - min (int32), key = one int64 per voxel; min3_dev (3 x int32) receives the min */
+int cdseg_voxelize(const float* coord, double grid_size, long n, int32_t* grid, int64_t* key, int32_t* min3_dev,
+                   void* stream);
+/* largest run length of a seg_start array (m runs) = number of test fragments (count.max()) */
+int cdseg_max_run(const int32_t* seg_start, long m, int32_t* out_dev, void* stream);
+/* fragment `frag`: idx_part[v] = idx_sort[seg_start[v] + frag % count_v].  ref: transform.py:862-864 */
+int cdseg_fragment_select(const int32_t* idx_sort, const int32_t* seg_start, long m, int frag, int32_t* idx_part,
+                          void* stream);
+/* pred[idx[i], :] += softmax(logits[i, :]).  ref: engines/test.py:261-267 */
+int cdseg_softmax_vote(const float* logits, int ldl, const int32_t* idx, long m, int c, float* pred, int ldp,
+                       void* stream);
+/* out[i] = first arg-max of row i.  ref: engines/test.py:278 */
+int cdseg_argmax_rows(const float* x, int ldx, long n, int c, int32_t* out, void* stream);
+
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
  * block itself (sparse-conv CPE, Linear+LayerNorms, QKV, window attention, proj, MLP), carving its

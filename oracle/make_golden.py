@@ -304,6 +304,31 @@ def run_e2e_nocond(ref, cfg, scene, seed, sd_seed, tag):
     print(tag, out["seg_logits"].shape, float(out["seg_logits"].abs().mean()), "params", len(sd))
 
 
+def gen_gridsample(ref):
+    """GridSample(mode="test") of the reference on raw (un-voxelised) clouds: datasets/transform.py:796-897."""
+    import importlib.util
+    # the file alone: pointcept/datasets/__init__.py pulls in loggers / dataset classes this image lacks
+    spec = importlib.util.spec_from_file_location("_ref_transform", os.path.join(REF, "pointcept/datasets/transform.py"))
+    T = importlib.util.module_from_spec(spec)
+    sys.modules["_ref_transform"] = T  # the reference's Registry infers its scope from the defining module
+    spec.loader.exec_module(T)
+    for tag, seed, n, gsize in (("room", 5, 6000, 0.05), ("dense", 6, 3000, 0.2), ("neg", 7, 2000, 0.1)):
+        rng = np.random.default_rng(seed)
+        coord = (rng.random((n, 3)) * np.array([4.0, 3.0, 2.5])).astype(np.float32)
+        if tag == "neg":
+            coord -= np.array([2.0, 1.5, 0.3], dtype=np.float32)  # negative coordinates: floor, not truncation
+        color = rng.random((n, 3)).astype(np.float32)
+        gs = T.GridSample(grid_size=gsize, hash_type="fnv", mode="test", keys=("coord", "color"), return_grid_coord=True)
+        parts = gs(dict(coord=coord.copy(), color=color.copy()))
+        for p in parts:  # the transform slices every keyed array by idx_part
+            assert np.array_equal(p["coord"], coord[p["index"]]) and np.array_equal(p["color"], color[p["index"]])
+        idx = np.stack([p["index"] for p in parts]).astype(np.int64)
+        gc = np.stack([p["grid_coord"] for p in parts]).astype(np.int64)
+        np.savez_compressed(os.path.join(OUT, f"gridsample_test_{tag}.npz"), coord=coord, grid_size=np.float64(gsize),
+                            index=idx, grid_coord=gc)
+        print("gridsample", tag, idx.shape)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -317,3 +342,5 @@ if __name__ == "__main__":
         gen_ddim(ref)
     if "ptv3" in which:
         gen_ptv3(ref)
+    if "gs" in which:
+        gen_gridsample(ref)

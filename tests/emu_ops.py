@@ -239,3 +239,40 @@ def ddim_update(xt, eps, sqrt_ab_prev, sqrt_1m_ab, sqrt_ab, sqrt_1m_ab_prev, fin
 
 def axpy(a, b, alpha):
     return a + alpha * b
+
+
+# ---- test-time pipeline ops (cdsegnet_amd/csrc/testtime.hip)
+def bind_stream(stream=None):
+    pass
+
+
+def unbind_stream():
+    pass
+
+
+def voxelize(coord, grid_size):
+    g = torch.floor(coord.double() / float(grid_size)).long()
+    mn = g.min(0).values
+    g = g - mn
+    key = (g[:, 0] << 42) | (g[:, 1] << 21) | g[:, 2]
+    return g.int(), key, mn.int()
+
+
+def max_run(seg_start, m):
+    s = seg_start[: m + 1].long()
+    return (s[1:] - s[:-1]).max().int().reshape(1)
+
+
+def fragment_select(idx_sort, seg_start, m, frag):
+    s = seg_start[: m + 1].long()
+    c = s[1:] - s[:-1]
+    return idx_sort[s[:-1] + frag % c].int()
+
+
+def softmax_vote(logits, idx, pred):
+    pred[idx.long()] += torch.softmax(logits.float(), -1)
+    return pred
+
+
+def argmax_rows(x):
+    return x.argmax(1).int()

@@ -103,3 +103,34 @@ def test_engine_ptv3_without_condition(emulated):
     inp = {k: torch.as_tensor(v) for k, v in fixture_input(fx).items()}
     out = model.inference(inp, eval=False, draws=dict(perms=[p for p in fx["perms"]]))["seg_logits"].numpy()
     assert np.abs(out - fx["logits"]).max() < 2e-4
+
+
+def test_testtime_pipeline_host_logic(emulated, monkeypatch):
+    """cdsegnet_amd.testtime (GridSample test fragments -> per-fragment inference -> softmax vote -> arg-max)
+    on the emulated ops against the oracle pipeline with the same per-fragment logits."""
+    import cdsegnet_amd.testtime as tt
+    from oracle import testtime as OT
+    monkeypatch.setattr(tt, "ops", emu_ops)
+    fx = load_fixture("gridsample_test_dense.npz")
+    coord, gsize = torch.as_tensor(fx["coord"]), float(fx["grid_size"])
+    gs = tt.grid_sample_test(coord, gsize)
+    grid, parts = OT.grid_sample_test(fx["coord"], gsize)
+    assert gs["num_fragments"] == len(parts) and gs["num_voxels"] == len(parts[0])
+    assert np.array_equal(gs["grid_coord"].numpy(), grid)
+    for i, p in enumerate(parts):  # same fragments (as sets: the voxel ORDER differs, packed key vs FNV hash)
+        assert np.array_equal(np.sort(tt.fragment(gs, i).numpy()), np.sort(p))
+
+    class FakeModel:  # logits = a fixed function of the fragment's inputs, so both pipelines see the same numbers
+        def inference(self, inp, eval=False, noise_level=None):
+            assert inp["offset_host"] == [inp["coord"].shape[0]]
+            g = inp["grid_coord"].float()
+            return dict(seg_logits=torch.stack([g[:, 0] * 0.3 + inp["feat"][:, 0], g[:, 1] * 0.2, g[:, 2] * 0.25,
+                                                inp["coord"][:, 0]], 1))
+
+    feat = torch.as_tensor(np.random.default_rng(1).random((len(coord), 3)).astype(np.float32))
+    labels, pred = tt.segment_scene(FakeModel(), coord, feat, gsize, 4)
+    lg = [FakeModel().inference(dict(coord=coord[p], grid_coord=torch.as_tensor(grid[p]), feat=feat[p],
+                                     offset_host=[len(p)]))["seg_logits"].numpy() for p in parts]
+    ref_labels, ref_pred = OT.vote(len(coord), 4, parts, lg)
+    assert np.allclose(pred.numpy(), ref_pred, atol=1e-5)
+    assert np.array_equal(labels.numpy(), ref_labels)
