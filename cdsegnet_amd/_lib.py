@@ -75,7 +75,14 @@ SIGNATURES = {
     "cdseg_pool_level": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cdseg_pool_gather": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
+    "cdseg_coarse_orders_ws_bytes": (c_size_t, [c_long, c_int, c_int]),
+    "cdseg_coarse_orders": (c_int, [POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_long, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
     "cdseg_nbr_table": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cdseg_nbr_hash_slots": (c_long, [c_long]),
+    "cdseg_nbr_hash_build": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "cdseg_nbr_table_hashed": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_long,
+                                       c_void_p, c_void_p]),
     "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "cdseg_voxelize": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cdseg_max_run": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),

@@ -19,6 +19,8 @@
 // Epilogue: the accumulator tile goes through LDS so that bias / folded BatchNorm / GELU /
 // residual / un-pooling gather-add / second typed copy / row scatter run on row-contiguous
 // float4 groups and every store is a full 16-byte (8-byte for bf16) coalesced access.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -45,7 +47,11 @@ struct GemmP {
   float* ws;   // split-K partial sums (splits, M, N) fp32, or nullptr
   int splits;
   int kshift;
-  // row-wise LayerNorm fusion (only when one block holds complete rows: N <= BN, no split-K)
+  int gm, gn;  // output tiles
+  int xmode;   // block -> (tile, split) map: 0 plain, 1 W-slice per XCD, 2 contiguous row range per XCD
+  int fix;     // 0: epilogue straight from the accumulators; partial tiles -> ws, then 1: splitk_epilogue_kernel,
+               // 2: row_finish_kernel (LayerNorm over rows wider than a column tile, with or without split-K)
+  // row-wise LayerNorm fusion (needs complete rows: one block when N <= BN and no split-K, else fix == 2)
   const float* colbias;   // (N) added with the residual (timestep-embedding bias)
   const float* ln_pre_g;  // LayerNorm of the GEMM result BEFORE the residual add (CPE: x += LN(Linear(conv)))
   const float* ln_pre_b;
@@ -139,7 +145,118 @@ __device__ __forceinline__ void epilogue4(const GemmP& g, long m, int n, float4 
   }
 }
 
-// second pass of a split-K GEMM: sum the partial tiles, then the fused epilogue
+// ---- row-wise epilogue on a lane's float4 groups (columns c0 + 4 * (part + L * i)) of row m.
+// L lanes share a row; with LayerNorm the lanes of a row reduce through shuffles, so ALL lanes of a row group
+// must call this (inactive rows pass act_row = false).
+template <int MAXG>
+__device__ __forceinline__ void finish_row(const GemmP& g, long m, bool act_row, int part, int L, int groups, int c0,
+                                           float4 (&v)[MAXG]) {
+  const bool ln = g.ln_pre_g || g.ln_post_g;
+  if (!ln) {
+    if (act_row) {
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i)
+        if (part + L * i < groups) epilogue4(g, m, c0 + 4 * (part + L * i), v[i]);
+    }
+    return;
+  }
+  const float inv_n = 1.0f / (float)g.N;
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int cg = part + L * i;
+    if (cg < groups) {
+      const int n = c0 + 4 * cg;
+      if (g.bias) {
+        const float4 t = *reinterpret_cast<const float4*>(g.bias + n);
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+      if (g.scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(g.scale + n);
+        const float4 sh = *reinterpret_cast<const float4*>(g.shift + n);
+        v[i].x = v[i].x * sc.x + sh.x; v[i].y = v[i].y * sc.y + sh.y;
+        v[i].z = v[i].z * sc.z + sh.z; v[i].w = v[i].w * sc.w + sh.w;
+      }
+      if (g.act != CDSEG_ACT_NONE) {
+        v[i].x = apply_act(v[i].x, g.act); v[i].y = apply_act(v[i].y, g.act);
+        v[i].z = apply_act(v[i].z, g.act); v[i].w = apply_act(v[i].w, g.act);
+      }
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  auto row_layernorm = [&](const float* gam, const float* bet, float4 (&o)[MAXG]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+      if (part + L * i < groups) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int o2 = 1; o2 < L; o2 <<= 1) s += __shfl_xor(s, o2, 64);
+    const float mean = s * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+      if (part + L * i < groups) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    for (int o2 = 1; o2 < L; o2 <<= 1) q += __shfl_xor(q, o2, 64);
+    const float rstd = 1.0f / sqrtf(q * inv_n + g.ln_eps);
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+      if (part + L * i < groups) {
+        const int n = c0 + 4 * (part + L * i);
+        const float4 ga = *reinterpret_cast<const float4*>(gam + n);
+        const float4 be = *reinterpret_cast<const float4*>(bet + n);
+        o[i].x = (v[i].x - mean) * rstd * ga.x + be.x;
+        o[i].y = (v[i].y - mean) * rstd * ga.y + be.y;
+        o[i].z = (v[i].z - mean) * rstd * ga.z + be.z;
+        o[i].w = (v[i].w - mean) * rstd * ga.w + be.w;
+      }
+  };
+  if (g.ln_pre_g) row_layernorm(g.ln_pre_g, g.ln_pre_b, v);
+  if (act_row) {
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int cg = part + L * i;
+      if (cg >= groups) continue;
+      const int n = c0 + 4 * cg;
+      if (g.out2 && g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v[i]);
+      if (g.res) {
+        const float4 t = *reinterpret_cast<const float4*>(g.res + m * g.ldres + n);
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+      if (g.colbias) {
+        const float4 t = *reinterpret_cast<const float4*>(g.colbias + n);
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+      if (g.add_src) {
+        const float4 t = *reinterpret_cast<const float4*>(g.add_src + (long)g.add_idx[m] * g.ldadd + n);
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+      store_vec4(g.out, g.out_dtype, m * g.ldo + n, v[i]);
+      if (g.out2 && !g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v[i]);
+    }
+  } else {
+    // keep the shuffles of inactive rows well defined
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (g.ln_post_g) {
+    float4 h[MAXG];
+    row_layernorm(g.ln_post_g, g.ln_post_b, h);
+    if (act_row) {
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) {
+        const int cg = part + L * i;
+        if (cg < groups) store_vec4(g.ln_out, g.ln_out_dtype, m * g.ldln + c0 + 4 * cg, h[i]);
+      }
+    }
+  }
+}
+
+// second pass of a split-K GEMM without LayerNorm: sum the partial tiles in split order, then the fused epilogue.
+// (An in-kernel "last block finishes the tile" variant was measured and dropped: an agent-scope fence flushes and
+// invalidates the XCD's L2 (+55 us per launch); write-through partials avoid that but the serial tail of the
+// finishing block costs more than this launch.)
 __global__ void splitk_epilogue_kernel(GemmP g) {
   const long groups = g.M * (long)(g.N >> 2);
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +271,30 @@ __global__ void splitk_epilogue_kernel(GemmP g) {
     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
   }
   epilogue4(g, m, n, v);
+}
+
+// second pass for LayerNorm-fused GEMMs whose rows span several column tiles (and / or K splits): one wave per
+// row, the whole row in registers (N <= 512: two float4 per lane), split-K sum + the full row epilogue.
+__global__ __launch_bounds__(256) void row_finish_kernel(GemmP g) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= g.M) return;
+  const int groups = g.N >> 2;
+  const long sstride = g.M * (long)g.N;
+  float4 v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane + 64 * i < groups) {
+      const float* p = g.ws + m * g.N + 4 * (lane + 64 * i);
+      v[i] = *reinterpret_cast<const float4*>(p);
+      for (int s2 = 1; s2 < g.splits; ++s2) {
+        const float4 u = *reinterpret_cast<const float4*>(p + s2 * sstride);
+        v[i].x += u.x; v[i].y += u.y; v[i].z += u.z; v[i].w += u.w;
+      }
+    }
+  }
+  finish_row<2>(g, m, true, lane, 64, groups, 0, v);
 }
 
 // CT: compute/storage type of A and W.  BN: tile width.  NCH: 16-byte chunks per LDS row.
@@ -182,8 +323,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // block -> (row tile, column tile, K split).  Blocks go round-robin over the 8 XCDs (own L2 each):
+  //   xmode 1: all row tiles of one (column tile, split) = one W slice run on ONE XCD, so every XCD pulls 1/8 of W
+  //            from HBM instead of all of it (deep stages: few rows, W of several MB);
+  //   xmode 2: every XCD owns a contiguous range of row tiles (z-ordered rows: neighbour gathers stay in one L2).
+  int mt, sl;
+  {
+    const int bid = blockIdx.x, slices = g.gn * g.splits;
+    if (g.xmode == 1) {
+      const int j = bid >> 3;
+      mt = j % g.gm;
+      sl = (bid & 7) + 8 * (j / g.gm);
+      if (sl >= slices) return;
+    } else if (g.xmode == 2) {
+      const int j = bid >> 3, chunk = (g.gm + 7) >> 3;
+      mt = (bid & 7) * chunk + j / slices;
+      sl = j % slices;
+      if (j / slices >= chunk || mt >= g.gm) return;
+    } else {
+      mt = bid % g.gm;
+      sl = bid / g.gm;
+    }
+  }
+  const int nt = sl % g.gn, zs = sl / g.gn;
+  const long m0 = (long)mt * BM;
+  const int n0 = nt * BN;
   const long Kw = (long)g.kvol * g.K;  // W row length
 
   int nlive = 1;
@@ -277,8 +441,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
   const int fr = lane & 15, fg = lane >> 4;
 
   // split-K: this block reduces chunks [kc0, kc1) of the (compacted) K range
-  const int kc0 = (int)(((long)nkc * blockIdx.z) / gridDim.z);
-  const int kc1 = (int)(((long)nkc * (blockIdx.z + 1)) / gridDim.z);
+  const int kc0 = (int)(((long)nkc * zs) / g.splits);
+  const int kc1 = (int)(((long)nkc * (zs + 1)) / g.splits);
   if (kc0 < kc1) {
     load_tiles(kc0);
     store_tiles();
@@ -345,153 +509,109 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
         Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
-  // ---- fused LayerNorm epilogue: 4 lanes own one row (complete in this block), values stay in registers
-  if (g.ln_pre_g || g.ln_post_g) {
-    constexpr int MAXG = BN / 16;  // float4 groups per lane
-    const int row = tid >> 2, part = tid & 3;
-    const long m = m0 + row;
-    const bool act_row = m < g.M;
-    const int ng = g.N >> 2;
-    const float inv_n = 1.0f / (float)g.N;
-    float4 v[MAXG];
+  if (g.fix == 0) {
+    if (g.ln_pre_g || g.ln_post_g) {
+      // fused LayerNorm: the block holds complete rows; 4 lanes own one row, values stay in registers
+      constexpr int MAXG = BN / 16;
+      const int row = tid >> 2, part = tid & 3;
+      const long m = m0 + row;
+      const int ng = g.N >> 2;
+      float4 v[MAXG];
 #pragma unroll
-    for (int i = 0; i < MAXG; ++i) {
-      const int cg = part + 4 * i;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cg < ng) {
-        const int n = 4 * cg;
-        v[i] = *reinterpret_cast<const float4*>(Cs + row * CLD + n);
-        if (g.bias) {
-          const float4 t = *reinterpret_cast<const float4*>(g.bias + n);
-          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-        }
-        if (g.scale) {
-          const float4 sc = *reinterpret_cast<const float4*>(g.scale + n);
-          const float4 sh = *reinterpret_cast<const float4*>(g.shift + n);
-          v[i].x = v[i].x * sc.x + sh.x; v[i].y = v[i].y * sc.y + sh.y;
-          v[i].z = v[i].z * sc.z + sh.z; v[i].w = v[i].w * sc.w + sh.w;
-        }
-        if (g.act != CDSEG_ACT_NONE) {
-          v[i].x = apply_act(v[i].x, g.act); v[i].y = apply_act(v[i].y, g.act);
-          v[i].z = apply_act(v[i].z, g.act); v[i].w = apply_act(v[i].w, g.act);
-        }
-      }
+      for (int i = 0; i < MAXG; ++i)
+        v[i] = (part + 4 * i < ng) ? *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * (part + 4 * i))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      finish_row<MAXG>(g, m, m < g.M, part, 4, ng, 0, v);
+      return;
     }
-    auto row_layernorm = [&](const float* gam, const float* bet, float4 (&o)[MAXG]) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXG; ++i)
-        if (part + 4 * i < ng) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      const float mean = s * inv_n;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXG; ++i)
-        if (part + 4 * i < ng) {
-          const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-          q += (a * a + b * b) + (c * c + d * d);
-        }
-      q += __shfl_xor(q, 1, 64);
-      q += __shfl_xor(q, 2, 64);
-      const float rstd = 1.0f / sqrtf(q * inv_n + g.ln_eps);
-#pragma unroll
-      for (int i = 0; i < MAXG; ++i)
-        if (part + 4 * i < ng) {
-          const int n = 4 * (part + 4 * i);
-          const float4 ga = *reinterpret_cast<const float4*>(gam + n);
-          const float4 be = *reinterpret_cast<const float4*>(bet + n);
-          o[i].x = (v[i].x - mean) * rstd * ga.x + be.x;
-          o[i].y = (v[i].y - mean) * rstd * ga.y + be.y;
-          o[i].z = (v[i].z - mean) * rstd * ga.z + be.z;
-          o[i].w = (v[i].w - mean) * rstd * ga.w + be.w;
-        }
-    };
-    if (g.ln_pre_g) row_layernorm(g.ln_pre_g, g.ln_pre_b, v);
-    if (act_row) {
-#pragma unroll
-      for (int i = 0; i < MAXG; ++i) {
-        const int cg = part + 4 * i;
-        if (cg >= ng) continue;
-        const int n = 4 * cg;
-        if (g.out2 && g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v[i]);
-        if (g.res) {
-          const float4 t = *reinterpret_cast<const float4*>(g.res + m * g.ldres + n);
-          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-        }
-        if (g.colbias) {
-          const float4 t = *reinterpret_cast<const float4*>(g.colbias + n);
-          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-        }
-        if (g.add_src) {
-          const float4 t = *reinterpret_cast<const float4*>(g.add_src + (long)g.add_idx[m] * g.ldadd + n);
-          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-        }
-        store_vec4(g.out, g.out_dtype, m * g.ldo + n, v[i]);
-        if (g.out2 && !g.out2_pre_add) store_vec4(g.out2, g.out2_dtype, m * g.ldo2 + n, v[i]);
-      }
-    } else {
-      // keep the shuffles of inactive rows well defined
-#pragma unroll
-      for (int i = 0; i < MAXG; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (g.ln_post_g) {
-      float4 h[MAXG];
-      row_layernorm(g.ln_post_g, g.ln_post_b, h);
-      if (act_row) {
-#pragma unroll
-        for (int i = 0; i < MAXG; ++i) {
-          const int cg = part + 4 * i;
-          if (cg < ng) store_vec4(g.ln_out, g.ln_out_dtype, m * g.ldln + 4 * cg, h[i]);
-        }
-      }
+    // epilogue on row-contiguous groups of 4 columns
+    constexpr int GPR = BN / 4;  // groups per row
+    for (int item = tid; item < BM * GPR; item += 256) {
+      const int row = item / GPR, cg = item % GPR;
+      const long m = m0 + row;
+      const int n = n0 + 4 * cg;
+      if (m >= g.M || n >= g.N) continue;
+      epilogue4(g, m, n, *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg));
     }
     return;
   }
 
-  // ---- epilogue on row-contiguous groups of 4 columns (or raw partial tile for split-K)
-  constexpr int GPR = BN / 4;  // groups per row
-  for (int item = tid; item < BM * GPR; item += 256) {
-    const int row = item / GPR, cg = item % GPR;
-    const long m = m0 + row;
-    const int n = n0 + 4 * cg;
-    if (m >= g.M || n >= g.N) continue;
-    const float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
-    if (gridDim.z > 1) {
-      *reinterpret_cast<float4*>(g.ws + ((long)blockIdx.z * g.M + m) * g.N + n) = v;
-    } else {
-      epilogue4(g, m, n, v);
+  // ---- raw partial tile -> workspace; a second launch sums the splits and runs the (row) epilogue
+  {
+    constexpr int GPR = BN / 4;
+    for (int item = tid; item < BM * GPR; item += 256) {
+      const int row = item / GPR, cg = item % GPR;
+      const long m = m0 + row;
+      const int n = n0 + 4 * cg;
+      if (m >= g.M || n >= g.N) continue;
+      *reinterpret_cast<float4*>(g.ws + ((long)zs * g.M + m) * g.N + n) =
+          *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
     }
   }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 template <typename CT, int NCH, bool GATHER>
 int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   constexpr int BK = NCH * (16 / (int)sizeof(CT));
-  const unsigned gm = (unsigned)((p.M + 63) / 64);
+  static const int split_target = env_int("CDSEG_GEMM_SPLIT_TARGET", 512);
+  static const int split_max = env_int("CDSEG_GEMM_SPLIT_MAX", 32);
+  static const int xmode_env = env_int("CDSEG_GEMM_XMODE", -1);
+  const int gm = (int)((p.M + 63) / 64);
   const bool ln = p.ln_pre_g || p.ln_post_g;
   // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
   const int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
-  (void)ln;
-  const unsigned gn = (unsigned)((p.N + bn - 1) / bn);
+  const int gn = (p.N + bn - 1) / bn;
   // split-K when the output tiles alone cannot fill the chip (deep stages: few points, long reductions)
   int splits = 1;
   const long nkc = ((long)p.kvol * p.K + BK - 1) / BK;
   const long blocks = (long)gm * gn;
-  if (p.ws && p.vec_ok && !ln && blocks < 256 && nkc >= 4) {
-    splits = (int)((512 + blocks - 1) / blocks);
-    if (splits > nkc / 2) splits = (int)(nkc / 2);
-    if (splits > 16) splits = 16;
-    while (splits > 1 && (size_t)splits * p.M * p.N * sizeof(float) > ws_bytes) --splits;
+  const bool can_fix = p.ws && p.vec_ok && !p.out_idx;
+  static const int plain_min_nkc = env_int("CDSEG_GEMM_SPLIT_MIN_NKC", 16);
+  if (can_fix && blocks < 256 && nkc >= (GATHER ? 4 : plain_min_nkc)) {
+    int smax = (int)(nkc / 2);
+    if (smax > split_max) smax = split_max;
+    while (smax > 1 && (size_t)smax * p.M * p.N * sizeof(float) > ws_bytes) --smax;
+    splits = (int)((split_target + blocks - 1) / blocks);
+    if (splits > smax) splits = smax;
+    // prefer a slice count (column tiles x splits) that spreads evenly over the 8 XCDs
+    for (int c = splits; c <= smax && c < splits + 4; ++c)
+      if ((gn * c) % 8 == 0) { splits = c; break; }
     if (splits < 1) splits = 1;
   }
+  p.fix = 0;
+  if (splits > 1) p.fix = ln ? 2 : 1;
+  else if (ln && gn > 1) p.fix = 2;
+  if (p.fix) {
+    if (!can_fix || (size_t)splits * p.M * p.N * sizeof(float) > ws_bytes) return CDSEG_ERR_WORKSPACE;
+    if (p.fix == 2 && p.N > 512) return CDSEG_ERR_UNSUPPORTED;
+  }
   p.splits = splits;
-  const dim3 grid(gm, gn, (unsigned)splits);
+  p.gm = gm;
+  p.gn = gn;
+  const int slices = gn * splits;
+  const long wbytes = (long)p.N * p.kvol * p.K * (long)sizeof(CT);
+  p.xmode = 0;
+  if (slices >= 8 && wbytes >= (1 << 20) && gm > 1) p.xmode = 1;
+  else if (GATHER && gm >= 64) p.xmode = 2;
+  if (xmode_env >= 0) p.xmode = (xmode_env == 1 && slices < 8) ? 0 : xmode_env;
+  unsigned nblk;
+  if (p.xmode == 1) nblk = 8u * (unsigned)((slices + 7) / 8) * (unsigned)gm;
+  else if (p.xmode == 2) nblk = 8u * (unsigned)((gm + 7) / 8) * (unsigned)slices;
+  else nblk = (unsigned)gm * (unsigned)slices;
+  const dim3 grid(nblk);
   if (bn == 32) hipLaunchKernelGGL((gemm_kernel<CT, 32, NCH, GATHER>), grid, dim3(256), 0, s, p);
   else if (bn == 64) hipLaunchKernelGGL((gemm_kernel<CT, 64, NCH, GATHER>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<CT, 128, NCH, GATHER>), grid, dim3(256), 0, s, p);
   if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
-  if (splits > 1) {
+  if (p.fix == 2) {
+    hipLaunchKernelGGL(row_finish_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
+    if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
+  } else if (p.fix == 1) {
     const long groups = p.M * (long)(p.N >> 2);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
     if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
@@ -537,14 +657,18 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   p.ln_post_b = a->ln_post_b; p.ln_out = a->ln_out; p.ldln = a->ldln; p.ln_out_dtype = a->ln_out_dtype;
   p.ln_eps = a->ln_eps;
   if (p.ln_pre_g || p.ln_post_g) {
-    // a block must hold complete rows; rows are processed as float4 groups; no row scatter
-    if (a->N > 128 || !p.vec_ok || a->out_idx || (p.ln_pre_g && !p.ln_pre_b) || (p.ln_post_g && (!p.ln_post_b || !a->ln_out)) ||
+    // complete rows are finished by one block (N <= 128 directly, wider rows / split-K through the workspace);
+    // rows are processed as float4 groups; no row scatter
+    if (a->N > 512 || !p.vec_ok || a->out_idx || (p.ln_pre_g && !p.ln_pre_b) || (p.ln_post_g && (!p.ln_post_b || !a->ln_out)) ||
         (a->ln_out && (a->ldln % 4)))
       return CDSEG_ERR_UNSUPPORTED;
   }
   if (p.colbias && !al16(p.colbias)) p.vec_ok = 0;
   p.ws = (a->ws && ((((uintptr_t)a->ws) & 15) == 0)) ? (float*)a->ws : nullptr;
   p.splits = 1;
+  p.fix = 0;
+  p.gm = p.gn = 1;
+  p.xmode = 0;
   p.kshift = -1;
   if ((a->K & (a->K - 1)) == 0) {
     int sh = 0;

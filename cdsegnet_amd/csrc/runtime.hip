@@ -20,7 +20,7 @@ struct Carver {
   }
 };
 
-constexpr int FUSE_LN_MAX_C = 128;
+constexpr int FUSE_LN_MAX_C = 512;  // widest row one GEMM block finishes (LayerNorm fused into the epilogue)
 constexpr size_t SPLITK_WS_CAP = (size_t)64 << 20;
 
 inline size_t esz(int dtype) { return dtype == CDSEG_F32 ? 4 : 2; }
@@ -41,9 +41,11 @@ Layout carve(const cdseg_block_desc* d, long n, void* scratch) {
   L.o = c.take(n * C * e);
   L.u = c.take(n * (size_t)d->hidden * e);
   L.y2 = d->channels > FUSE_LN_MAX_C ? c.take(n * C * 4) : nullptr;
-  // split-K partial tiles: needed by any GEMM of the block whose output has few tiles (the narrowest is N = C)
+  // partial tiles: needed by any GEMM of the block whose output has few tiles (the narrowest is N = C) for split-K,
+  // and by the LayerNorm-fused GEMMs whose rows span several column tiles (C > 128)
   const long tiles = ((n + 63) / 64) * (((long)C + 127) / 128);
-  L.ws_bytes = tiles < 256 ? (size_t)16 * n * (size_t)(3 * C > (size_t)d->hidden ? 3 * C : d->hidden) * 4 : 0;
+  L.ws_bytes = tiles < 256 ? (size_t)32 * n * (size_t)(3 * C > (size_t)d->hidden ? 3 * C : d->hidden) * 4
+                           : (C > 128 ? (size_t)n * C * 4 : 0);
   if (L.ws_bytes > SPLITK_WS_CAP) L.ws_bytes = SPLITK_WS_CAP;
   L.ws = L.ws_bytes ? c.take(L.ws_bytes) : nullptr;
   L.total = align_up(c.off, 256);

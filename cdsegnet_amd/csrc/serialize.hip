@@ -54,7 +54,13 @@ __global__ void grid_max_kernel(const G* __restrict__ grid, long n3, unsigned lo
     long long t = __shfl_xor(m, o, 64);
     m = t > m ? t : m;
   }
-  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)m);
+  __shared__ long long wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic per block (thousands of same-address 64-bit atomics cost ~50 us)
+    for (int w = 1; w < 4; ++w) m = wmax[w] > m ? wmax[w] : m;
+    atomicMax(out, (unsigned long long)m);
+  }
 }
 
 __global__ void offset2batch_kernel(const int64_t* __restrict__ offset, int nb, long n, int32_t* __restrict__ batch) {
@@ -143,6 +149,45 @@ __global__ void level_finish_kernel(const int32_t* __restrict__ incl, const int3
   }
 }
 
+// ---- coarse-level curve orders WITHOUT sorting.  A pooled level's code on any of the four curves is the fine code
+// shifted right (ref: ptv3.py:503-514 - SerializedPooling shifts the parent codes and arg-sorts them); z-order and
+// Hilbert keys are hierarchical, so the fine points of one coarse cell are contiguous in EVERY fine curve order and
+// the coarse order is the fine order with each point replaced by its cluster id and consecutive duplicates removed.
+// One flag / scan / compact pass covers all levels x curves (segments back to back; each yields exactly m_l flags).
+struct CoarseP {
+  const int32_t* cluster[8];  // per level: fine point -> cluster id
+  const int32_t* order[3];    // per curve: rank -> fine point
+  long n0;
+  int nlev, ncurve;
+};
+
+__device__ __forceinline__ bool coarse_head(const CoarseP& p, long i, int32_t* v_out) {
+  const long per = (long)p.ncurve * p.n0;
+  const int l = (int)(i / per);
+  const long r = i - (long)l * per;
+  const int c = (int)(r / p.n0);
+  const long j = r - (long)c * p.n0;
+  const int32_t* cl = p.cluster[l];
+  const int32_t* od = p.order[c];
+  const int32_t v = cl[od[j]];
+  *v_out = v;
+  return j == 0 || cl[od[j - 1]] != v;
+}
+
+__global__ void coarse_flag_kernel(CoarseP p, long total, int32_t* __restrict__ flag) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int32_t v;
+  flag[i] = coarse_head(p, i, &v) ? 1 : 0;
+}
+
+__global__ void coarse_compact_kernel(CoarseP p, long total, const int32_t* __restrict__ pos, int32_t* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int32_t v;
+  if (coarse_head(p, i, &v)) out[pos[i] - 1] = v;
+}
+
 // pooled level arrays from the first fine point of every cluster
 __global__ void pool_gather_kernel(const int32_t* __restrict__ seg_start, long m, long n_fine, int pd,
                                    const int32_t* __restrict__ grid_f, const int32_t* __restrict__ batch_f,
@@ -195,6 +240,51 @@ __global__ void nbr_table_kernel(const int64_t* __restrict__ zc, const int32_t* 
   nbr[kmajor ? (long)o * n + i : t] = res;
 }
 
+// ---- hashed variant: open-addressing table of point indices keyed by the (batch | z) code.  One build per level
+// serves every kernel size; a lookup is ~1.3 probes instead of a log2(n)-deep binary search with no locality.
+__device__ __forceinline__ uint32_t code_hash(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+__global__ void nbr_hash_build_kernel(const int64_t* __restrict__ zc, long n, int32_t* __restrict__ table, uint32_t mask) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t slot = code_hash((uint64_t)zc[i]) & mask;
+  while (atomicCAS(&table[slot], -1, (int32_t)i) != -1) slot = (slot + 1) & mask;
+}
+
+__global__ void nbr_table_hashed_kernel(const int64_t* __restrict__ zc, const int32_t* __restrict__ grid,
+                                        const int32_t* __restrict__ batch, long n, int depth, int ksize, int kmajor,
+                                        const int32_t* __restrict__ table, uint32_t mask, int32_t* __restrict__ nbr) {
+  const int kv = ksize * ksize * ksize;
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * kv) return;
+  // thread order follows the output layout so the stores coalesce
+  const int o = kmajor ? (int)(t / n) : (int)(t % kv);
+  const long i = kmajor ? t - (long)o * n : t / kv;
+  const int r = ksize >> 1;
+  const int a = o / (ksize * ksize), b = (o / ksize) % ksize, c = o % ksize;
+  const int x = grid[3 * i + 0] + a - r, y = grid[3 * i + 1] + b - r, z = grid[3 * i + 2] + c - r;
+  const int lim = 1 << depth;
+  int res = -1;
+  if (o == kv / 2) {
+    res = (int)i;
+  } else if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+    const int64_t key = (int64_t)((((uint64_t)batch[i]) << (3 * depth)) | z_key((uint32_t)x, (uint32_t)y, (uint32_t)z, depth));
+    uint32_t slot = code_hash((uint64_t)key) & mask;
+    for (;;) {
+      const int32_t idx = table[slot];
+      if (idx < 0) break;
+      if (zc[idx] == key) { res = idx; break; }
+      slot = (slot + 1) & mask;
+    }
+  }
+  nbr[kmajor ? (long)o * n + i : i * kv + o] = res;
+}
+
 // attention slot plan (ptv3.py:188-244 in scatter form).  For padded slot p of batch element b:
 //   local < n_b  : rank = local                       (real slot, its output is kept)
 //   local >= n_b : rank = local - K                   (borrowed from the previous patch's tail)
@@ -230,7 +320,7 @@ int cdseg_grid_max(const void* grid, int elem_bytes, long n3, int64_t* out_dev, 
   if (hipMemsetAsync(out_dev, 0, sizeof(int64_t), s) != hipSuccess) return CDSEG_ERR_LAUNCH;
   if (n3 <= 0) return CDSEG_OK;
   int blocks = (int)((n3 + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 128) blocks = 128;
   if (elem_bytes == 8)
     hipLaunchKernelGGL(grid_max_kernel<int64_t>, dim3(blocks), dim3(256), 0, s, (const int64_t*)grid, n3,
                        (unsigned long long*)out_dev);
@@ -393,6 +483,41 @@ int cdseg_pool_level(const int64_t* zcode_sorted, long n, int shift, int32_t* cl
   return CDSEG_OK;
 }
 
+size_t cdseg_coarse_orders_ws_bytes(long n0, int nlev, int ncurve) {
+  const size_t total = (size_t)n0 * nlev * ncurve;
+  size_t scan_bytes = 0;
+  (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, total,
+                                rocprim::plus<int32_t>(), (hipStream_t)0, false);
+  return 2 * ((total * sizeof(int32_t) + 255) & ~(size_t)255) + scan_bytes + 1024;
+}
+
+// clusters: nlev device pointers (fine point -> cluster id of level l); orders: ncurve device pointers (rank -> fine
+// point); out: int32, level l / curve c at offset ncurve * sum_{l' < l} m_l' + c * m_l.
+int cdseg_coarse_orders(const int32_t* const* clusters, int nlev, const int32_t* const* orders, int ncurve, long n0,
+                        int32_t* out, void* ws, size_t ws_bytes, void* stream) {
+  if (n0 <= 0 || nlev <= 0 || ncurve <= 0) return CDSEG_OK;
+  if (nlev > 8 || ncurve > 3 || !clusters || !orders || !out) return CDSEG_ERR_ARG;
+  if (ws_bytes < cdseg_coarse_orders_ws_bytes(n0, nlev, ncurve)) return CDSEG_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  CoarseP p;
+  for (int l = 0; l < 8; ++l) p.cluster[l] = l < nlev ? clusters[l] : nullptr;
+  for (int c = 0; c < 3; ++c) p.order[c] = c < ncurve ? orders[c] : nullptr;
+  p.n0 = n0; p.nlev = nlev; p.ncurve = ncurve;
+  const long total = n0 * nlev * ncurve;
+  char* w = (char*)ws;
+  const size_t arr = (((size_t)total * sizeof(int32_t)) + 255) & ~(size_t)255;
+  int32_t* flag = (int32_t*)w;
+  int32_t* pos = (int32_t*)(w + arr);
+  hipLaunchKernelGGL(coarse_flag_kernel, grid1d(total), dim3(256), 0, s, p, total, flag);
+  size_t scan_bytes = ws_bytes - 2 * arr;
+  hipError_t e = rocprim::inclusive_scan((void*)(w + 2 * arr), scan_bytes, (const int32_t*)flag, pos, (size_t)total,
+                                         rocprim::plus<int32_t>(), s, false);
+  if (e != hipSuccess) return CDSEG_ERR_LAUNCH;
+  hipLaunchKernelGGL(coarse_compact_kernel, grid1d(total), dim3(256), 0, s, p, total, pos, out);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
 int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling_depth, const int32_t* grid_f,
                       const int32_t* batch_f, const int64_t* code4_f, int32_t* grid_c, int32_t* batch_c,
                       int64_t* code4_c, void* stream) {
@@ -410,6 +535,35 @@ int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int3
   const long total = n * ksize * ksize * ksize;
   hipLaunchKernelGGL(nbr_table_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid, batch, n,
                      depth, ksize, kmajor, nbr);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+long cdseg_nbr_hash_slots(long n) {
+  long s = 1024;
+  while (s < 2 * n) s <<= 1;
+  return s;
+}
+
+// table: cdseg_nbr_hash_slots(n) int32 slots
+int cdseg_nbr_hash_build(const int64_t* zcode_sorted, long n, int32_t* table, long slots, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (slots < cdseg_nbr_hash_slots(n) || (slots & (slots - 1)) || slots > (1l << 31)) return CDSEG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(table, 0xff, (size_t)slots * sizeof(int32_t), s) != hipSuccess) return CDSEG_ERR_LAUNCH;
+  hipLaunchKernelGGL(nbr_hash_build_kernel, grid1d(n), dim3(256), 0, s, zcode_sorted, n, table, (uint32_t)(slots - 1));
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_nbr_table_hashed(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
+                           int ksize, int kmajor, const int32_t* table, long slots, int32_t* nbr, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (ksize != 3 && ksize != 5) return CDSEG_ERR_ARG;
+  if (!table || slots <= 0 || (slots & (slots - 1))) return CDSEG_ERR_ARG;
+  const long total = n * ksize * ksize * ksize;
+  hipLaunchKernelGGL(nbr_table_hashed_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid,
+                     batch, n, depth, ksize, kmajor, table, (uint32_t)(slots - 1), nbr);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

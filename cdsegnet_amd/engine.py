@@ -35,12 +35,14 @@ def _pooling_depth(stride):
 
 class Level:
     """One voxel resolution of the scene, points in (batch | z) sorted order."""
+    HASH_MIN_POINTS = 20000
 
     def __init__(self, cum, depth, n, grid, batch, code4, offs_host):
         self.cum, self.depth, self.n = cum, depth, n
         self.grid, self.batch, self.code4 = grid, batch, code4
         self.offs_host = offs_host  # (B+1) python ints
         self._order = {}
+        self._hash = None
         self._nbr = {}
         self._pad = {}
         self._slots = {}
@@ -59,7 +61,13 @@ class Level:
     def nbr(self, ksize, kmajor=False):
         key = (ksize, kmajor)
         if key not in self._nbr:
-            self._nbr[key] = ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
+            if self.n >= self.HASH_MIN_POINTS:  # big level: hashed lookups; the table serves every kernel size
+                if self._hash is None:
+                    self._hash = ops.nbr_hash(self.code4[0])
+                self._nbr[key] = ops.nbr_table_hashed(self.code4[0], self.grid, self.batch, self.depth, ksize,
+                                                      self._hash, kmajor)
+            else:  # small level: a short binary search over the sorted codes
+                self._nbr[key] = ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
         return self._nbr[key]
 
     def pad_host(self, patch_size, enable_flash):
@@ -335,6 +343,14 @@ class Engine:
                 g, b, c4 = ops.pool_gather(tmp[i][1], m, n, cum, grid0, bat0, code0)
                 plan.levels[cum] = Level(cum, depth - cum, m, g, b, c4, [0] + [v + 1 for v in e])
                 plan.links[(0, cum)] = (tmp[i][0], tmp[i][1])
+            # curve orders of the pooled levels: derived from the level-0 orders (hierarchical keys), not sorted
+            used = sorted({CURVES.index(o) for o in bb.order} - {0})
+            if used:
+                lv0 = plan.levels[0]
+                derived = ops.coarse_orders([t[0] for t in tmp], [lv0.order(c) for c in used], host[:len(coarse)])
+                for i, cum in enumerate(coarse):
+                    for k, c in enumerate(used):
+                        plan.levels[cum]._order[c] = derived[i][k]
         # every padding plan the model will ask for, uploaded with ONE host->device copy
         if self._pad_keys is None:  # static per model: walk the module tree once
             self._pad_keys = sorted({(int(m_.patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
@@ -360,7 +376,7 @@ class Engine:
     def _buf(self, rows, cols, dtype):
         return torch.empty((rows, cols), dtype=dtype, device=self.device)
 
-    FUSE_LN_MAX_C = 128  # a GEMM block holds complete rows up to this width -> LayerNorm in the epilogue
+    FUSE_LN_MAX_C = 512  # rows up to this width are finished by one GEMM block -> LayerNorm in the epilogue
 
     def _cpe(self, st, pre, xc, tbias=None, next_norm=None):
         """x += LN(Linear(SubMConv3d(xc)))  [+ t bias]   (ref: ptv3.py:401-411).

@@ -244,6 +244,26 @@ def pool_level(zcode_sorted, shift_bits, count_out=None):
     return cluster, seg_start, count
 
 
+def coarse_orders(clusters, orders, sizes):
+    """Curve orders of all pooled levels from the level-0 orders (no sort).  clusters: per level (n0) int32 cluster
+    ids of the level-0 points; orders: per curve (n0) int32 rank -> level-0 point; sizes: per level m_l.
+    Returns [[order of level l on curve c for c] for l] as views of one int32 buffer."""
+    lib = _lib.load()
+    n0 = clusters[0].numel()
+    nl, nc = len(clusters), len(orders)
+    dev = clusters[0].device
+    out = torch.empty(nc * int(sum(sizes)), dtype=torch.int32, device=dev)
+    ws = workspace(lib.cdseg_coarse_orders_ws_bytes(n0, nl, nc), dev)
+    cp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in clusters])
+    op = (ctypes.c_void_p * nc)(*[t.data_ptr() for t in orders])
+    check(lib.cdseg_coarse_orders(cp, nl, op, nc, n0, _ptr(out), _ptr(ws), ws.numel(), _stream()), "coarse_orders")
+    res, pos = [], 0
+    for m in sizes:
+        res.append([out[pos + c * m: pos + (c + 1) * m] for c in range(nc)])
+        pos += nc * m
+    return res
+
+
 def pool_gather(seg_start, m, n_fine, pooling_depth, grid_f, batch_f, code4_f):
     dev = grid_f.device
     grid_c = torch.empty((m, 3), dtype=torch.int32, device=dev)
@@ -262,6 +282,26 @@ def nbr_table(zcode_sorted, grid_i32, batch_i32, depth, ksize, kmajor=False):
     nbr = torch.empty(shape, dtype=torch.int32, device=grid_i32.device)
     check(_lib.load().cdseg_nbr_table(_ptr(zcode_sorted), _ptr(grid_i32), _ptr(batch_i32), n, int(depth), int(ksize),
                                       1 if kmajor else 0, _ptr(nbr), _stream()), "nbr_table")
+    return nbr
+
+
+def nbr_hash(zcode_sorted):
+    """Open-addressing table (int32 point indices) over the sorted codes of one level."""
+    lib = _lib.load()
+    n = zcode_sorted.numel()
+    slots = lib.cdseg_nbr_hash_slots(n)
+    table = torch.empty(slots, dtype=torch.int32, device=zcode_sorted.device)
+    check(lib.cdseg_nbr_hash_build(_ptr(zcode_sorted), n, _ptr(table), slots, _stream()), "nbr_hash_build")
+    return table
+
+
+def nbr_table_hashed(zcode_sorted, grid_i32, batch_i32, depth, ksize, table, kmajor=False):
+    n = zcode_sorted.numel()
+    kv = ksize ** 3
+    nbr = torch.empty((kv, n) if kmajor else (n, kv), dtype=torch.int32, device=zcode_sorted.device)
+    check(_lib.load().cdseg_nbr_table_hashed(_ptr(zcode_sorted), _ptr(grid_i32), _ptr(batch_i32), n, int(depth),
+                                              int(ksize), 1 if kmajor else 0, _ptr(table), table.numel(), _ptr(nbr),
+                                              _stream()), "nbr_table_hashed")
     return nbr
 
 
@@ -329,7 +369,10 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
         a.ln_post_g = a.ln_post_b = a.ln_out = None
     a.ln_eps = float(ln_eps)
     if ((m + 63) >> 6) * ((a.N + 127) >> 7) < 256:  # split-K partials: only when the output has few tiles
-        ws = workspace(min(16 * m * a.N * 4, 64 << 20), out.device)
+        ws = workspace(min(32 * m * a.N * 4, 64 << 20), out.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    elif a.N > 128 and (ln_pre is not None or ln_post is not None):  # rows over several column tiles
+        ws = workspace(m * a.N * 4, out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     else:
         a.ws, a.ws_bytes = None, 0

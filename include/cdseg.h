@@ -90,6 +90,14 @@ int cdseg_plan_gather_grid(const void* grid, int grid_elem_bytes, const int32_t*
  * run-start flags, seg_start (count+1 entries) are the run starts, *count_dev the number of runs. */
 int cdseg_pool_level(const int64_t* zcode_sorted, long n, int shift_bits, int32_t* cluster, int32_t* seg_start,
                      int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
+/* Curve orders of ALL pooled levels without sorting: z-order / Hilbert keys are hierarchical, so the coarse order on a
+ * curve is the level-0 order with every point replaced by its cluster id and consecutive duplicates dropped
+ * (replaces torch.argsort(code >> 3*depth) of SerializedPooling, ref ptv3.py:503-514).
+ * clusters[l] (n0): level-0 point -> cluster id at pooled level l; orders[c] (n0): rank -> level-0 point on curve c.
+ * out: level l / curve c at int32 offset ncurve * sum_{l'<l} m_l' + c * m_l. */
+size_t cdseg_coarse_orders_ws_bytes(long n0, int nlev, int ncurve);
+int cdseg_coarse_orders(const int32_t* const* clusters, int nlev, const int32_t* const* orders, int ncurve, long n0,
+                        int32_t* out, void* ws, size_t ws_bytes, void* stream);
 /* pooled grid / batch / codes from the first fine point of each run.  ref: ptv3.py:489-491, 519-525 */
 int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling_depth, const int32_t* grid_f,
                       const int32_t* batch_f, const int64_t* code4_f, int32_t* grid_c, int32_t* batch_c,
@@ -103,6 +111,12 @@ int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling
 int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
                     int ksize, int kmajor, int32_t* nbr, void* stream);
 
+/* Hashed neighbour lookup (large levels): one open-addressing table of point indices per level, keyed by the
+ * (batch | z) code, serves every kernel size.  table: cdseg_nbr_hash_slots(n) int32. Same output as cdseg_nbr_table. */
+long cdseg_nbr_hash_slots(long n);
+int cdseg_nbr_hash_build(const int64_t* zcode_sorted, long n, int32_t* table, long slots, void* stream);
+int cdseg_nbr_table_hashed(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
+                           int ksize, int kmajor, const int32_t* table, long slots, int32_t* nbr, void* stream);
 /* ------------------------------------------------------------------ attention padding plan
  * ref: ptv3.py:188-244 (get_padding_and_inverse) in gather/scatter form: for every padded slot
  * the row to read (gidx) and the row to write (widx, -1 for the borrowed duplicates).

@@ -83,6 +83,21 @@ def pool_level(zs, shift, count_out=None):
     return cluster, seg, cnt
 
 
+def coarse_orders(clusters, orders, sizes):
+    res = []
+    for cl, m in zip(clusters, sizes):
+        per = []
+        for od in orders:
+            v = cl[od.long()]
+            keep = torch.ones_like(v, dtype=torch.bool)
+            keep[1:] = v[1:] != v[:-1]
+            o = v[keep]
+            assert o.numel() == m
+            per.append(o.int())
+        res.append(per)
+    return res
+
+
 def pool_gather(seg, m, n_fine, pd, grid_f, batch_f, code4_f):
     h = seg[:m].long()
     return grid_f[h] >> pd, batch_f[h], code4_f[:, h] >> (3 * pd)
@@ -91,6 +106,14 @@ def pool_gather(seg, m, n_fine, pd, grid_f, batch_f, code4_f):
 def nbr_table(zs, grid, batch, depth, ksize, kmajor=False):
     t = torch.from_numpy(OM.subm_neighbors(grid.numpy(), batch.numpy(), ksize)).int()
     return t.t().contiguous() if kmajor else t
+
+
+def nbr_hash(zs):
+    return torch.zeros(1, dtype=torch.int32)
+
+
+def nbr_table_hashed(zs, grid, batch, depth, ksize, table, kmajor=False):
+    return nbr_table(zs, grid, batch, depth, ksize, kmajor)
 
 
 def pad_plan(order, offs, offs_pad, patch, n_pad):

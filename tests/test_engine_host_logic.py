@@ -134,3 +134,28 @@ def test_testtime_pipeline_host_logic(emulated, monkeypatch):
     ref_labels, ref_pred = OT.vote(len(coord), 4, parts, lg)
     assert np.allclose(pred.numpy(), ref_pred, atol=1e-5)
     assert np.array_equal(labels.numpy(), ref_labels)
+
+
+@pytest.mark.parametrize("name", ["tiny64", "room1500", "batch2", "lidar5000", "rand16"])
+def test_coarse_orders_need_no_sort(name):
+    """The property the engine's plan relies on: z-order / Hilbert keys are hierarchical, so arg-sorting the shifted
+    codes of a pooled level (ptv3.py:503-514) equals de-duplicating the cluster ids along the level-0 order."""
+    from oracle import serialization as S
+    fx = load_fixture(f"serialization_{name}.npz")
+    grid, batch, depth = fx["grid_coord"], fx["batch"], int(fx["depth"])
+    z = S.encode(grid, batch, depth, "z")
+    for pd in (1, 2, 3):
+        if pd >= depth:
+            break
+        _, cluster = np.unique(z >> (3 * pd), return_inverse=True)
+        m = cluster.max() + 1
+        head = np.full(m, -1, dtype=np.int64)
+        head[cluster[::-1]] = np.arange(len(z))[::-1]  # any member: the shifted code is the same for all of them
+        for order in ("z-trans", "hilbert", "hilbert-trans"):
+            code = S.encode(grid, batch, depth, order)
+            assert len(np.unique(code[head] >> (3 * pd))) == m  # coarse codes are unique: the arg-sort has no ties
+            ref = np.argsort(code[head] >> (3 * pd), kind="stable")
+            v = cluster[np.argsort(code, kind="stable")]
+            keep = np.ones(len(v), dtype=bool)
+            keep[1:] = v[1:] != v[:-1]
+            assert np.array_equal(v[keep], ref), (name, pd, order)
