@@ -7,7 +7,10 @@
 A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-attention
 fusion) over one synthetic ScanNet-shaped scene per GPU (BASELINE.json configs[1]: ~120k voxels,
 6-ch features, 20 classes, bf16), inputs already resident in HBM.  Scenes are independent units:
-each rank runs its own scene, no data-path collective ("scaling": "weak").  RCCL is used once to
+each rank runs its own scenes, no data-path collective ("scaling": "weak"); within a rank the K
+steps go through DefaultSegmentorV2.inference_many, which keeps up to --lanes scenes in flight on
+separate HIP streams (every scene still runs the full path; `single_scene_latency_ms` reports the
+one-scene-at-a-time latency next to the throughput).  RCCL is used once to
 broadcast the weights from rank 0 and for the final timing / counter reductions.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = serialized window attention,
@@ -39,7 +42,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--dataset", default="scannet", choices=["scannet", "scannet200", "nuscenes"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -47,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--cpu-points", type=int, default=12000)
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="independent scenes in flight per GPU (HIP streams); 1 = strictly one scene at a time")
     return ap.parse_args()
 
 
@@ -97,11 +102,12 @@ def main():
     inp["offset_host"] = [int(v) for v in sc["offset"]]
     torch.manual_seed(54421566 + rank)
 
-    def step():
-        return model.inference(dict(inp), eval=False)["seg_logits"]
+    def run(k):
+        """k steps = k independent scene inferences, up to --lanes of them in flight (DefaultSegmentorV2.inference_many)."""
+        return model.inference_many([dict(inp) for _ in range(k)], lanes=args.lanes)[-1]["seg_logits"]
 
-    for _ in range(args.warmup):
-        out = step()
+    if args.warmup:
+        out = run(args.warmup)
     torch.cuda.synchronize()
     timer = not args.no_kernel_timer
     if world > 1:
@@ -111,8 +117,7 @@ def main():
         ops.attention_prof_enable(True)
     work0 = model.engine().attn_work
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -121,6 +126,20 @@ def main():
     attn_ms, attn_launches = ops.attention_prof_summary() if timer else (0.0, 0)
     attn_work = model.engine().attn_work - work0
     ops.attention_prof_enable(False)
+    # after the timed region: the same kernel with nothing else on the GPU (one scene at a time), and that scene's latency
+    iso = None
+    if timer and rank == 0:
+        torch.cuda.synchronize()
+        ops.attention_prof_enable(True)
+        w1 = model.engine().attn_work
+        t1 = time.perf_counter()
+        for _ in range(5):
+            model.inference(dict(inp), eval=False)
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 5
+        ims, il = ops.attention_prof_summary()
+        iso = dict(ms=ims, launches=il, work=model.engine().attn_work - w1, latency_ms=1e3 * lat)
+        ops.attention_prof_enable(False)
     assert torch.isfinite(out).all()
 
     # per-class intersection/union/target counters of the last step: the per-scene record the reference
@@ -152,7 +171,7 @@ def main():
             "config": {"workload": f"{args.dataset}-shape {n}-point scene per GPU, CDSegNet 1-step inference "
                                    f"(PT-v3m1 dual backbone, 101.4M params, random-init), 1 scene/step/GPU",
                        "points_per_scene": n, "precision": args.precision, "scenes_per_step_per_gpu": 1,
-                       "noise": "device Philox"},
+                       "scenes_in_flight_per_gpu": args.lanes, "noise": "device Philox"},
         }
         if timer and attn_ms > 0:
             achieved = attn_work / (attn_ms * 1e-3) / 1e12
@@ -163,7 +182,14 @@ def main():
                                "launches_per_step": attn_launches / args.steps,
                                "avg_launch_us": 1e3 * attn_ms / attn_launches,
                                "algorithmic_gflop_per_step": attn_work / args.steps / 1e9,
-                               "note": "VALU/transcendental-issue bound at head dim 16 (DESIGN.md 5)"}
+                               "note": "VALU/transcendental-issue bound at head dim 16 (DESIGN.md 5); durations are "
+                                       "HIP-event times inside the timed region, where up to --lanes scenes share the GPU"}
+            if iso and iso["ms"] > 0:
+                ia = iso["work"] / (iso["ms"] * 1e-3) / 1e12
+                res["roofline"]["isolated"] = {"achieved": ia, "frac": ia / peak,
+                                               "avg_launch_us": 1e3 * iso["ms"] / iso["launches"],
+                                               "note": "same kernel, one scene at a time (nothing else on the GPU)"}
+                res["single_scene_latency_ms"] = iso["latency_ms"]
             res["kernel_ms_per_step"] = {"attention": attn_ms / args.steps}
             tpath = os.path.join(ROOT, "profiles", "r01_attention_traffic.json")
             if args.precision == "bf16" and os.path.exists(tpath):

@@ -33,6 +33,7 @@ class GemmArgs(Structure):
         ("ws", c_void_p), ("ws_bytes", c_size_t),
         ("colbias", c_void_p), ("ln_pre_g", c_void_p), ("ln_pre_b", c_void_p), ("ln_post_g", c_void_p),
         ("ln_post_b", c_void_p), ("ln_out", c_void_p), ("ldln", c_int), ("ln_out_dtype", c_int), ("ln_eps", c_float),
+        ("nbr_kmajor", c_int),
     ]
 
 
@@ -79,10 +80,6 @@ SIGNATURES = {
     "cdseg_coarse_orders": (c_int, [POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_long, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
     "cdseg_nbr_table": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "cdseg_nbr_hash_slots": (c_long, [c_long]),
-    "cdseg_nbr_hash_build": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p]),
-    "cdseg_nbr_table_hashed": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_long,
-                                       c_void_p, c_void_p]),
     "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "cdseg_voxelize": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cdseg_max_run": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),

@@ -47,6 +47,7 @@ struct GemmP {
   float* ws;   // split-K partial sums (splits, M, N) fp32, or nullptr
   int splits;
   int kshift;
+  long nbr_sm, nbr_so;  // neighbour table strides (row, offset): (kvol, 1) row-major or (1, M) offset-major
   int gm, gn;  // output tiles
   int xmode;   // block -> (tile, split) map: 0 plain, 1 W-slice per XCD, 2 contiguous row range per XCD
   int fix;     // 0: epilogue straight from the accumulators; partial tiles -> ws, then 1: splitk_epilogue_kernel,
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
       if (m < g.M) {
         unsigned long long lo = 0ull, hi = 0ull;
         for (int o = tid & 3; o < g.kvol; o += 4)
-          if (g.nbr[m * g.kvol + o] >= 0) {
+          if (g.nbr[m * g.nbr_sm + (long)o * g.nbr_so] >= 0) {
             if (o < 64) lo |= 1ull << o; else hi |= 1ull << (o - 64);
           }
         if (lo) atomicOr(&smask[0], lo);
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
         if (GATHER) {
           const int j = kshift >= 0 ? (kv >> kshift) : (int)((unsigned)kv / (unsigned)g.K);
           const int cc = kv - j * g.K;
-          const int src = g.nbr[m * g.kvol + live[1 + j]];
+          const int src = g.nbr[m * g.nbr_sm + (long)live[1 + j] * g.nbr_so];
           if (src >= 0) a_reg[i] = *reinterpret_cast<const uint4*>((const CT*)g.A + (long)src * g.lda + cc);
         } else {
           a_reg[i] = *reinterpret_cast<const uint4*>((const CT*)g.A + m * g.lda + kv);
@@ -653,6 +654,8 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
              (!a->res || (a->ldres % 4 == 0 && al16(a->res))) &&
              (!a->add_src || (a->ldadd % 4 == 0 && al16(a->add_src))) && (!a->bias || al16(a->bias)) &&
              (!a->scale || (al16(a->scale) && al16(a->shift)));
+  p.nbr_sm = a->nbr_kmajor ? 1 : a->kvol;
+  p.nbr_so = a->nbr_kmajor ? a->M : 1;
   p.colbias = a->colbias; p.ln_pre_g = a->ln_pre_g; p.ln_pre_b = a->ln_pre_b; p.ln_post_g = a->ln_post_g;
   p.ln_post_b = a->ln_post_b; p.ln_out = a->ln_out; p.ldln = a->ldln; p.ln_out_dtype = a->ln_out_dtype;
   p.ln_eps = a->ln_eps;

@@ -86,7 +86,7 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
   // ---- CPE: x += LN(Linear(SubMConv3d(xc)))  [+ t bias];  h = LN1(x)      (ptv3.py:401-413)
   {
     cdseg_gemm_args a = base_args(d, L, n);
-    a.A = io->xc_in; a.lda = C; a.W = d->cpe_conv_w; a.bias = d->cpe_conv_b; a.nbr = io->nbr; a.kvol = 27;
+    a.A = io->xc_in; a.lda = C; a.W = d->cpe_conv_w; a.bias = d->cpe_conv_b; a.nbr = io->nbr; a.nbr_kmajor = 1; a.kvol = 27;
     a.N = C; a.K = C; a.out = L.y; a.ldo = C; a.out_dtype = T;
     if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
   }

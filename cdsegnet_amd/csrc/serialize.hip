@@ -219,8 +219,10 @@ __global__ void nbr_table_kernel(const int64_t* __restrict__ zc, const int32_t* 
   const int kv = ksize * ksize * ksize;
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * kv) return;
-  const long i = t / kv;
-  const int o = (int)(t - i * kv);
+  // offset-major output: a wave = one offset of 64 consecutive z-ordered points, whose neighbours are again close in
+  // z-order, so the lanes' binary searches walk the same cache lines (and the stores coalesce)
+  const long i = kmajor ? t % n : t / kv;
+  const int o = kmajor ? (int)(t / n) : (int)(t - i * kv);
   const int r = ksize >> 1;
   const int a = o / (ksize * ksize), b = (o / ksize) % ksize, c = o % ksize;
   const int x = grid[3 * i + 0] + a - r, y = grid[3 * i + 1] + b - r, z = grid[3 * i + 2] + c - r;
@@ -238,51 +240,6 @@ __global__ void nbr_table_kernel(const int64_t* __restrict__ zc, const int32_t* 
     if (lo < n && zc[lo] == key) res = (int)lo;
   }
   nbr[kmajor ? (long)o * n + i : t] = res;
-}
-
-// ---- hashed variant: open-addressing table of point indices keyed by the (batch | z) code.  One build per level
-// serves every kernel size; a lookup is ~1.3 probes instead of a log2(n)-deep binary search with no locality.
-__device__ __forceinline__ uint32_t code_hash(uint64_t k) {
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdull;
-  k ^= k >> 33;
-  return (uint32_t)k;
-}
-
-__global__ void nbr_hash_build_kernel(const int64_t* __restrict__ zc, long n, int32_t* __restrict__ table, uint32_t mask) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t slot = code_hash((uint64_t)zc[i]) & mask;
-  while (atomicCAS(&table[slot], -1, (int32_t)i) != -1) slot = (slot + 1) & mask;
-}
-
-__global__ void nbr_table_hashed_kernel(const int64_t* __restrict__ zc, const int32_t* __restrict__ grid,
-                                        const int32_t* __restrict__ batch, long n, int depth, int ksize, int kmajor,
-                                        const int32_t* __restrict__ table, uint32_t mask, int32_t* __restrict__ nbr) {
-  const int kv = ksize * ksize * ksize;
-  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * kv) return;
-  // thread order follows the output layout so the stores coalesce
-  const int o = kmajor ? (int)(t / n) : (int)(t % kv);
-  const long i = kmajor ? t - (long)o * n : t / kv;
-  const int r = ksize >> 1;
-  const int a = o / (ksize * ksize), b = (o / ksize) % ksize, c = o % ksize;
-  const int x = grid[3 * i + 0] + a - r, y = grid[3 * i + 1] + b - r, z = grid[3 * i + 2] + c - r;
-  const int lim = 1 << depth;
-  int res = -1;
-  if (o == kv / 2) {
-    res = (int)i;
-  } else if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
-    const int64_t key = (int64_t)((((uint64_t)batch[i]) << (3 * depth)) | z_key((uint32_t)x, (uint32_t)y, (uint32_t)z, depth));
-    uint32_t slot = code_hash((uint64_t)key) & mask;
-    for (;;) {
-      const int32_t idx = table[slot];
-      if (idx < 0) break;
-      if (zc[idx] == key) { res = idx; break; }
-      slot = (slot + 1) & mask;
-    }
-  }
-  nbr[kmajor ? (long)o * n + i : i * kv + o] = res;
 }
 
 // attention slot plan (ptv3.py:188-244 in scatter form).  For padded slot p of batch element b:
@@ -535,35 +492,6 @@ int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int3
   const long total = n * ksize * ksize * ksize;
   hipLaunchKernelGGL(nbr_table_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid, batch, n,
                      depth, ksize, kmajor, nbr);
-  CDSEG_CHECK_LAUNCH();
-  return CDSEG_OK;
-}
-
-long cdseg_nbr_hash_slots(long n) {
-  long s = 1024;
-  while (s < 2 * n) s <<= 1;
-  return s;
-}
-
-// table: cdseg_nbr_hash_slots(n) int32 slots
-int cdseg_nbr_hash_build(const int64_t* zcode_sorted, long n, int32_t* table, long slots, void* stream) {
-  if (n <= 0) return CDSEG_OK;
-  if (slots < cdseg_nbr_hash_slots(n) || (slots & (slots - 1)) || slots > (1l << 31)) return CDSEG_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(table, 0xff, (size_t)slots * sizeof(int32_t), s) != hipSuccess) return CDSEG_ERR_LAUNCH;
-  hipLaunchKernelGGL(nbr_hash_build_kernel, grid1d(n), dim3(256), 0, s, zcode_sorted, n, table, (uint32_t)(slots - 1));
-  CDSEG_CHECK_LAUNCH();
-  return CDSEG_OK;
-}
-
-int cdseg_nbr_table_hashed(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
-                           int ksize, int kmajor, const int32_t* table, long slots, int32_t* nbr, void* stream) {
-  if (n <= 0) return CDSEG_OK;
-  if (ksize != 3 && ksize != 5) return CDSEG_ERR_ARG;
-  if (!table || slots <= 0 || (slots & (slots - 1))) return CDSEG_ERR_ARG;
-  const long total = n * ksize * ksize * ksize;
-  hipLaunchKernelGGL(nbr_table_hashed_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid,
-                     batch, n, depth, ksize, kmajor, table, (uint32_t)(slots - 1), nbr);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

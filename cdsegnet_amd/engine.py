@@ -19,6 +19,7 @@ MI355X-first data layout (not the reference's):
 Host<->device syncs: offset + grid max (depth), pooled point counts (one copy for all levels).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -33,16 +34,27 @@ def _pooling_depth(stride):
     return (math.ceil(stride) - 1).bit_length()
 
 
+def _shared(cache, key, build):
+    """Lazily built plan item shared by the two branch streams: the builder's stream records an event, a consumer
+    on the other stream waits for it (the item itself lives as long as the plan)."""
+    ent = cache.get(key)
+    cur = ops.current_stream_id()
+    if ent is None:
+        val = build()
+        ent = cache[key] = (val, cur, ops.record_event() if cur is not None else None)
+    elif ent[1] != cur and ent[2] is not None:
+        ops.wait_event(ent[2])
+    return ent[0]
+
+
 class Level:
     """One voxel resolution of the scene, points in (batch | z) sorted order."""
-    HASH_MIN_POINTS = 20000
 
     def __init__(self, cum, depth, n, grid, batch, code4, offs_host):
         self.cum, self.depth, self.n = cum, depth, n
         self.grid, self.batch, self.code4 = grid, batch, code4
         self.offs_host = offs_host  # (B+1) python ints
         self._order = {}
-        self._hash = None
         self._nbr = {}
         self._pad = {}
         self._slots = {}
@@ -51,24 +63,18 @@ class Level:
         """rank -> physical row for a curve (None = identity for z)."""
         if curve == 0:
             return None
-        if curve not in self._order:
+
+        def build():
             nb = len(self.offs_host) - 1
             end_bit = min(64, 3 * self.depth + max(1, nb.bit_length()))
-            _, perm = ops.sort_pairs(self.code4[curve], None, end_bit=end_bit)
-            self._order[curve] = perm
-        return self._order[curve]
+            return ops.sort_pairs(self.code4[curve], None, end_bit=end_bit)[1]
+        return _shared(self._order, curve, build)
 
     def nbr(self, ksize, kmajor=False):
-        key = (ksize, kmajor)
-        if key not in self._nbr:
-            if self.n >= self.HASH_MIN_POINTS:  # big level: hashed lookups; the table serves every kernel size
-                if self._hash is None:
-                    self._hash = ops.nbr_hash(self.code4[0])
-                self._nbr[key] = ops.nbr_table_hashed(self.code4[0], self.grid, self.batch, self.depth, ksize,
-                                                      self._hash, kmajor)
-            else:  # small level: a short binary search over the sorted codes
-                self._nbr[key] = ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
-        return self._nbr[key]
+        # offset-major tables: a wave searches one offset of 64 consecutive z-ordered points (same cache lines);
+        # an open-addressing hash table was measured and is NOT faster (two dependent random reads per lookup)
+        return _shared(self._nbr, (ksize, kmajor),
+                       lambda: ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor))
 
     def pad_host(self, patch_size, enable_flash):
         """Host side of the padding plan (ref: ptv3.py:188-250): K, offs, offs_pad, patch_start (int32 arrays)."""
@@ -97,11 +103,10 @@ class Level:
         return self._pad[key]
 
     def slots(self, curve, patch_size, enable_flash):
-        key = (curve, patch_size, enable_flash)
-        if key not in self._slots:
+        def build():
             K, n_pad, offs, offs_pad = self.pad(patch_size, enable_flash)[:4]
-            self._slots[key] = ops.pad_plan(self.order(curve), offs, offs_pad, K, n_pad)
-        return self._slots[key]
+            return ops.pad_plan(self.order(curve), offs, offs_pad, K, n_pad)
+        return _shared(self._slots, (curve, patch_size, enable_flash), build)
 
 
 class Plan:
@@ -111,11 +116,11 @@ class Plan:
 
     def link(self, a, b):
         """fine level a -> coarse level b: (cluster (n_a) int32, seg_start (n_b + 1) int32)."""
-        if (a, b) not in self.links:
+        def build():
             la, lb = self.levels[a], self.levels[b]
             cluster, seg, _ = ops.pool_level(la.code4[0], 3 * (lb.cum - la.cum))
-            self.links[(a, b)] = (cluster, seg)
-        return self.links[(a, b)]
+            return (cluster, seg)
+        return _shared(self.links, (a, b), build)
 
 
 class State:
@@ -137,6 +142,11 @@ class Engine:
         self.rng_offset = 0
         self.use_native_blocks = True  # one library call per Block instead of ~8 binding calls
         self._pad_keys = None
+        self._side = {}
+        self.fork_stage = 1  # dominant-branch encoder stage at which the noise-branch encoder is forked (None: serial)
+        env = os.environ.get("CDSEG_FORK_STAGE")
+        if env is not None:
+            self.fork_stage = None if env.lower() in ("none", "-1", "") else int(env)
         self.attn_work = 0.0  # algorithmic attention FLOPs issued so far (4 * 16 * H * sum_p L_p^2 per launch)
 
     # ------------------------------------------------------------------ weights
@@ -287,12 +297,33 @@ class Engine:
                          fc1_b=w[pre + ".fc1.b"], fc2_w=w[pre + ".fc2.w"], fc2_b=w[pre + ".fc2.b"])
                 self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
                                                            mod.attn.scale, 1e-5, t)
-        self._scratch = None
+        self._scratch = {}
 
     def scratch(self, nbytes):
-        if self._scratch is None or self._scratch.numel() < nbytes:
-            self._scratch = torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8, device=self.device)
-        return self._scratch
+        key = ops.current_stream_id()  # one scratch arena per stream (the two branches run concurrently)
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._scratch[key] = torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def _on_side_stream(self, fn):
+        """Run fn's launches on the engine's side stream, ordered after everything issued so far on the bound
+        stream.  Returns (fn's result, completion event).  Tensors allocated inside belong to the side stream's
+        allocator pool; they are consumed on the main stream only after the completion event."""
+        main = torch.cuda.current_stream()
+        side = self._side.get(main.cuda_stream)  # one side stream per calling stream (scenes may run on several)
+        if side is None:
+            side = self._side[main.cuda_stream] = torch.cuda.Stream(device=self.device)
+        fork_ev = ops.record_event()
+        try:
+            with torch.cuda.stream(side):
+                ops.bind_stream(side)
+                ops.wait_event(fork_ev)
+                out = fn()
+                done = ops.record_event()
+        finally:
+            ops.bind_stream(main)
+        return out, done
 
     # ------------------------------------------------------------------ plan
     def build_plan(self, grid, offset_dev, offset_host, n):
@@ -342,7 +373,7 @@ class Engine:
                 e = host[len(coarse) + i * nb: len(coarse) + (i + 1) * nb]
                 g, b, c4 = ops.pool_gather(tmp[i][1], m, n, cum, grid0, bat0, code0)
                 plan.levels[cum] = Level(cum, depth - cum, m, g, b, c4, [0] + [v + 1 for v in e])
-                plan.links[(0, cum)] = (tmp[i][0], tmp[i][1])
+                plan.links[(0, cum)] = ((tmp[i][0], tmp[i][1]), ops.current_stream_id(), None)
             # curve orders of the pooled levels: derived from the level-0 orders (hierarchical keys), not sorted
             used = sorted({CURVES.index(o) for o in bb.order} - {0})
             if used:
@@ -350,7 +381,7 @@ class Engine:
                 derived = ops.coarse_orders([t[0] for t in tmp], [lv0.order(c) for c in used], host[:len(coarse)])
                 for i, cum in enumerate(coarse):
                     for k, c in enumerate(used):
-                        plan.levels[cum]._order[c] = derived[i][k]
+                        plan.levels[cum]._order[c] = (derived[i][k], ops.current_stream_id(), None)
         # every padding plan the model will ask for, uploaded with ONE host->device copy
         if self._pad_keys is None:  # static per model: walk the module tree once
             self._pad_keys = sorted({(int(m_.patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
@@ -384,7 +415,7 @@ class Engine:
         w, lv = self.w, st.level
         c = st.x.shape[1]
         y = self._buf(lv.n, c, self.T)
-        ops.gemm(xc, w[pre + "0.w"], y, bias=w[pre + "0.b"], nbr=lv.nbr(3), kvol=27)
+        ops.gemm(xc, w[pre + "0.w"], y, bias=w[pre + "0.b"], nbr=lv.nbr(3, True), nbr_kmajor=True, kvol=27)
         h = self._buf(lv.n, c, self.T) if next_norm else None
         if c <= self.FUSE_LN_MAX_C:
             ops.gemm(y, w[pre + "1.w"], st.x, bias=w[pre + "1.b"], ln_pre=(w[pre + "2.g"], w[pre + "2.b"]), res=st.x,
@@ -426,7 +457,7 @@ class Engine:
             self.attn_work += 64.0 * att.num_heads * sum_l2
             desc = self.block_desc[pre]
             xc_out = st.x if self.T == torch.float32 else self._buf(n, c, self.T)
-            ops.block_forward(desc, n, st.x, st.xc, xc_out, tbias, lv.nbr(3), gidx, widx, patch_start,
+            ops.block_forward(desc, n, st.x, st.xc, xc_out, tbias, lv.nbr(3, True), gidx, widx, patch_start,
                               patch_start.numel() - 1, max_len, self.scratch(ops.block_scratch_bytes(desc, n)))
             st.xc = xc_out
             return
@@ -458,7 +489,7 @@ class Engine:
         x = self._buf(lv.n, cout, torch.float32)
         xc = x if self.T == torch.float32 else self._buf(lv.n, cout, self.T)
         ops.gemm(a, w[pre + ".w"], x, scale=w[pre + ".bn.scale"], shift=w[pre + ".bn.shift"], act=ops.ACT_GELU,
-                 nbr=lv.nbr(5), kvol=125, out2=None if xc is x else xc)
+                 nbr=lv.nbr(5, True), nbr_kmajor=True, kvol=125, out2=None if xc is x else xc)
         return State(lv, x, xc, curves)
 
     def run_pooling(self, plan, st, pre, cum_to, perm):
@@ -725,22 +756,35 @@ class Engine:
                     self.run_block(st, mod, key, tb.get(key))
             return st
 
-        # ref: ptv3.py:1781-1794 (the c/n interleave only matters for the order of the randperm draws)
-        if cond:
-            cst = self.run_embedding(plan, c_feat, c_perm, "c_emb", c_curves)
-        nst = self.run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
+        # ref: ptv3.py:1781-1794.  The reference interleaves the two encoders (c0 n0 c1 n1 n2 c2 n3 n4); that order
+        # only fixes which randperm draw each stage consumes.  The encoders are independent until the cross block, so
+        # the noise-branch encoder is issued on a SIDE STREAM, forked when the dominant branch reaches stage
+        # `fork_stage`: its throughput-bound 120k-point blocks then fill the CUs that the dominant branch's deep,
+        # latency-bound stages (a few hundred to a few thousand points) leave idle.
         if cond:
             assert bb.c_num_stages == 3 and bb.n_num_stages == 5, "interleave hard-wired as in ptv3.py:1785-1794"
-            cst = enc_stage(cst, "c", 0, c_cum, None)
-            nst = enc_stage(nst, "n", 0, n_cum, None)
-            cst = enc_stage(cst, "c", 1, c_cum, next(pi))
-            nst = enc_stage(nst, "n", 1, n_cum, next(pi))
-            nst = enc_stage(nst, "n", 2, n_cum, next(pi))
-            cst = enc_stage(cst, "c", 2, c_cum, next(pi))
-            nst = enc_stage(nst, "n", 3, n_cum, next(pi))
-            nst = enc_stage(nst, "n", 4, n_cum, next(pi))
+            p_c1, p_n1, p_n2, p_c2, p_n3, p_n4 = (next(pi) for _ in range(6))
+            n_perms = [None, p_n1, p_n2, p_n3, p_n4]
+
+            def c_branch():
+                st = self.run_embedding(plan, c_feat, c_perm, "c_emb", c_curves)
+                st = enc_stage(st, "c", 0, c_cum, None)
+                st = enc_stage(st, "c", 1, c_cum, p_c1)
+                return enc_stage(st, "c", 2, c_cum, p_c2)
+
+            fork = self.fork_stage if (dev.type == "cuda" and self.fork_stage is not None) else None
+            cst = c_branch() if fork is None else None
+            nst = self.run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
+            join = None
+            for s in range(bb.n_num_stages):
+                if fork is not None and s == fork:
+                    cst, join = self._on_side_stream(c_branch)
+                nst = enc_stage(nst, "n", s, n_cum, n_perms[s])
+            if join is not None:
+                ops.wait_event(join)
             self.run_cross_block(nst, cst)
         else:
+            nst = self.run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
             for s in range(bb.n_num_stages):
                 nst = enc_stage(nst, "n", s, n_cum, next(pi) if s > 0 else None)
         self.trace = {"n_bottleneck": nst.x}

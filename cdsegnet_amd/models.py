@@ -370,6 +370,7 @@ class DefaultSegmentorV2(nn.Module):
             self.t_emb_table = calc_t_emb_table(T, T_dim)  # (T, T_dim) host table, uploaded on first use
         # engine knobs (not part of the reference API)
         self.precision = "bf16"        # "bf16" (MFMA bf16, fp32 accumulate/residual) | "fp32" (exact-fp32 MFMA)
+        self._lanes = {}
         self.noise_source = "torch_cpu"  # "torch_cpu" replays the reference's CPU-generator draws | "device"
         self._engine = None
 
@@ -402,6 +403,46 @@ class DefaultSegmentorV2(nn.Module):
             raise NotImplementedError("eval=True (loss computation) is outside the inference hot path; "
                                       "the reference tester calls inference(eval=False) (engines/test.py:216)")
         return dict(seg_logits=self.engine().inference(input_dict, noise_level=noise_level, draws=draws))
+
+    @torch.no_grad()
+    def inference_many(self, input_dicts, lanes=3, noise_level=None, draws=None):
+        """Throughput form of ``inference`` for a sequence of INDEPENDENT scenes (the tester's loop over scenes /
+        fragments, ref: engines/test.py:197-279): scene i runs on HIP stream ``lane[i % lanes]``, so up to ``lanes``
+        scenes are in flight on the GPU.  The deep, latency-bound stages of one scene (a few hundred points, tens of
+        workgroups) then overlap the throughput-bound 120k-point stages of another, and a scene's two host syncs
+        (serialization depth, pooled sizes) only wait for its own lane.  Same kernels, same results as calling
+        ``inference`` scene by scene (random draws are consumed in the same order).
+        Returns the list of output dicts, valid on the caller's current stream."""
+        dicts = list(input_dicts)
+        if not dicts:
+            return []
+        dev = dicts[0]["feat"].device
+        eng = self.engine()
+        if dev.type != "cuda" or lanes <= 1:
+            return [self.inference(d, eval=False, noise_level=noise_level,
+                                   draws=None if draws is None else draws[i]) for i, d in enumerate(dicts)]
+        cur = torch.cuda.current_stream(dev)
+        key = (dev.index, int(lanes))
+        streams = self._lanes.get(key)
+        if streams is None:
+            streams = self._lanes[key] = [torch.cuda.Stream(device=dev) for _ in range(int(lanes))]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        for st in streams[:len(dicts)]:
+            st.wait_event(ready)  # inputs produced on the caller's stream
+        outs = []
+        fork, eng.fork_stage = eng.fork_stage, None  # concurrency comes from the lanes; no intra-scene fork
+        try:
+            for i, d in enumerate(dicts):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    o = eng.inference(d, noise_level=noise_level, draws=None if draws is None else draws[i])
+                o.record_stream(cur)
+                outs.append(dict(seg_logits=o))
+        finally:
+            eng.fork_stage = fork
+        for st in streams[:len(dicts)]:
+            cur.wait_stream(st)
+        return outs
 
     @torch.no_grad()
     def inference_ddim(self, input_dict, T=1000, step=1, report=10, eval=True, mode="avg", noise_level=None, draws=None):

@@ -86,21 +86,39 @@ def _ptr(t):
 
 
 _STREAM = None
+_STREAM_OBJ = None
 
 
 def bind_stream(stream=None):
     """Cache the HIP stream every op launches on (torch.cuda.current_stream() costs ~8 us per query, and an
-    inference issues ~500 launches).  The engine binds the current stream once per inference call."""
-    global _STREAM
+    inference issues ~500 launches).  The engine binds the current torch stream once per inference call and
+    re-binds when it switches to its side stream."""
+    global _STREAM, _STREAM_OBJ
     if stream is None:
-        stream = torch.cuda.current_stream().cuda_stream
-    _STREAM = ctypes.c_void_p(stream)
+        stream = torch.cuda.current_stream()
+    _STREAM_OBJ = stream
+    _STREAM = ctypes.c_void_p(stream.cuda_stream)
     return _STREAM
 
 
 def unbind_stream():
-    global _STREAM
-    _STREAM = None
+    global _STREAM, _STREAM_OBJ
+    _STREAM = _STREAM_OBJ = None
+
+
+def current_stream_id():
+    """Identity of the bound stream (None when nothing is bound)."""
+    return _STREAM.value if _STREAM is not None else None
+
+
+def record_event():
+    ev = torch.cuda.Event()
+    ev.record(_STREAM_OBJ if _STREAM_OBJ is not None else torch.cuda.current_stream())
+    return ev
+
+
+def wait_event(ev):
+    (_STREAM_OBJ if _STREAM_OBJ is not None else torch.cuda.current_stream()).wait_event(ev)
 
 
 def _stream():
@@ -119,7 +137,7 @@ def dt(t):
 
 def workspace(nbytes, device):
     """Per-device scratch buffer (grown geometrically, never shrunk)."""
-    key = (device.type, device.index)
+    key = (device.type, device.index, _STREAM.value if _STREAM is not None else None)  # one buffer per stream
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -285,26 +303,6 @@ def nbr_table(zcode_sorted, grid_i32, batch_i32, depth, ksize, kmajor=False):
     return nbr
 
 
-def nbr_hash(zcode_sorted):
-    """Open-addressing table (int32 point indices) over the sorted codes of one level."""
-    lib = _lib.load()
-    n = zcode_sorted.numel()
-    slots = lib.cdseg_nbr_hash_slots(n)
-    table = torch.empty(slots, dtype=torch.int32, device=zcode_sorted.device)
-    check(lib.cdseg_nbr_hash_build(_ptr(zcode_sorted), n, _ptr(table), slots, _stream()), "nbr_hash_build")
-    return table
-
-
-def nbr_table_hashed(zcode_sorted, grid_i32, batch_i32, depth, ksize, table, kmajor=False):
-    n = zcode_sorted.numel()
-    kv = ksize ** 3
-    nbr = torch.empty((kv, n) if kmajor else (n, kv), dtype=torch.int32, device=zcode_sorted.device)
-    check(_lib.load().cdseg_nbr_table_hashed(_ptr(zcode_sorted), _ptr(grid_i32), _ptr(batch_i32), n, int(depth),
-                                              int(ksize), 1 if kmajor else 0, _ptr(table), table.numel(), _ptr(nbr),
-                                              _stream()), "nbr_table_hashed")
-    return nbr
-
-
 def pad_plan(order, offs, offs_pad, patch, n_pad):
     dev = offs.device
     gidx = torch.empty(n_pad, dtype=torch.int32, device=dev)
@@ -317,6 +315,7 @@ def pad_plan(order, offs, offs_pad, patch, n_pad):
 # ------------------------------------------------------------------ float ops
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
          nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
+         nbr_kmajor=False,
          ln_post=None, ln_out=None, ln_eps=1e-5):
     """out = epilogue(A @ W^T) (or the gathered-A sparse-conv form when nbr is given).
     A (M,K) [or the gather source], W (N, kvol*K), both of the compute dtype."""
@@ -346,7 +345,8 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     a.A = A.data_ptr()
     a.res, a.add_src, a.add_idx, a.nbr, a.out_idx = _dp(res), _dp(add_src), _dp(add_idx), _dp(nbr), _dp(out_idx)
     a.out, a.out2 = out.data_ptr(), _dp(out2)
-    m = int(M if M is not None else (nbr.shape[0] if nbr is not None else A.shape[0]))
+    m = int(M if M is not None else (nbr.shape[1 if nbr_kmajor else 0] if nbr is not None else A.shape[0]))
+    a.nbr_kmajor = 1 if nbr_kmajor else 0
     a.M = m
     a.lda = A.stride(0)
     a.ldo = out.stride(0)

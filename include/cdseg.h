@@ -111,12 +111,6 @@ int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling
 int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
                     int ksize, int kmajor, int32_t* nbr, void* stream);
 
-/* Hashed neighbour lookup (large levels): one open-addressing table of point indices per level, keyed by the
- * (batch | z) code, serves every kernel size.  table: cdseg_nbr_hash_slots(n) int32. Same output as cdseg_nbr_table. */
-long cdseg_nbr_hash_slots(long n);
-int cdseg_nbr_hash_build(const int64_t* zcode_sorted, long n, int32_t* table, long slots, void* stream);
-int cdseg_nbr_table_hashed(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
-                           int ksize, int kmajor, const int32_t* table, long slots, int32_t* nbr, void* stream);
 /* ------------------------------------------------------------------ attention padding plan
  * ref: ptv3.py:188-244 (get_padding_and_inverse) in gather/scatter form: for every padded slot
  * the row to read (gidx) and the row to write (widx, -1 for the borrowed duplicates).
@@ -141,7 +135,7 @@ typedef struct cdseg_gemm_args {
   const float* res;       /* (M, ldres) or NULL */
   const float* add_src;   /* (*, ldadd) or NULL */
   const int32_t* add_idx; /* (M) */
-  const int32_t* nbr;     /* (M, kvol) or NULL */
+  const int32_t* nbr;     /* (M, kvol), or (kvol, M) when nbr_kmajor, or NULL */
   const int32_t* out_idx; /* (M) or NULL */
   void* out;              /* (M, ldo) out_dtype */
   void* out2;             /* (M, ldo2) out2_dtype or NULL */
@@ -164,6 +158,7 @@ typedef struct cdseg_gemm_args {
   void* ln_out;           /* (M, ldln) ln_out_dtype */
   int ldln, ln_out_dtype;
   float ln_eps;
+  int nbr_kmajor;         /* neighbour table is offset-major (kvol, M): coalesced index loads, cheaper to build */
 } cdseg_gemm_args;
 int cdseg_gemm(const cdseg_gemm_args* args_host, void* stream);
 
@@ -279,7 +274,7 @@ typedef struct cdseg_block_io {
   const void* xc_in;       /* (n, C) T: CPE conv input (sparse_conv_feat of the reference) */
   void* xc_out;            /* (n, C) T: shadow copy of the block output (may alias x when T is fp32) */
   const float* tbias;      /* (C) timestep bias or NULL */
-  const int32_t* nbr;      /* (n, 27) kernel map of the stage */
+  const int32_t* nbr;      /* (27, n) OFFSET-MAJOR kernel map of the stage (cdseg_nbr_table with kmajor = 1) */
   const int32_t* gidx;     /* attention slot plan of the block's curve */
   const int32_t* widx;
   const int32_t* patch_start;

@@ -108,14 +108,6 @@ def nbr_table(zs, grid, batch, depth, ksize, kmajor=False):
     return t.t().contiguous() if kmajor else t
 
 
-def nbr_hash(zs):
-    return torch.zeros(1, dtype=torch.int32)
-
-
-def nbr_table_hashed(zs, grid, batch, depth, ksize, table, kmajor=False):
-    return nbr_table(zs, grid, batch, depth, ksize, kmajor)
-
-
 def pad_plan(order, offs, offs_pad, patch, n_pad):
     offs, offs_pad = offs.numpy().astype(np.int64), offs_pad.numpy().astype(np.int64)
     gidx = np.empty(n_pad, dtype=np.int32)
@@ -142,9 +134,11 @@ def _act(v, act):
 
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
          nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
-         ln_post=None, ln_out=None, ln_eps=1e-5):
+         ln_post=None, ln_out=None, ln_eps=1e-5, nbr_kmajor=False):
     assert A.dtype == W.dtype
     Af, Wf = A.float(), W.float()
+    if nbr is not None and nbr_kmajor:
+        nbr = nbr.t()
     if nbr is None:
         v = Af @ Wf.t()
     else:
@@ -270,6 +264,18 @@ def bind_stream(stream=None):
 
 
 def unbind_stream():
+    pass
+
+
+def current_stream_id():
+    return None
+
+
+def record_event():
+    return None
+
+
+def wait_event(ev):
     pass
 
 

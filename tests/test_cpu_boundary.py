@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_gemm_args_struct_layout_matches_header():
-    # 12 pointers, one long, 14 ints, ws pointer + size, 6 LN pointers, 2 ints + float (+pad): any drift between include/cdseg.h and the ctypes mirror breaks every GEMM
+    # 12 pointers, one long, 14 ints, ws pointer + size, 6 LN pointers, 2 ints + float + int: any drift between include/cdseg.h and the ctypes mirror breaks every GEMM
     assert ctypes.sizeof(_lib.GemmArgs) == 12 * 8 + 8 + 14 * 4 + 16 + 6 * 8 + 16
     names = [f[0] for f in _lib.GemmArgs._fields_]
     hdr = open(os.path.join(ROOT, "include", "cdseg.h")).read()

@@ -294,3 +294,35 @@ def test_testtime_pipeline_vs_oracle():
     agree = (labels.cpu().numpy() == ref_labels).mean()
     print(f"[testtime pipeline fp32] max_prob_err={err:.3e} label_agreement={agree:.5f} fragments={len(parts)}")
     assert err < 1e-4 and agree > 0.999
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_inference_many_equals_scene_by_scene(precision):
+    """Scenes in flight on several HIP streams (inference_many) give bit-identical logits to one inference call
+    per scene (same kernels, same draw order), including scenes of different sizes sharing a lane."""
+    cfg = configs.mini_config()
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=4), strict=True)
+    model = model.to("cuda").eval()
+    model.precision = precision
+    scenes = [synth.room_scene(20 + i, n) for i, n in enumerate((5000, 1800, 7000, 2500, 5000, 900, 3000))]
+    dicts = [{k: torch.as_tensor(sc[k]).cuda() for k in ("coord", "grid_coord", "feat", "offset")} for sc in scenes]
+    torch.manual_seed(123)
+    ref = [model.inference(dict(d), eval=False)["seg_logits"].clone() for d in dicts]
+    for lanes in (2, 3):
+        torch.manual_seed(123)
+        outs = model.inference_many([dict(d) for d in dicts], lanes=lanes)
+        torch.cuda.synchronize()
+        for a, b in zip(outs, ref):
+            assert torch.equal(a["seg_logits"], b)
+    # the intra-scene fork (noise-branch encoder on a side stream) is result-neutral too
+    eng = model.engine()
+    keep = eng.fork_stage
+    try:
+        for fs in (None, 0, 3):
+            eng.fork_stage = fs
+            torch.manual_seed(123)
+            got = model.inference(dict(dicts[0]), eval=False)["seg_logits"]
+            assert torch.equal(got, ref[0]), fs
+    finally:
+        eng.fork_stage = keep

@@ -125,18 +125,6 @@ def test_neighbour_table_vs_oracle(ops, name, ksize):
     assert np.array_equal(nbr_t, ref.T)
 
 
-@pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000", "rand16"])
-@pytest.mark.parametrize("ksize", [3, 5])
-def test_hashed_neighbour_table_equals_binary_search(ops, name, ksize):
-    fx = load_fixture(f"serialization_{name}.npz")
-    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
-    table = ops.nbr_hash(zs)
-    for kmajor in (False, True):
-        a = ops.nbr_table(zs, g0, b0, depth, ksize, kmajor)
-        b = ops.nbr_table_hashed(zs, g0, b0, depth, ksize, table, kmajor)
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("name", CLOUDS)
 @pytest.mark.parametrize("K", [4, 16, 1024])
 def test_pad_plan_vs_reference_golden(ops, name, K):

@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--conv", action="store_true", help="include sparse-conv shapes (builds a 120k scene plan)")
+    ap.add_argument("--kmajor", action="store_true", help="offset-major neighbour tables")
     args = ap.parse_args()
     dev = torch.device("cuda")
     bf = torch.bfloat16
@@ -71,12 +72,12 @@ def main():
         cur = (zs, gz, bz, code4, depth, len(grid))
         for lvl, (n_expect, c) in enumerate(stages):
             zs, gz, bz, code4, d, n = cur
-            nbr = ops.nbr_table(zs, gz, bz, d, 3)
+            nbr = ops.nbr_table(zs, gz, bz, d, 3, args.kmajor)
             x = torch.randn(n, c, device=dev).to(bf)
             w = (torch.randn(c, 27 * c, device=dev) / (27 * c) ** 0.5).to(bf)
             b = torch.randn(c, device=dev)
             o = torch.empty(n, c, dtype=bf, device=dev)
-            us = time_op(lambda: ops.gemm(x, w, o, bias=b, nbr=nbr, kvol=27), args.iters)
+            us = time_op(lambda: ops.gemm(x, w, o, bias=b, nbr=nbr, kvol=27, nbr_kmajor=args.kmajor), args.iters)
             rows.append((f"conv3 n={n}", n, c, 27 * c, us, 2.0 * n * c * 27 * c / us / 1e6))
             if lvl < 4:
                 cl, seg, cnt = ops.pool_level(zs, 3)
