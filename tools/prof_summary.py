@@ -32,6 +32,29 @@ def main():
         "group by name, grid_x, grid_y order by sum(duration) desc"))
     for n, gx, gy, c, a, s in rows:
         print(f"{c:7d} {s / 1e6 / steps:9.3f} ms/step {a / 1e3:9.2f} us  grid=({gx},{gy})  {short(n)}")
+    concurrency(db, cur)
+
+
+def concurrency(db, cur):
+    """GPU occupancy of the stream timeline: union of kernel intervals vs the sum of their durations."""
+    rows = list(cur.execute("select start, end from kernels order by start"))
+    if not rows:
+        return
+    # skip the start-up part (weight upload / first-step allocation): keep the last 60 % of the dispatches
+    rows = rows[int(len(rows) * 0.4):]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    busy, cs, ce = 0, rows[0][0], rows[0][1]
+    for a, b in rows[1:]:
+        if a > ce:
+            busy += ce - cs
+            cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    busy += ce - cs
+    total = sum(b - a for a, b in rows)
+    print(f"\n# timeline over the last 60% of dispatches: wall {1e-6 * (t1 - t0):.2f} ms, some kernel running "
+          f"{100.0 * busy / (t1 - t0):.1f}% of it, sum of kernel durations / wall = {total / (t1 - t0):.2f} "
+          f"(average kernels in flight)")
 
 
 if __name__ == "__main__":
