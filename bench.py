@@ -104,7 +104,8 @@ def main():
 
     def run(k):
         """k steps = k independent scene inferences, up to --lanes of them in flight (DefaultSegmentorV2.inference_many)."""
-        return model.inference_many([dict(inp) for _ in range(k)], lanes=args.lanes)[-1]["seg_logits"]
+        return model.inference_many([dict(inp) for _ in range(k)], lanes=args.lanes,
+                                    threads=os.environ.get("CDSEG_LANE_THREADS", "0") != "0")[-1]["seg_logits"]
 
     if args.warmup:
         out = run(args.warmup)

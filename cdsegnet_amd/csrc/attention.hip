@@ -22,6 +22,7 @@
 //  * f32 (the 1e-3 parity mode): v_mfma_f32_16x16x4_f32 for both products, exact fp32.
 // LDS layouts are bank-conflict free for every fragment read (tools/lds_conflicts.py).
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -30,6 +31,7 @@ namespace {
 
 // optional HIP-event timing of every attention launch on its own stream (bench.py's roofline leg)
 bool g_prof_on = false;
+std::mutex g_prof_mu;  // launches may come from several host threads (one per lane)
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 
 struct AttnP {
@@ -427,6 +429,7 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
     hipLaunchKernelGGL(attn_f32_kernel, grid, block, SMEM_F32, s, p);
   if (g_prof_on) {
     (void)hipEventRecord(e1, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_events.emplace_back(e0, e1);
   }
   CDSEG_CHECK_LAUNCH();
@@ -435,6 +438,7 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
 
 // enable / disable event timing of the attention launches (drops earlier records)
 extern "C" int cdseg_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& ev : g_prof_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -446,6 +450,7 @@ extern "C" int cdseg_prof_enable(int on) {
 
 // after a device synchronisation: total milliseconds and number of attention launches recorded
 extern "C" int cdseg_prof_summary(double* total_ms, long* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   double t = 0.0;
   for (auto& ev : g_prof_events) {
     float ms = 0.f;

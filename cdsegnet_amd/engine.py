@@ -20,6 +20,7 @@ Host<->device syncs: offset + grid max (depth), pooled point counts (one copy fo
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -34,6 +35,13 @@ def _pooling_depth(stride):
     return (math.ceil(stride) - 1).bit_length()
 
 
+class _ShareEvents(threading.local):
+    on = False  # set by the engine while a scene uses its side stream (per host thread)
+
+
+SHARE_EVENTS = _ShareEvents()
+
+
 def _shared(cache, key, build):
     """Lazily built plan item shared by the two branch streams: the builder's stream records an event, a consumer
     on the other stream waits for it (the item itself lives as long as the plan)."""
@@ -41,7 +49,7 @@ def _shared(cache, key, build):
     cur = ops.current_stream_id()
     if ent is None:
         val = build()
-        ent = cache[key] = (val, cur, ops.record_event() if cur is not None else None)
+        ent = cache[key] = (val, cur, ops.record_event() if (cur is not None and SHARE_EVENTS.on) else None)
     elif ent[1] != cur and ent[2] is not None:
         ops.wait_event(ent[2])
     return ent[0]
@@ -147,6 +155,8 @@ class Engine:
         env = os.environ.get("CDSEG_FORK_STAGE")
         if env is not None:
             self.fork_stage = None if env.lower() in ("none", "-1", "") else int(env)
+        self._work_lock = threading.Lock()
+        self._tls = threading.local()  # per host thread: device-RNG cursor
         self.attn_work = 0.0  # algorithmic attention FLOPs issued so far (4 * 16 * H * sum_p L_p^2 per launch)
 
     # ------------------------------------------------------------------ weights
@@ -454,7 +464,7 @@ class Engine:
             att = mod.attn
             gidx, widx = lv.slots(st.curves[att.order_index], att.patch_size, att.enable_flash)
             _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
-            self.attn_work += 64.0 * att.num_heads * sum_l2
+            self._add_work(64.0 * att.num_heads * sum_l2)
             desc = self.block_desc[pre]
             xc_out = st.x if self.T == torch.float32 else self._buf(n, c, self.T)
             ops.block_forward(desc, n, st.x, st.xc, xc_out, tbias, lv.nbr(3, True), gidx, widx, patch_start,
@@ -468,7 +478,7 @@ class Engine:
         curve = st.curves[att.order_index]
         gidx, widx = lv.slots(curve, att.patch_size, att.enable_flash)
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
-        self.attn_work += 64.0 * att.num_heads * sum_l2
+        self._add_work(64.0 * att.num_heads * sum_l2)
         o = self._buf(n, c, self.T)
         ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
                       att.scale, o, work=64.0 * att.num_heads * sum_l2)
@@ -571,7 +581,7 @@ class Engine:
         q_gidx, widx = lv.slots(nst.curves[att.order_index], K, att.enable_flash)
         kv_gidx, _ = lv.slots(cst.curves[att.order_index], K, att.enable_flash)
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(K, att.enable_flash)
-        self.attn_work += 64.0 * att.num_heads * sum_l2
+        self._add_work(64.0 * att.num_heads * sum_l2)
         o = self._buf(n, cq, self.T)
         ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o,
                       work=64.0 * att.num_heads * sum_l2)
@@ -597,10 +607,34 @@ class Engine:
             d["perms"] = [torch.randperm(no).tolist() for _ in range(n_perms)]
         return d
 
+    def predraw(self, input_dict, noise_level=None):
+        """The random draws of one single-step inference, taken NOW from torch's CPU generator (and the device-RNG
+        stream ids reserved now): lets inference_many issue scenes from several threads while the draws stay in
+        scene order."""
+        m, bb = self.model, self.model.backbone
+        feat = input_dict["feat"]
+        per_call = (2 + len(bb.c_stride) + len(bb.n_stride)) if bb.condition else (1 + len(bb.n_stride))
+        d = self.draw(feat.shape[0], tuple(feat.shape), m.c_in_channels, noise_level, per_call)
+        d["rng_base"] = self.reserve_rng()
+        return d
+
+    def _add_work(self, flops):
+        with self._work_lock:
+            self.attn_work += flops
+
+    RNG_RESERVE = 8  # device-RNG streams one single-step inference may consume
+
+    def reserve_rng(self, k=None):
+        """Reserve a block of device-RNG stream ids (call in scene order from ONE thread: keeps the device noise
+        of scene i independent of which lane / thread runs it)."""
+        base = self.rng_offset
+        self.rng_offset += self.RNG_RESERVE if k is None else int(k)
+        return base
+
     def _device_randn(self, shape):
         seed = torch.initial_seed()
-        out = ops.randn(shape, seed, self.rng_offset, self.device)
-        self.rng_offset += 1
+        out = ops.randn(shape, seed, self._tls.rng, self.device)
+        self._tls.rng += 1
         return out
 
     # ------------------------------------------------------------------ forward
@@ -638,6 +672,8 @@ class Engine:
         per_call = (2 + len(bb.c_stride) + len(bb.n_stride)) if cond else (1 + len(bb.n_stride))
         if draws is None:
             draws = self.draw(n, tuple(feat.shape), c_ch, noise_level, per_call * n_backbone_calls, always_noise)
+        self._tls.rng = (draws["rng_base"] if "rng_base" in draws
+                         else self.reserve_rng(max(self.RNG_RESERVE, 2 + n_backbone_calls)))
         feat = feat.float().contiguous()
         if noise_level is not None:  # ref: default.py:373-374 (perturbs feat and rebinds it in input_dict)
             fn = draws.get("feat_noise")
@@ -773,6 +809,7 @@ class Engine:
                 return enc_stage(st, "c", 2, c_cum, p_c2)
 
             fork = self.fork_stage if (dev.type == "cuda" and self.fork_stage is not None) else None
+            SHARE_EVENTS.on = fork is not None
             cst = c_branch() if fork is None else None
             nst = self.run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
             join = None

@@ -5,6 +5,7 @@ marshalling layer: PyTorch provides device memory and the stream, every computat
 the hand-written HIP kernels of libcdseg_hip.so.  No fallbacks: tensors must live on a GPU.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -15,7 +16,6 @@ __all__ = ["ACT_NONE", "ACT_GELU", "ACT_SWISH", "F32", "BF16"]
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _WS = {}
-_GEMM_CACHE = {}
 
 
 class _LazyLib:
@@ -85,44 +85,54 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-_STREAM = None
-_STREAM_OBJ = None
+class _ThreadState(threading.local):
+    """Per host thread: the bound stream, the GEMM argument-block cache and the Block I/O struct (inference_many
+    issues each lane from its own thread; ctypes structs are filled in place, so they cannot be shared)."""
+
+    def __init__(self):
+        self.stream = None      # ctypes.c_void_p of the bound HIP stream
+        self.stream_obj = None  # the torch stream object
+        self.gemm_cache = {}
+        self.block_io = None
+
+
+_TLS = _ThreadState()
 
 
 def bind_stream(stream=None):
-    """Cache the HIP stream every op launches on (torch.cuda.current_stream() costs ~8 us per query, and an
-    inference issues ~500 launches).  The engine binds the current torch stream once per inference call and
+    """Cache the HIP stream every op of THIS THREAD launches on (torch.cuda.current_stream() costs ~8 us per query,
+    and an inference issues ~500 launches).  The engine binds the current torch stream once per inference call and
     re-binds when it switches to its side stream."""
-    global _STREAM, _STREAM_OBJ
     if stream is None:
         stream = torch.cuda.current_stream()
-    _STREAM_OBJ = stream
-    _STREAM = ctypes.c_void_p(stream.cuda_stream)
-    return _STREAM
+    _TLS.stream_obj = stream
+    _TLS.stream = ctypes.c_void_p(stream.cuda_stream)
+    return _TLS.stream
 
 
 def unbind_stream():
-    global _STREAM, _STREAM_OBJ
-    _STREAM = _STREAM_OBJ = None
+    _TLS.stream = _TLS.stream_obj = None
 
 
 def current_stream_id():
     """Identity of the bound stream (None when nothing is bound)."""
-    return _STREAM.value if _STREAM is not None else None
+    st = _TLS.stream
+    return st.value if st is not None else None
 
 
 def record_event():
     ev = torch.cuda.Event()
-    ev.record(_STREAM_OBJ if _STREAM_OBJ is not None else torch.cuda.current_stream())
+    ev.record(_TLS.stream_obj if _TLS.stream_obj is not None else torch.cuda.current_stream())
     return ev
 
 
 def wait_event(ev):
-    (_STREAM_OBJ if _STREAM_OBJ is not None else torch.cuda.current_stream()).wait_event(ev)
+    (_TLS.stream_obj if _TLS.stream_obj is not None else torch.cuda.current_stream()).wait_event(ev)
 
 
 def _stream():
-    return _STREAM if _STREAM is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = _TLS.stream
+    return st if st is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _need_gpu(*ts):
@@ -137,7 +147,7 @@ def dt(t):
 
 def workspace(nbytes, device):
     """Per-device scratch buffer (grown geometrically, never shrunk)."""
-    key = (device.type, device.index, _STREAM.value if _STREAM is not None else None)  # one buffer per stream
+    key = (device.type, device.index, current_stream_id())  # one buffer per stream
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -323,7 +333,8 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
         _need_gpu(A, W, out)
     # the weight-side half of the argument block is static per layer: cache it keyed by the weight tensor
     key = (W.data_ptr(), _dp(bias), _dp(scale), _dp(shift), int(kvol), int(act))
-    ent = _GEMM_CACHE.get(key)
+    cache = _TLS.gemm_cache
+    ent = cache.get(key)
     if ent is None:
         for t in (bias, scale, shift):
             if t is not None and t.dtype != torch.float32:
@@ -336,9 +347,9 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
         a.compute_dtype = dt(W)
         a.act = int(act)
         ent = (a, ctypes.byref(a), W)  # keep W alive with the cache entry
-        if len(_GEMM_CACHE) > 4096:
-            _GEMM_CACHE.clear()
-        _GEMM_CACHE[key] = ent
+        if len(cache) > 4096:
+            cache.clear()
+        cache[key] = ent
     a = ent[0]
     if (res is not None and res.dtype != torch.float32) or (add_src is not None and add_src.dtype != torch.float32):
         raise _lib.CdsegError("gemm residuals are float32")
@@ -402,16 +413,12 @@ def block_scratch_bytes(desc, n):
     return _lib.load().cdseg_block_scratch_bytes(desc[1], int(n))
 
 
-_BLOCK_IO = None
-
-
 def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start, num_patches, max_len, scratch):
     """One PTv3 Block on the native executor (all launches issued by the library, one host call)."""
-    global _BLOCK_IO
-    if _BLOCK_IO is None:
+    if _TLS.block_io is None:
         io = _lib.BlockIO()
-        _BLOCK_IO = (io, ctypes.byref(io))
-    io, ref = _BLOCK_IO
+        _TLS.block_io = (io, ctypes.byref(io))
+    io, ref = _TLS.block_io
     io.n = int(n)
     io.x, io.xc_in, io.xc_out, io.tbias = x.data_ptr(), xc_in.data_ptr(), xc_out.data_ptr(), _dp(tbias)
     io.nbr, io.gidx, io.widx, io.patch_start = nbr.data_ptr(), gidx.data_ptr(), widx.data_ptr(), patch_start.data_ptr()

@@ -309,12 +309,24 @@ def test_inference_many_equals_scene_by_scene(precision):
     dicts = [{k: torch.as_tensor(sc[k]).cuda() for k in ("coord", "grid_coord", "feat", "offset")} for sc in scenes]
     torch.manual_seed(123)
     ref = [model.inference(dict(d), eval=False)["seg_logits"].clone() for d in dicts]
-    for lanes in (2, 3):
+    for lanes, threads in ((2, True), (3, True), (3, False)):
         torch.manual_seed(123)
-        outs = model.inference_many([dict(d) for d in dicts], lanes=lanes)
+        outs = model.inference_many([dict(d) for d in dicts], lanes=lanes, threads=threads)
         torch.cuda.synchronize()
         for a, b in zip(outs, ref):
-            assert torch.equal(a["seg_logits"], b)
+            assert torch.equal(a["seg_logits"], b), (lanes, threads)
+    # device-drawn noise: the stream ids are reserved in scene order, so the lanes do not change the result either
+    model.noise_source = "device"
+    torch.manual_seed(5)
+    model.engine().rng_offset = 0
+    a = [o["seg_logits"].clone() for o in model.inference_many([dict(d) for d in dicts], lanes=1)]
+    torch.manual_seed(5)
+    model.engine().rng_offset = 0
+    b = model.inference_many([dict(d) for d in dicts], lanes=3, threads=True)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y["seg_logits"])
+    model.noise_source = "torch_cpu"
     # the intra-scene fork (noise-branch encoder on a side stream) is result-neutral too
     eng = model.engine()
     keep = eng.fork_stage
