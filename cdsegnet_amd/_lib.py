@@ -86,6 +86,10 @@ SIGNATURES = {
     "cdseg_fragment_select": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "cdseg_softmax_vote": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
     "cdseg_argmax_rows": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
+    "cdseg_knn1_ws_bytes": (c_size_t, [c_long]),
+    "cdseg_knn1": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, POINTER(c_float), c_float,
+                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cdseg_iou_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),

@@ -106,6 +106,123 @@ __global__ void argmax_rows_kernel(const float* __restrict__ x, int ldx, long n,
   if (lane == 0) out[row] = bi;
 }
 
+// ---- evaluator: exact 1-nearest-neighbour label transfer + IoU counters
+// ref: engines/hooks/evaluator.py:132-140 -> pointops.knn_query(1, ...), a brute-force O(m n) scan per query
+// (libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104: strict '<', ascending index => lowest index on ties).
+// Here: uniform grid over the reference points (cell keys sorted with the library's radix sort), every query walks
+// the cube shells around its own cell and stops as soon as no unvisited cell can hold a closer (or equal, lower-index)
+// point; exact, with a brute-force fallback for queries far from every reference point.
+struct KnnP {
+  const float* ref;          // (n,3)
+  const float* qry;          // (m,3)
+  const int32_t* ref_off;    // (B) cumulative ends
+  const int32_t* qry_off;    // (B)
+  const int64_t* key_sorted; // (n) sorted cell keys
+  const int32_t* perm;       // (n) sorted position -> reference point
+  float ox, oy, oz, cell;    // grid origin (<= every reference coordinate) and cell size
+  int nb, gmax;              // batches; cells per axis - 1 (keys are clamped to [0, gmax])
+  long n, m;
+};
+
+__device__ __forceinline__ int batch_of(const int32_t* off, int nb, long i) {
+  int lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] > i) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ int64_t cell_key(int b, int cx, int cy, int cz) {
+  return ((int64_t)b << 60) | ((int64_t)cx << 40) | ((int64_t)cy << 20) | (int64_t)cz;
+}
+
+__global__ void knn_cell_key_kernel(KnnP p, int64_t* __restrict__ key) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  const int b = batch_of(p.ref_off, p.nb, i);
+  const int cx = min(p.gmax, max(0, (int)floorf((p.ref[3 * i] - p.ox) / p.cell)));
+  const int cy = min(p.gmax, max(0, (int)floorf((p.ref[3 * i + 1] - p.oy) / p.cell)));
+  const int cz = min(p.gmax, max(0, (int)floorf((p.ref[3 * i + 2] - p.oz) / p.cell)));
+  key[i] = cell_key(b, cx, cy, cz);
+}
+
+__device__ __forceinline__ void knn_consider(const KnnP& p, int j, float qx, float qy, float qz, float& best,
+                                             int& best_i) {
+  const float dx = qx - p.ref[3 * j], dy = qy - p.ref[3 * j + 1], dz = qz - p.ref[3 * j + 2];
+  const float d2 = dx * dx + dy * dy + dz * dz;
+  if (d2 < best || (d2 == best && j < best_i)) { best = d2; best_i = j; }
+}
+
+__global__ void knn1_kernel(KnnP p, int max_shell, int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= p.m) return;
+  const int b = batch_of(p.qry_off, p.nb, q);
+  const int rs = b ? p.ref_off[b - 1] : 0, re = p.ref_off[b];
+  const float qx = p.qry[3 * q], qy = p.qry[3 * q + 1], qz = p.qry[3 * q + 2];
+  float best = 1e10f;  // the reference's initial distance
+  int best_i = -1;
+  if (re > rs) {
+    // the query's own cell (unclamped: a query may lie outside the reference bounding box)
+    const float fx = (qx - p.ox) / p.cell, fy = (qy - p.oy) / p.cell, fz = (qz - p.oz) / p.cell;
+    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    // distance from the query to the nearest face of its own cell: every point outside the searched cube of
+    // radius r cells is farther than r * cell + edge
+    float edge = fminf(fminf(fx - cx, cx + 1 - fx), fminf(fminf(fy - cy, cy + 1 - fy), fminf(fz - cz, cz + 1 - fz)));
+    edge = fmaxf(edge, 0.f) * p.cell * 0.999f;  // slack for the rounding of the divisions above
+    bool done = false;
+    for (int r = 0; r <= max_shell && !done; ++r) {
+      for (int dx = -r; dx <= r; ++dx) {
+        const int x = cx + dx;
+        if (x < 0 || x > p.gmax) continue;
+        for (int dy = -r; dy <= r; ++dy) {
+          const int y = cy + dy;
+          if (y < 0 || y > p.gmax) continue;
+          const bool face = dx == -r || dx == r || dy == -r || dy == r;
+          // inside the (dx, dy) column only the two end caps belong to shell r, a face column belongs to it whole
+          const int zstep = face ? 1 : (r == 0 ? 1 : 2 * r);
+          for (int dz = -r; dz <= r; dz += zstep) {
+            const int z = cz + dz;
+            if (z < 0 || z > p.gmax) continue;
+            const int64_t key = cell_key(b, x, y, z);
+            long lo = rs, hi = re;  // keys of batch b occupy [rs, re) of the sorted array (batch is the top field)
+            while (lo < hi) {
+              const long mid = (lo + hi) >> 1;
+              if (p.key_sorted[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            for (; lo < re && p.key_sorted[lo] == key; ++lo) knn_consider(p, p.perm[lo], qx, qy, qz, best, best_i);
+          }
+        }
+      }
+      const float lb = r * p.cell * 0.99999f + edge;
+      done = best_i >= 0 && best < lb * lb;  // strict: an equal-distance, lower-index point may still be outside
+    }
+    if (!done) {  // far from every reference point: the reference's brute-force scan
+      best = 1e10f;
+      best_i = -1;
+      for (int j = rs; j < re; ++j) knn_consider(p, j, qx, qy, qz, best, best_i);
+    }
+  }
+  idx_out[q] = best_i;
+  if (d2_out) d2_out[q] = best;
+}
+
+// per-class intersection / prediction / target counts; ignore_index rows are dropped.  ref: utils/misc.py:52-65
+__global__ void iou_counts_kernel(const int32_t* __restrict__ pred, const int32_t* __restrict__ pred_idx,
+                                  const int32_t* __restrict__ target, long n, int k, int ignore,
+                                  unsigned long long* __restrict__ out /* (3,k): inter, pred, target */) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = target[i];
+  if (t == ignore) return;
+  const int pr = pred_idx ? pred[pred_idx[i]] : pred[i];
+  if (pr >= 0 && pr < k) atomicAdd(&out[k + pr], 1ull);
+  if (t >= 0 && t < k) {
+    atomicAdd(&out[2 * k + t], 1ull);
+    if (pr == t) atomicAdd(&out[t], 1ull);
+  }
+}
+
 inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 }  // namespace
@@ -154,6 +271,54 @@ int cdseg_softmax_vote(const float* logits, int ldl, const int32_t* idx, long m,
   if (m <= 0 || c <= 0) return CDSEG_OK;
   hipLaunchKernelGGL(softmax_vote_kernel, g1(m * 64), dim3(256), 0, (hipStream_t)stream, logits, ldl, idx, m, c, pred,
                      ldp);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// Exact 1-NN of every query among the reference points of the same batch element.
+// origin (3 floats, host): <= every reference coordinate; cell: grid cell size (a few voxel sizes).
+// ws: >= cdseg_knn1_ws_bytes(n).  idx (m) int32 (-1 for an empty batch element), dist2 (m) float or NULL.
+size_t cdseg_knn1_ws_bytes(long n) {
+  return cdseg_sort_ws_bytes(n) + 2 * (((size_t)n * 8 + 255) & ~(size_t)255) + (((size_t)n * 4 + 255) & ~(size_t)255);
+}
+
+int cdseg_knn1(const float* ref_xyz, const int32_t* ref_offset, long n, const float* qry_xyz, const int32_t* qry_offset,
+               long m, int nb, const float* origin, float cell, int32_t* idx, float* dist2, void* ws, size_t ws_bytes,
+               void* stream) {
+  if (m <= 0) return CDSEG_OK;
+  if (nb <= 0 || nb > 8 || !(cell > 0) || !origin) return CDSEG_ERR_ARG;
+  if (ws_bytes < cdseg_knn1_ws_bytes(n)) return CDSEG_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  KnnP p;
+  p.ref = ref_xyz; p.qry = qry_xyz; p.ref_off = ref_offset; p.qry_off = qry_offset;
+  p.ox = origin[0]; p.oy = origin[1]; p.oz = origin[2]; p.cell = cell; p.nb = nb; p.gmax = (1 << 20) - 1;
+  p.n = n; p.m = m;
+  char* w = (char*)ws;
+  const size_t a8 = (((size_t)n * 8) + 255) & ~(size_t)255, a4 = (((size_t)n * 4) + 255) & ~(size_t)255;
+  int64_t* key = (int64_t*)w;
+  int64_t* key_sorted = (int64_t*)(w + a8);
+  int32_t* perm = (int32_t*)(w + 2 * a8);
+  if (n > 0) {
+    hipLaunchKernelGGL(knn_cell_key_kernel, g1(n), dim3(256), 0, s, p, key);
+    const int rc = cdseg_sort_pairs(key, key_sorted, nullptr, perm, n, 63, w + 2 * a8 + a4, ws_bytes - 2 * a8 - a4, stream);
+    if (rc != CDSEG_OK) return rc;
+  }
+  p.key_sorted = key_sorted; p.perm = perm;
+  hipLaunchKernelGGL(knn1_kernel, g1(m), dim3(256), 0, s, p, 6, idx, dist2);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// out (3,k) int64 zeroed here: intersection, prediction and target counts (union = pred + target - intersection).
+// pred_idx (n) or NULL: the prediction of row i is pred[pred_idx[i]] (the 1-NN label transfer).
+int cdseg_iou_counts(const int32_t* pred, const int32_t* pred_idx, const int32_t* target, long n, int k, int ignore_index,
+                     int64_t* out, void* stream) {
+  if (k <= 0) return CDSEG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, (size_t)3 * k * sizeof(int64_t), s) != hipSuccess) return CDSEG_ERR_LAUNCH;
+  if (n <= 0) return CDSEG_OK;
+  hipLaunchKernelGGL(iou_counts_kernel, g1(n), dim3(256), 0, s, pred, pred_idx, target, n, k, ignore_index,
+                     (unsigned long long*)out);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

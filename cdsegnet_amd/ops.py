@@ -561,6 +561,29 @@ def argmax_rows(x):
     return out
 
 
+def knn1(ref_xyz, ref_offset, qry_xyz, qry_offset, origin, cell, want_dist=False):
+    """Exact nearest reference point (same batch element) of every query.  offsets: int32 cumulative ends."""
+    lib = _lib.load()
+    _need_gpu(ref_xyz, qry_xyz)
+    ref_xyz, qry_xyz = ref_xyz.float().contiguous(), qry_xyz.float().contiguous()
+    n, m = ref_xyz.shape[0], qry_xyz.shape[0]
+    idx = torch.empty(m, dtype=torch.int32, device=qry_xyz.device)
+    d2 = torch.empty(m, dtype=torch.float32, device=qry_xyz.device) if want_dist else None
+    ws = workspace(lib.cdseg_knn1_ws_bytes(n), qry_xyz.device)
+    org = (ctypes.c_float * 3)(*[float(v) for v in origin])
+    check(lib.cdseg_knn1(_ptr(ref_xyz), _ptr(ref_offset), n, _ptr(qry_xyz), _ptr(qry_offset), m, ref_offset.numel(), org,
+                         float(cell), _ptr(idx), _ptr(d2), _ptr(ws), ws.numel(), _stream()), "knn1")
+    return (idx, d2) if want_dist else idx
+
+
+def iou_counts(pred, target, num_classes, ignore_index=-1, pred_idx=None):
+    """(3, K) int64: intersection, prediction and target counts (rows with target == ignore_index dropped)."""
+    out = torch.empty((3, num_classes), dtype=torch.int64, device=pred.device)
+    check(_lib.load().cdseg_iou_counts(_ptr(pred), _ptr(pred_idx), _ptr(target), target.numel(), int(num_classes),
+                                        int(ignore_index), _ptr(out), _stream()), "iou_counts")
+    return out
+
+
 # ------------------------------------------------------------------ reference-shaped composites
 def serialization(grid_coord, batch, orders=("z", "z-trans", "hilbert", "hilbert-trans"), depth=None):
     """Point.serialization before the shuffle (structure.py:47-93): code, order, inverse as (k, N) int64

@@ -34,25 +34,37 @@ def fragment(gs, i):
 
 
 @torch.no_grad()
-def segment_scene(model, coord, feat, grid_size, num_classes, noise_level=None, max_fragments=None):
+def segment_scene(model, coord, feat, grid_size, num_classes, noise_level=None, max_fragments=None, lanes=3):
     """Fragmented inference + softmax voting of one raw scene (engines/test.py:181-279, bs = 1, no TTA).
-    coord (N,3) f32, feat (N,C) f32 on the GPU.  Returns (labels int32 (N,), pred (N, num_classes) f32)."""
+    coord (N,3) f32, feat (N,C) f32 on the GPU.  Returns (labels int32 (N,), pred (N, num_classes) f32).
+    The fragments are independent scenes for the model, so they go through ``inference_many`` (up to ``lanes`` in
+    flight); the votes are accumulated afterwards in fragment order, exactly like the reference's loop."""
     ops.bind_stream()
-    gs = grid_sample_test(coord, grid_size)
-    n = gs["n"]
-    pred = torch.zeros((n, num_classes), dtype=torch.float32, device=coord.device)
-    nfrag = gs["num_fragments"] if max_fragments is None else min(gs["num_fragments"], max_fragments)
-    for i in range(nfrag):
-        ops.bind_stream()
-        idx = fragment(gs, i)
-        m = idx.numel()
-        inp = dict(coord=ops.gather_rows(coord.float().contiguous(), idx),
-                   grid_coord=ops.gather_rows(gs["grid_coord"], idx),
-                   feat=ops.gather_rows(feat.float().contiguous(), idx),
-                   offset=torch.tensor([m], dtype=torch.int64, device=coord.device), offset_host=[m])
-        logits = model.inference(inp, eval=False, noise_level=noise_level)["seg_logits"]
-        ops.bind_stream()
-        ops.softmax_vote(logits, idx, pred)
-    labels = ops.argmax_rows(pred)
-    ops.unbind_stream()
+    try:
+        gs = grid_sample_test(coord, grid_size)
+        n = gs["n"]
+        pred = torch.zeros((n, num_classes), dtype=torch.float32, device=coord.device)
+        nfrag = gs["num_fragments"] if max_fragments is None else min(gs["num_fragments"], max_fragments)
+        coord_f, feat_f = coord.float().contiguous(), feat.float().contiguous()
+        idxs, dicts = [], []
+        for i in range(nfrag):
+            idx = fragment(gs, i)
+            m = idx.numel()
+            idxs.append(idx)
+            dicts.append(dict(coord=ops.gather_rows(coord_f, idx), grid_coord=ops.gather_rows(gs["grid_coord"], idx),
+                              feat=ops.gather_rows(feat_f, idx),
+                              offset=torch.tensor([m], dtype=torch.int64, device=coord.device), offset_host=[m]))
+    finally:
+        ops.unbind_stream()
+    if hasattr(model, "inference_many"):
+        outs = model.inference_many(dicts, lanes=lanes, noise_level=noise_level)
+    else:
+        outs = [model.inference(d, eval=False, noise_level=noise_level) for d in dicts]
+    ops.bind_stream()
+    try:
+        for idx, o in zip(idxs, outs):
+            ops.softmax_vote(o["seg_logits"], idx, pred)
+        labels = ops.argmax_rows(pred)
+    finally:
+        ops.unbind_stream()
     return labels, pred

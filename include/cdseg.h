@@ -235,6 +235,21 @@ int cdseg_softmax_vote(const float* logits, int ldl, const int32_t* idx, long m,
 /* out[i] = first arg-max of row i.  ref: engines/test.py:278 */
 int cdseg_argmax_rows(const float* x, int ldx, long n, int c, int32_t* out, void* stream);
 
+/* ------------------------------------------------------------------ evaluator
+ * ref: engines/hooks/evaluator.py:132-140 (pointops.knn_query(1, ...) label transfer), utils/misc.py:52-65 (IoU counts).
+ * Exact 1-NN of every query among the reference points of the same batch element (lowest index on ties, like the
+ * reference's brute-force scan, libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104), found through a uniform
+ * grid: origin (3 host floats) <= every reference coordinate, cell = grid cell size.  offsets: cumulative ends (nb).
+ * idx (m) int32, dist2 (m) float or NULL. */
+size_t cdseg_knn1_ws_bytes(long n);
+int cdseg_knn1(const float* ref_xyz, const int32_t* ref_offset, long n, const float* qry_xyz, const int32_t* qry_offset,
+               long m, int nb, const float* origin, float cell, int32_t* idx, float* dist2, void* ws, size_t ws_bytes,
+               void* stream);
+/* out (3,k) int64: per-class intersection, prediction and target counts over rows with target != ignore_index;
+ * pred_idx (n) or NULL: row i is predicted pred[pred_idx[i]]. */
+int cdseg_iou_counts(const int32_t* pred, const int32_t* pred_idx, const int32_t* target, long n, int k, int ignore_index,
+                     int64_t* out, void* stream);
+
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
  * block itself (sparse-conv CPE, Linear+LayerNorms, QKV, window attention, proj, MLP), carving its

@@ -329,6 +329,25 @@ def gen_gridsample(ref):
         print("gridsample", tag, idx.shape)
 
 
+def gen_iou(ref):
+    """intersection_and_union of the reference (utils/misc.py:38-50) on random label arrays with ignored rows."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_misc", os.path.join(REF, "pointcept/utils/misc.py"))
+    M = importlib.util.module_from_spec(spec)
+    sys.modules["_ref_misc"] = M
+    spec.loader.exec_module(M)
+    rng = np.random.default_rng(3)
+    fx = {}
+    for tag, n, k in (("a", 5000, 20), ("b", 777, 13), ("c", 10000, 200)):
+        target = rng.integers(-1, k, size=n).astype(np.int64)  # -1 = ignore_index
+        pred = np.where(rng.random(n) < 0.6, np.maximum(target, 0), rng.integers(0, k, size=n)).astype(np.int64)
+        i, u, t = M.intersection_and_union(pred, target, k, -1)
+        fx.update({f"{tag}_pred": pred, f"{tag}_target": target, f"{tag}_k": np.int64(k), f"{tag}_inter": i,
+                   f"{tag}_union": u, f"{tag}_tgt": t})
+    np.savez_compressed(os.path.join(OUT, "iou_counts.npz"), **fx)
+    print("iou fixture", {k: v.shape for k, v in fx.items() if k.endswith("inter")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -344,3 +363,5 @@ if __name__ == "__main__":
         gen_ptv3(ref)
     if "gs" in which:
         gen_gridsample(ref)
+    if "iou" in which:
+        gen_iou(ref)

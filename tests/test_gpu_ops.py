@@ -591,3 +591,73 @@ def test_coarse_orders_equal_sorted_orders(ops, name):
     for lvl in range(len(clusters)):
         for c in range(3):
             assert torch.equal(derived[lvl][c], sorted_orders[lvl][c]), (name, lvl, c)
+
+
+# ---------------------------------------------------------------- evaluator kernels (testtime.hip)
+def _knn_case(ops, ref, roff, qry, qoff, cell):
+    from oracle import testtime as OT
+    want, wd2 = OT.knn1_bruteforce(ref, roff, qry, qoff)
+    idx, d2 = ops.knn1(dev(ref), dev(np.asarray(roff, dtype=np.int32)), dev(qry), dev(np.asarray(qoff, dtype=np.int32)),
+                       ref.min(0).tolist(), cell, want_dist=True)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    bad = idx != want
+    # any disagreement must be an exact-distance tie broken differently by fp32 contraction, never a farther point
+    assert np.all(np.abs(d2[bad] - wd2[bad]) <= 1e-6 * (1 + wd2[bad])), (bad.sum(), d2[bad][:4], wd2[bad][:4])
+    assert bad.mean() < 1e-3
+    return idx
+
+
+def test_knn1_vs_bruteforce_oracle(ops):
+    rng = np.random.default_rng(1)
+    # voxelised scene + its raw points (the evaluator's use): two batch elements
+    raw = (rng.random((30000, 3)) * np.array([4.0, 3.0, 0.3])).astype(np.float32)
+    keep = rng.random(30000) < 0.35
+    ref = raw[keep]
+    nr0 = int(keep[:14000].sum())
+    _knn_case(ops, ref, [nr0, len(ref)], raw, [14000, 30000], 0.05)
+    # queries far outside the reference box (shell limit -> brute-force fallback), tiny and huge cells
+    far = np.concatenate([raw[:500], raw[:200] + np.float32(50.0), raw[:100] - np.float32(3.0)])
+    _knn_case(ops, ref[:nr0], [nr0], far, [len(far)], 0.05)
+    _knn_case(ops, ref[:nr0], [nr0], far[:600], [600], 0.004)
+    _knn_case(ops, ref[:nr0], [nr0], far[:600], [600], 5.0)
+    # integer lattice: exact ties -> lowest index wins, bit-exact
+    lat = rng.integers(0, 12, size=(4000, 3)).astype(np.float32)
+    q = rng.integers(0, 12, size=(3000, 3)).astype(np.float32) + np.float32(0.5)
+    from oracle import testtime as OT
+    want, _ = OT.knn1_bruteforce(lat, [4000], q, [3000])
+    got = ops.knn1(dev(lat), dev(np.array([4000], dtype=np.int32)), dev(q), dev(np.array([3000], dtype=np.int32)),
+                   [0.0, 0.0, 0.0], 1.0).cpu().numpy()
+    assert np.array_equal(got, want)
+    # an empty batch element
+    got = ops.knn1(dev(lat), dev(np.array([0, 4000], dtype=np.int32)), dev(q), dev(np.array([10, 3000], dtype=np.int32)),
+                   [0.0, 0.0, 0.0], 1.0).cpu().numpy()
+    assert np.all(got[:10] == -1) and np.all(got[10:] >= 0)
+
+
+def test_iou_counts_vs_reference_fixture(ops):
+    fx = load_fixture("iou_counts.npz")
+    for tag in ("a", "b", "c"):
+        k = int(fx[f"{tag}_k"])
+        out = ops.iou_counts(dev(fx[f"{tag}_pred"].astype(np.int32)), dev(fx[f"{tag}_target"].astype(np.int32)), k, -1)
+        out = out.cpu().numpy()
+        assert np.array_equal(out[0], fx[f"{tag}_inter"])
+        assert np.array_equal(out[1] + out[2] - out[0], fx[f"{tag}_union"])
+        assert np.array_equal(out[2], fx[f"{tag}_tgt"])
+
+
+def test_evaluate_scene_vs_oracle(ops):
+    from cdsegnet_amd import evaluate
+    from oracle import testtime as OT
+    rng = np.random.default_rng(5)
+    raw = (rng.random((20000, 3)) * np.array([3.0, 2.0, 0.2])).astype(np.float32)
+    keep = rng.random(20000) < 0.4
+    coord = raw[keep]
+    k = 13
+    logits = rng.normal(size=(len(coord), k)).astype(np.float32)
+    seg = rng.integers(-1, k, size=len(raw))
+    d = dict(coord=dev(coord), offset=dev(np.array([len(coord)], dtype=np.int64)), origin_coord=dev(raw),
+             origin_offset=dev(np.array([len(raw)], dtype=np.int64)), origin_segment=dev(seg))
+    counts = evaluate.evaluate_scene(dev(logits), d, k, ignore_index=-1, reduce=False).cpu().numpy()
+    idx, _ = OT.knn1_bruteforce(coord, [len(coord)], raw, [len(raw)])
+    i, u, t = OT.intersection_and_union(logits.argmax(1)[idx], seg, k, -1)
+    assert np.array_equal(counts[0], i) and np.array_equal(counts[1], u) and np.array_equal(counts[2], t)

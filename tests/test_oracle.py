@@ -217,3 +217,27 @@ def test_vote_oracle_properties():
         cover[p] += 1
     assert np.allclose(pred.sum(1), cover, atol=1e-5)  # each vote is a probability vector
     assert labels.shape == (n,)
+
+
+# ---------------------------------------------------------------- evaluator
+def test_iou_oracle_vs_reference_fixture():
+    from oracle import testtime as TT
+    fx = load_fixture("iou_counts.npz")
+    for tag in ("a", "b", "c"):
+        i, u, t = TT.intersection_and_union(fx[f"{tag}_pred"], fx[f"{tag}_target"], int(fx[f"{tag}_k"]), -1)
+        assert np.array_equal(i, fx[f"{tag}_inter"]) and np.array_equal(u, fx[f"{tag}_union"])
+        assert np.array_equal(t, fx[f"{tag}_tgt"])
+
+
+def test_knn_oracle_vs_kdtree():
+    from scipy.spatial import cKDTree
+    from oracle import testtime as TT
+    rng = np.random.default_rng(0)
+    ref = rng.random((3000, 3)).astype(np.float32)
+    qry = rng.random((5000, 3)).astype(np.float32)
+    idx, d2 = TT.knn1_bruteforce(ref, [1200, 3000], qry, [2500, 5000])
+    for (rs, re), (qs, qe) in (((0, 1200), (0, 2500)), ((1200, 3000), (2500, 5000))):
+        d, j = cKDTree(ref[rs:re].astype(np.float64)).query(qry[qs:qe].astype(np.float64))
+        same = (j + rs) == idx[qs:qe]
+        assert same.mean() > 0.999  # float32 vs float64 near-ties only
+        assert np.allclose(np.sqrt(d2[qs:qe]), d, atol=1e-5)
