@@ -76,11 +76,17 @@ SIGNATURES = {
     "cdseg_pool_level": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cdseg_pool_gather": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
+    "cdseg_pool_levels_ws_bytes": (c_size_t, [c_long, c_int]),
+    "cdseg_pool_levels": (c_int, [c_void_p, c_long, POINTER(c_int), c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    "cdseg_link_derive": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "cdseg_coarse_orders_ws_bytes": (c_size_t, [c_long, c_int, c_int]),
     "cdseg_coarse_orders": (c_int, [POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_long, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
     "cdseg_nbr_table": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "cdseg_pad_plan_batch": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
+                                     POINTER(c_long), c_int, c_void_p, c_void_p, c_void_p]),
     "cdseg_voxelize": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cdseg_max_run": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
     "cdseg_fragment_select": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),

@@ -188,6 +188,54 @@ __global__ void coarse_compact_kernel(CoarseP p, long total, const int32_t* __re
   if (coarse_head(p, i, &v)) out[pos[i] - 1] = v;
 }
 
+// ---- all pooling levels of a scene in one flag / scan / finish pass (levels back to back in one array)
+struct LevelsP {
+  int shift[8];
+  int nlev, nb;
+  long n;
+};
+
+__global__ void levels_flag_kernel(const int64_t* __restrict__ zc, LevelsP p, int32_t* __restrict__ flag) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.n * p.nlev) return;
+  const int l = (int)(t / p.n);
+  const long i = t - (long)l * p.n;
+  const int sh = p.shift[l];
+  flag[t] = (i == 0 || (zc[i] >> sh) != (zc[i - 1] >> sh)) ? 1 : 0;
+}
+
+// cluster (L,n), seg_start (L,n+1), meta (L, 1+nb): [count, cluster id of the last point of every batch element]
+__global__ void levels_finish_kernel(const int32_t* __restrict__ incl, const int32_t* __restrict__ flag, LevelsP p,
+                                     const int32_t* __restrict__ last_idx, int32_t* __restrict__ cluster,
+                                     int32_t* __restrict__ seg_start, int32_t* __restrict__ meta) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.n * p.nlev) return;
+  const int l = (int)(t / p.n);
+  const long i = t - (long)l * p.n;
+  const int base = l ? incl[(long)l * p.n - 1] : 0;
+  const int c = incl[t] - base - 1;
+  cluster[t] = c;
+  int32_t* seg = seg_start + (long)l * (p.n + 1);
+  if (flag[t]) seg[c] = (int32_t)i;
+  if (i == p.n - 1) {
+    seg[c + 1] = (int32_t)p.n;
+    meta[l * (1 + p.nb)] = c + 1;
+  }
+  for (int b = 0; b < p.nb; ++b)
+    if (last_idx[b] == i) meta[l * (1 + p.nb) + 1 + b] = c;
+}
+
+// link between two pooled levels a (finer) and b from their links to level 0:
+//   cluster_ab[j] = cluster_0b[seg_0a[j]] (j < m_a);  seg_ab[k] = cluster_0a[seg_0b[k]] (k < m_b), seg_ab[m_b] = m_a
+__global__ void link_derive_kernel(const int32_t* __restrict__ cl0a, const int32_t* __restrict__ seg0a, long ma,
+                                   const int32_t* __restrict__ cl0b, const int32_t* __restrict__ seg0b, long mb,
+                                   int32_t* __restrict__ cluster_ab, int32_t* __restrict__ seg_ab) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ma) cluster_ab[t] = cl0b[seg0a[t]];
+  if (t < mb) seg_ab[t] = cl0a[seg0b[t]];
+  if (t == mb) seg_ab[mb] = (int32_t)ma;
+}
+
 // pooled level arrays from the first fine point of every cluster
 __global__ void pool_gather_kernel(const int32_t* __restrict__ seg_start, long m, long n_fine, int pd,
                                    const int32_t* __restrict__ grid_f, const int32_t* __restrict__ batch_f,
@@ -264,6 +312,37 @@ __global__ void pad_plan_kernel(const int32_t* __restrict__ order, const int32_t
   const int g = order ? order[rank] : rank;
   gidx[p] = g;
   widx[p] = real ? g : -1;
+}
+
+// all slot plans of a scene (every level x curve x patch size) in one launch
+struct PadBatchP {
+  const int32_t* order[CDSEG_PAD_BATCH_MAX];
+  const int32_t* offs[CDSEG_PAD_BATCH_MAX];
+  const int32_t* offs_pad[CDSEG_PAD_BATCH_MAX];
+  int K[CDSEG_PAD_BATCH_MAX];
+  long start[CDSEG_PAD_BATCH_MAX + 1];  // prefix sums of n_pad = offsets into gidx / widx
+  int count, nb;
+};
+
+__global__ void pad_plan_batch_kernel(PadBatchP b, int32_t* __restrict__ gidx, int32_t* __restrict__ widx) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.start[b.count]) return;
+  int j = 0;
+  while (j + 1 < b.count && b.start[j + 1] <= t) ++j;
+  const long p = t - b.start[j];
+  const int32_t* offs = b.offs[j];
+  const int32_t* offs_pad = b.offs_pad[j];
+  int lo = 0, hi = b.nb - 1;  // first batch element with offs_pad[e+1] > p
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (offs_pad[mid + 1] > p) hi = mid; else lo = mid + 1;
+  }
+  const int local = (int)(p - offs_pad[lo]);
+  const bool real = local < offs[lo + 1] - offs[lo];
+  const int rank = offs[lo] + (real ? local : local - b.K[j]);
+  const int g = b.order[j] ? b.order[j][rank] : rank;
+  gidx[t] = g;
+  widx[t] = real ? g : -1;
 }
 
 inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
@@ -475,6 +554,52 @@ int cdseg_coarse_orders(const int32_t* const* clusters, int nlev, const int32_t*
   return CDSEG_OK;
 }
 
+size_t cdseg_pool_levels_ws_bytes(long n, int nlev) {
+  const size_t total = (size_t)n * nlev;
+  size_t scan_bytes = 0;
+  (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, total,
+                                rocprim::plus<int32_t>(), (hipStream_t)0, false);
+  return 2 * ((total * sizeof(int32_t) + 255) & ~(size_t)255) + scan_bytes + 1024;
+}
+
+// All pooling levels over the z-sorted level-0 codes in one pass.  shifts (host, nlev <= 8): 3 * cumulative pooling
+// depth per level; last_idx (nb, device): index of the last point of every batch element.
+// cluster (nlev, n), seg_start (nlev, n + 1), meta (nlev, 1 + nb) int32 = [count, cluster of last_idx[b] ...].
+int cdseg_pool_levels(const int64_t* zcode_sorted, long n, const int* shifts, int nlev, const int32_t* last_idx, int nb,
+                      int32_t* cluster, int32_t* seg_start, int32_t* meta, void* ws, size_t ws_bytes, void* stream) {
+  if (n <= 0 || nlev <= 0) return CDSEG_ERR_ARG;
+  if (nlev > 8 || nb <= 0 || !shifts || !last_idx) return CDSEG_ERR_ARG;
+  if (ws_bytes < cdseg_pool_levels_ws_bytes(n, nlev)) return CDSEG_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  LevelsP p;
+  for (int l = 0; l < 8; ++l) p.shift[l] = l < nlev ? shifts[l] : 0;
+  p.nlev = nlev; p.nb = nb; p.n = n;
+  const long total = n * nlev;
+  char* w = (char*)ws;
+  const size_t arr = (((size_t)total * sizeof(int32_t)) + 255) & ~(size_t)255;
+  int32_t* flag = (int32_t*)w;
+  int32_t* incl = (int32_t*)(w + arr);
+  size_t scan_bytes = ws_bytes - 2 * arr;
+  hipLaunchKernelGGL(levels_flag_kernel, grid1d(total), dim3(256), 0, s, zcode_sorted, p, flag);
+  hipError_t e = rocprim::inclusive_scan((void*)(w + 2 * arr), scan_bytes, (const int32_t*)flag, incl, (size_t)total,
+                                         rocprim::plus<int32_t>(), s, false);
+  if (e != hipSuccess) return CDSEG_ERR_LAUNCH;
+  hipLaunchKernelGGL(levels_finish_kernel, grid1d(total), dim3(256), 0, s, incl, flag, p, last_idx, cluster, seg_start,
+                     meta);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_link_derive(const int32_t* cluster_0a, const int32_t* seg_0a, long ma, const int32_t* cluster_0b,
+                      const int32_t* seg_0b, long mb, int32_t* cluster_ab, int32_t* seg_ab, void* stream) {
+  if (ma <= 0 || mb <= 0) return CDSEG_ERR_ARG;
+  const long t = (ma > mb + 1 ? ma : mb + 1);
+  hipLaunchKernelGGL(link_derive_kernel, grid1d(t), dim3(256), 0, (hipStream_t)stream, cluster_0a, seg_0a, ma,
+                     cluster_0b, seg_0b, mb, cluster_ab, seg_ab);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
 int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling_depth, const int32_t* grid_f,
                       const int32_t* batch_f, const int64_t* code4_f, int32_t* grid_c, int32_t* batch_c,
                       int64_t* code4_c, void* stream) {
@@ -502,6 +627,28 @@ int cdseg_pad_plan(const int32_t* order, const int32_t* offs, const int32_t* off
   if (nb <= 0 || patch <= 0) return CDSEG_ERR_ARG;
   hipLaunchKernelGGL(pad_plan_kernel, grid1d(n_pad), dim3(256), 0, (hipStream_t)stream, order, offs, offs_pad, nb,
                      patch, n_pad, gidx, widx);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// count (<= CDSEG_PAD_BATCH_MAX) slot plans at once: plan j uses orders[j] (NULL = identity), offs[j], offs_pad[j],
+// patch[j], n_pad[j]; its gidx / widx start at sum_{i<j} n_pad[i] of the output arrays.
+int cdseg_pad_plan_batch(int count, const int32_t* const* orders, const int32_t* const* offs,
+                         const int32_t* const* offs_pad, const int* patch, const long* n_pad, int nb, int32_t* gidx,
+                         int32_t* widx, void* stream) {
+  if (count <= 0) return CDSEG_OK;
+  if (count > CDSEG_PAD_BATCH_MAX || nb <= 0) return CDSEG_ERR_ARG;
+  PadBatchP b;
+  b.count = count;
+  b.nb = nb;
+  b.start[0] = 0;
+  for (int j = 0; j < count; ++j) {
+    if (patch[j] <= 0 || n_pad[j] < 0) return CDSEG_ERR_ARG;
+    b.order[j] = orders[j]; b.offs[j] = offs[j]; b.offs_pad[j] = offs_pad[j]; b.K[j] = patch[j];
+    b.start[j + 1] = b.start[j] + n_pad[j];
+  }
+  if (b.start[count] == 0) return CDSEG_OK;
+  hipLaunchKernelGGL(pad_plan_batch_kernel, grid1d(b.start[count]), dim3(256), 0, (hipStream_t)stream, b, gidx, widx);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

@@ -126,6 +126,9 @@ class Plan:
         """fine level a -> coarse level b: (cluster (n_a) int32, seg_start (n_b + 1) int32)."""
         def build():
             la, lb = self.levels[a], self.levels[b]
+            if a > 0 and (0, a) in self.links and (0, b) in self.links:  # two gathers instead of a flag/scan pass
+                (cl0a, seg0a), (cl0b, seg0b) = self.link(0, a), self.link(0, b)
+                return ops.link_derive(cl0a, seg0a, la.n, cl0b, seg0b, lb.n)
             cluster, seg, _ = ops.pool_level(la.code4[0], 3 * (lb.cum - la.cum))
             return (cluster, seg)
         return _shared(self.links, (a, b), build)
@@ -308,6 +311,7 @@ class Engine:
                 self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
                                                            mod.attn.scale, 1e-5, t)
         self._scratch = {}
+        self._scratch_bytes = {}
 
     def scratch(self, nbytes):
         key = ops.current_stream_id()  # one scratch arena per stream (the two branches run concurrently)
@@ -370,14 +374,11 @@ class Engine:
         coarse = [c for c in all_cum if c > 0]
         if coarse:
             dev = grid.device
-            counts = torch.empty(len(coarse), dtype=torch.int32, device=dev)
             last_idx = torch.tensor([v - 1 for v in offset_host], dtype=torch.int32, device=dev)
-            tmp, ends = [], []
-            for i, cum in enumerate(coarse):
-                cluster, seg, _ = ops.pool_level(zs, 3 * cum, count_out=counts[i:i + 1])
-                tmp.append((cluster, seg))
-                ends.append(ops.gather_i32(cluster, last_idx))
-            host = torch.cat([counts] + ends).cpu().tolist()  # the one sync for all pooled sizes
+            cl_all, seg_all, meta = ops.pool_levels(zs, [3 * cum for cum in coarse], last_idx)
+            tmp = [(cl_all[i], seg_all[i]) for i in range(len(coarse))]
+            meta_h = meta.cpu().tolist()  # the one sync for all pooled sizes
+            host = [r[0] for r in meta_h] + [v for r in meta_h for v in r[1:]]
             for i, cum in enumerate(coarse):
                 m = host[i]
                 e = host[len(coarse) + i * nb: len(coarse) + (i + 1) * nb]
@@ -411,6 +412,18 @@ class Engine:
             lv.set_pad(key, K, offs_pad, patch_start, up[pos:pos + la], up[pos + la:pos + la + lb],
                        up[pos + la + lb:pos + la + lb + lc])
             pos += la + lb + lc
+        # ... and every slot plan (level x curve x patch key) with ONE launch
+        curves = sorted({CURVES.index(o) for o in bb.order})
+        items, where = [], []
+        for cum, lv in plan.levels.items():
+            for key in pad_keys:
+                K, n_pad, offs, offs_pad = lv.pad(*key)[:4]
+                for c in curves:
+                    items.append((lv.order(c), offs, offs_pad, K, n_pad))
+                    where.append((lv, (c,) + key))
+        cur = ops.current_stream_id()
+        for (lv, key), gw in zip(where, ops.pad_plan_batch(items, nb)):
+            lv._slots[key] = (gw, cur, None)
         return plan
 
     # ------------------------------------------------------------------ layers
@@ -464,11 +477,16 @@ class Engine:
             att = mod.attn
             gidx, widx = lv.slots(st.curves[att.order_index], att.patch_size, att.enable_flash)
             _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
-            self._add_work(64.0 * att.num_heads * sum_l2)
+            self.attn_work += 64.0 * att.num_heads * sum_l2
             desc = self.block_desc[pre]
             xc_out = st.x if self.T == torch.float32 else self._buf(n, c, self.T)
+            sb = self._scratch_bytes.get((pre, n))
+            if sb is None:
+                if len(self._scratch_bytes) > 4096:
+                    self._scratch_bytes.clear()
+                sb = self._scratch_bytes[(pre, n)] = ops.block_scratch_bytes(desc, n)
             ops.block_forward(desc, n, st.x, st.xc, xc_out, tbias, lv.nbr(3, True), gidx, widx, patch_start,
-                              patch_start.numel() - 1, max_len, self.scratch(ops.block_scratch_bytes(desc, n)))
+                              patch_start.numel() - 1, max_len, self.scratch(sb))
             st.xc = xc_out
             return
         h = self._cpe(st, pre + ".cpe", st.xc, tbias, next_norm=pre + ".norm1")

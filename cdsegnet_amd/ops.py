@@ -272,6 +272,30 @@ def pool_level(zcode_sorted, shift_bits, count_out=None):
     return cluster, seg_start, count
 
 
+def pool_levels(zcode_sorted, shifts, last_idx):
+    """All pooling levels at once -> (cluster (L,n), seg_start (L,n+1), meta (L,1+nb)) int32 on the device."""
+    lib = _lib.load()
+    n, L, nb = zcode_sorted.numel(), len(shifts), last_idx.numel()
+    dev = zcode_sorted.device
+    cluster = torch.empty((L, n), dtype=torch.int32, device=dev)
+    seg = torch.empty((L, n + 1), dtype=torch.int32, device=dev)
+    meta = torch.empty((L, 1 + nb), dtype=torch.int32, device=dev)
+    ws = workspace(lib.cdseg_pool_levels_ws_bytes(n, L), dev)
+    sh = (ctypes.c_int * L)(*[int(v) for v in shifts])
+    check(lib.cdseg_pool_levels(_ptr(zcode_sorted), n, sh, L, _ptr(last_idx), nb, _ptr(cluster), _ptr(seg), _ptr(meta),
+                                _ptr(ws), ws.numel(), _stream()), "pool_levels")
+    return cluster, seg, meta
+
+
+def link_derive(cl0a, seg0a, ma, cl0b, seg0b, mb):
+    dev = cl0a.device
+    cluster = torch.empty(int(ma), dtype=torch.int32, device=dev)
+    seg = torch.empty(int(mb) + 1, dtype=torch.int32, device=dev)
+    check(_lib.load().cdseg_link_derive(_ptr(cl0a), _ptr(seg0a), int(ma), _ptr(cl0b), _ptr(seg0b), int(mb),
+                                         _ptr(cluster), _ptr(seg), _stream()), "link_derive")
+    return cluster, seg
+
+
 def coarse_orders(clusters, orders, sizes):
     """Curve orders of all pooled levels from the level-0 orders (no sort).  clusters: per level (n0) int32 cluster
     ids of the level-0 points; orders: per curve (n0) int32 rank -> level-0 point; sizes: per level m_l.
@@ -323,6 +347,34 @@ def pad_plan(order, offs, offs_pad, patch, n_pad):
 
 
 # ------------------------------------------------------------------ float ops
+PAD_BATCH_MAX = 48
+
+
+def pad_plan_batch(items, nb):
+    """items: list of (order or None, offs, offs_pad, patch, n_pad) -> list of (gidx, widx), one launch."""
+    lib = _lib.load()
+    res = []
+    for s0 in range(0, len(items), PAD_BATCH_MAX):
+        chunk = items[s0:s0 + PAD_BATCH_MAX]
+        k = len(chunk)
+        total = sum(int(it[4]) for it in chunk)
+        dev = chunk[0][1].device
+        gidx = torch.empty(total, dtype=torch.int32, device=dev)
+        widx = torch.empty(total, dtype=torch.int32, device=dev)
+        orders = (ctypes.c_void_p * k)(*[None if it[0] is None else it[0].data_ptr() for it in chunk])
+        offs = (ctypes.c_void_p * k)(*[it[1].data_ptr() for it in chunk])
+        offs_pad = (ctypes.c_void_p * k)(*[it[2].data_ptr() for it in chunk])
+        patch = (ctypes.c_int * k)(*[int(it[3]) for it in chunk])
+        npad = (ctypes.c_long * k)(*[int(it[4]) for it in chunk])
+        check(lib.cdseg_pad_plan_batch(k, orders, offs, offs_pad, patch, npad, int(nb), _ptr(gidx), _ptr(widx), _stream()),
+              "pad_plan_batch")
+        pos = 0
+        for it in chunk:
+            res.append((gidx[pos:pos + int(it[4])], widx[pos:pos + int(it[4])]))
+            pos += int(it[4])
+    return res
+
+
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
          nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
          nbr_kmajor=False,

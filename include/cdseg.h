@@ -90,6 +90,16 @@ int cdseg_plan_gather_grid(const void* grid, int grid_elem_bytes, const int32_t*
  * run-start flags, seg_start (count+1 entries) are the run starts, *count_dev the number of runs. */
 int cdseg_pool_level(const int64_t* zcode_sorted, long n, int shift_bits, int32_t* cluster, int32_t* seg_start,
                      int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
+/* All pooling levels of a scene in one flag / scan / finish pass (replaces one cdseg_pool_level per level).
+ * shifts (host, nlev <= 8) = 3 * cumulative pooling depth; last_idx (nb, device) = last point of each batch element.
+ * cluster (nlev, n), seg_start (nlev, n + 1), meta (nlev, 1 + nb) = [count, cluster of last_idx[b] ...] int32. */
+size_t cdseg_pool_levels_ws_bytes(long n, int nlev);
+int cdseg_pool_levels(const int64_t* zcode_sorted, long n, const int* shifts, int nlev, const int32_t* last_idx, int nb,
+                      int32_t* cluster, int32_t* seg_start, int32_t* meta, void* ws, size_t ws_bytes, void* stream);
+/* Link between two pooled levels a (finer, m_a points) and b (m_b) from their links to level 0:
+ * cluster_ab (m_a), seg_ab (m_b + 1). */
+int cdseg_link_derive(const int32_t* cluster_0a, const int32_t* seg_0a, long ma, const int32_t* cluster_0b,
+                      const int32_t* seg_0b, long mb, int32_t* cluster_ab, int32_t* seg_ab, void* stream);
 /* Curve orders of ALL pooled levels without sorting: z-order / Hilbert keys are hierarchical, so the coarse order on a
  * curve is the level-0 order with every point replaced by its cluster id and consecutive duplicates dropped
  * (replaces torch.argsort(code >> 3*depth) of SerializedPooling, ref ptv3.py:503-514).
@@ -117,6 +127,12 @@ int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int3
  * order: rank -> row for the curve of this block (NULL = identity); offs/offs_pad (nb+1). */
 int cdseg_pad_plan(const int32_t* order, const int32_t* offs, const int32_t* offs_pad, int nb, int patch, long n_pad,
                    int32_t* gidx, int32_t* widx, void* stream);
+/* every slot plan of a scene in ONE launch (count <= CDSEG_PAD_BATCH_MAX): plan j = (orders[j] or NULL, offs[j],
+ * offs_pad[j], patch[j], n_pad[j]); gidx / widx of plan j start at sum_{i<j} n_pad[i]. Pointer arrays are host arrays. */
+#define CDSEG_PAD_BATCH_MAX 48
+int cdseg_pad_plan_batch(int count, const int32_t* const* orders, const int32_t* const* offs,
+                         const int32_t* const* offs_pad, const int* patch, const long* n_pad, int nb, int32_t* gidx,
+                         int32_t* widx, void* stream);
 
 /* ------------------------------------------------------------------ dense / gathered GEMM
  * out = epilogue(A @ W^T): nn.Linear (ref: ptv3.py:170-171, 310-313, 463, 597-599, 1562) and,

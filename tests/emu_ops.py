@@ -83,6 +83,22 @@ def pool_level(zs, shift, count_out=None):
     return cluster, seg, cnt
 
 
+def pool_levels(zs, shifts, last_idx):
+    cl, sg, meta = [], [], []
+    for sh in shifts:
+        c, s_, cnt = pool_level(zs, sh)
+        cl.append(c)
+        sg.append(s_)
+        meta.append(torch.cat([cnt.int(), c[last_idx.long()].int()]))
+    return torch.stack(cl), torch.stack(sg), torch.stack(meta)
+
+
+def link_derive(cl0a, seg0a, ma, cl0b, seg0b, mb):
+    cluster = cl0b[seg0a[:ma].long()].int()
+    seg = torch.cat([cl0a[seg0b[:mb].long()].int(), torch.tensor([ma], dtype=torch.int32)])
+    return cluster, seg
+
+
 def coarse_orders(clusters, orders, sizes):
     res = []
     for cl, m in zip(clusters, sizes):
@@ -101,6 +117,10 @@ def coarse_orders(clusters, orders, sizes):
 def pool_gather(seg, m, n_fine, pd, grid_f, batch_f, code4_f):
     h = seg[:m].long()
     return grid_f[h] >> pd, batch_f[h], code4_f[:, h] >> (3 * pd)
+
+
+def pad_plan_batch(items, nb):
+    return [pad_plan(o, a, b, k, n) for o, a, b, k, n in items]
 
 
 def nbr_table(zs, grid, batch, depth, ksize, kmajor=False):

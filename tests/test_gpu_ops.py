@@ -661,3 +661,46 @@ def test_evaluate_scene_vs_oracle(ops):
     idx, _ = OT.knn1_bruteforce(coord, [len(coord)], raw, [len(raw)])
     i, u, t = OT.intersection_and_union(logits.argmax(1)[idx], seg, k, -1)
     assert np.array_equal(counts[0], i) and np.array_equal(counts[1], u) and np.array_equal(counts[2], t)
+
+
+@pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000"])
+def test_batched_plan_kernels_equal_single_calls(ops, name):
+    """pool_levels / link_derive / pad_plan_batch (one launch per scene) against the per-level / per-plan kernels."""
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    offs_np = np.concatenate([[0], np.cumsum(np.bincount(fx["batch"]))]).astype(np.int32)
+    nb = len(offs_np) - 1
+    last = dev((offs_np[1:] - 1).astype(np.int32))
+    shifts = [3, 6, 9]
+    cl, seg, meta = ops.pool_levels(zs, shifts, last)
+    meta = meta.cpu().numpy()
+    singles = []
+    for l, sh in enumerate(shifts):
+        c1, s1, cnt = ops.pool_level(zs, sh)
+        m = int(cnt.item())
+        singles.append((c1, s1, m))
+        assert meta[l, 0] == m
+        assert torch.equal(cl[l], c1) and torch.equal(seg[l][:m + 1], s1[:m + 1])
+        assert np.array_equal(meta[l, 1:], c1.cpu().numpy()[offs_np[1:] - 1])
+    # link between pooled levels 1 and 2 from their links to level 0 == pooling level 1's own codes
+    (c0a, s0a, ma), (c0b, s0b, mb) = singles[0], singles[1]
+    code0 = ops.encode4(g0, b0, depth)
+    ga, ba, ca = ops.pool_gather(s0a, ma, n, 1, g0, b0, code0)
+    want_c, want_s, want_m = ops.pool_level(ca[0].contiguous(), 3)
+    got_c, got_s = ops.link_derive(c0a, s0a, ma, c0b, s0b, mb)
+    assert int(want_m.item()) == mb
+    assert torch.equal(got_c, want_c[:ma]) and torch.equal(got_s, want_s[:mb + 1])
+    # slot plans
+    order = ops.sort_pairs(code0[2].contiguous())[1]
+    items = []
+    for K in (4, 16, 1024):
+        cnt = np.diff(offs_np)
+        padc = np.where(cnt > K, (cnt + K - 1) // K * K, cnt)
+        offs_pad = np.concatenate([[0], np.cumsum(padc)]).astype(np.int32)
+        for od in (None, order):
+            items.append((od, dev(offs_np), dev(offs_pad), K, int(offs_pad[-1])))
+    got = ops.pad_plan_batch(items, nb)
+    for (od, a, b, K, npad), (g, w) in zip(items, got):
+        g1, w1 = ops.pad_plan(od, a, b, K, npad)
+        assert torch.equal(g, g1) and torch.equal(w, w1)
