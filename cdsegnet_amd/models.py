@@ -407,7 +407,7 @@ class DefaultSegmentorV2(nn.Module):
         return dict(seg_logits=self.engine().inference(input_dict, noise_level=noise_level, draws=draws))
 
     @torch.no_grad()
-    def inference_many(self, input_dicts, lanes=3, noise_level=None, draws=None, threads=False):
+    def inference_many(self, input_dicts, lanes=4, noise_level=None, draws=None, threads=False):
         """Throughput form of ``inference`` for a sequence of INDEPENDENT scenes (the tester's loop over scenes /
         fragments, ref: engines/test.py:197-279): scene i runs on HIP stream ``lane[i % lanes]``, so up to ``lanes``
         scenes are in flight on the GPU.  The deep, latency-bound stages of one scene (a few hundred points, tens of

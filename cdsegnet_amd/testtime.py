@@ -34,7 +34,7 @@ def fragment(gs, i):
 
 
 @torch.no_grad()
-def segment_scene(model, coord, feat, grid_size, num_classes, noise_level=None, max_fragments=None, lanes=3):
+def segment_scene(model, coord, feat, grid_size, num_classes, noise_level=None, max_fragments=None, lanes=4):
     """Fragmented inference + softmax voting of one raw scene (engines/test.py:181-279, bs = 1, no TTA).
     coord (N,3) f32, feat (N,C) f32 on the GPU.  Returns (labels int32 (N,), pred (N, num_classes) f32).
     The fragments are independent scenes for the model, so they go through ``inference_many`` (up to ``lanes`` in
