@@ -152,6 +152,22 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
   const bf16_t* kb = (const bf16_t*)p.k + head * 16;
   const bf16_t* vb = (const bf16_t*)p.v + head * 16;
 
+  // largest squared key norm of the patch-head (for the score bound of the single-pass softmax below)
+  __shared__ unsigned s_kmax2;
+  if (tid == 0) s_kmax2 = 0u;
+  __syncthreads();
+  float kn2max = 0.f;
+  auto sq8 = [](const uint4& a) {
+    float t = 0.f;
+    const uint32_t u[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+      t = fmaf(lo, lo, fmaf(hi, hi, t));
+    }
+    return t;
+  };
+
   // ---- stage K (row-major, 16-B halves swizzled) and V^T (+ ones row, zero row).
   // One thread per key PAIR: 8 independent 16-B gathers in flight, V^T written as packed dwords.
   for (int pr = tid; pr < (Lp >> 1); pr += ATTN_THREADS) {
@@ -170,6 +186,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
       const uint4* vr = reinterpret_cast<const uint4*>(vb + g * p.ldv);
       k1[0] = kr[0]; k1[1] = kr[1]; v1[0] = vr[0]; v1[1] = vr[1];
     }
+    kn2max = fmaxf(kn2max, fmaxf(sq8(k0[0]) + sq8(k0[1]), sq8(k1[0]) + sq8(k1[1])));
     const int sw = (s0 >> 3) & 1;  // same for s1 (s0 even)
     *reinterpret_cast<uint4*>(Ks + s0 * 32 + ((0 ^ sw) << 4)) = k0[0];
     *reinterpret_cast<uint4*>(Ks + s0 * 32 + ((1 ^ sw) << 4)) = k0[1];
@@ -186,7 +203,10 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
         (s0 < L ? 0x3F80u : 0u) | (s1 < L ? 0x3F800000u : 0u);
     *reinterpret_cast<uint32_t*>(Vt + 17 * VT_STRIDE_BF16 + s0 * 2) = 0u;
   }
+  kn2max = wave_max(kn2max);
+  if (lane == 0) atomicMax(&s_kmax2, __float_as_uint(kn2max));  // non-negative floats order like their bit patterns
   __syncthreads();
+  const float kmax2 = __uint_as_float(s_kmax2);
 
   const int ql = lane & 31;  // query (B operand column) / key or head-dim row (A operand row)
   const int h = lane >> 5;
@@ -212,42 +232,67 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
       qf = qs.v;
     }
     const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // ---- pass 1: row max of S'^T = K Q'^T (lane (q,h) sees keys (r&3) + 8*(r>>2) + 4h of each tile)
-    float m0 = -INFINITY, m1 = -INFINITY;
-    int kt = 0;
-    for (; kt + 1 < nfull; kt += 2) {  // two independent tiles in flight
-      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf, zero16);
-      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf, zero16);
-      m0 = tile_max(sa, m0);
-      m1 = tile_max(sb, m1);
-    }
-    for (; kt < nkt; ++kt) {
-      f32x16_t s = qk_tile(Ks, kt, ql, h, qf, zero16);
-      if (kt >= nfull) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[r] = -INFINITY;
+    // P = exp2(S' - m), O^T (+ row sums in row 16) += [V^T; 1; 0] P^T, with S' - m straight out of the MFMA
+    // (C operand = -m, loop invariant)
+    auto exp_pv_pass = [&](float mrow) {
+      const float nm = -mrow;
+      const f32x16_t negm = {nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm};
+      f32x16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      int kt = 0;
+      for (; kt + 1 < nfull; kt += 2) {  // two independent tiles in flight
+        const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf, negm);
+        const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf, negm);
+        pv_tile<false>(sa, kt, h, L, vt_lane, acc);
+        pv_tile<false>(sb, kt + 1, h, L, vt_lane, acc);
       }
-      m0 = tile_max(s, m0);
+      for (; kt < nkt; ++kt) {
+        const f32x16_t s = qk_tile(Ks, kt, ql, h, qf, negm);
+        if (kt >= nfull) pv_tile<true>(s, kt, h, L, vt_lane, acc);
+        else pv_tile<false>(s, kt, h, L, vt_lane, acc);
+      }
+      return acc;
+    };
+    // ---- single pass: softmax is shift invariant, so any m >= max_j s_ij that does not underflow the row works.
+    // Cauchy-Schwarz gives one for free: s_ij <= |q'_i| * max_j |k_j|.  It replaces the row-max pass (a second QK^T
+    // MFMA sweep + a v_max3 per score pair; the kernel is VALU-issue bound).  P keeps its relative precision at
+    // any magnitude (fp32 / bf16 share the exponent range, the denominator comes from the same truncated values).
+    float qn2 = 0.f;
+    {
+      union { bf16x8_t v; uint32_t u[4]; } qq;
+      qq.v = qf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = __uint_as_float(qq.u[j] << 16), hi = __uint_as_float(qq.u[j] & 0xffff0000u);
+        qn2 = fmaf(lo, lo, fmaf(hi, hi, qn2));
+      }
+      qn2 += __shfl_xor(qn2, 32, 64);
     }
-    float m = fmaxf(m0, m1);
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    // ---- pass 2: S' - m comes straight out of the MFMA (C operand = -m, loop invariant), P = exp2(.),
-    //      O^T (+ row sums in row 16) += [V^T; 1; 0] P^T
-    const float nm = -m;
-    const f32x16_t negm = {nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm};
-    f32x16_t o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    kt = 0;
-    for (; kt + 1 < nfull; kt += 2) {
-      const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf, negm);
-      const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf, negm);
-      pv_tile<false>(sa, kt, h, L, vt_lane, o);
-      pv_tile<false>(sb, kt + 1, h, L, vt_lane, o);
-    }
-    for (; kt < nkt; ++kt) {
-      const f32x16_t s = qk_tile(Ks, kt, ql, h, qf, negm);
-      if (kt >= nfull) pv_tile<true>(s, kt, h, L, vt_lane, o);
-      else pv_tile<false>(s, kt, h, L, vt_lane, o);
+    f32x16_t o = exp_pv_pass(sqrtf(qn2 * kmax2) * 1.0005f);
+    // rows whose bound is looser than 2^60 (the largest term could sink towards the denormal range) are redone
+    // with the exact row max; wave-uniform branch, never taken for ordinary logits
+    const bool loose = qvalid && !(__shfl(o[8], ql, 64) >= 8.6736174e-19f);
+    if (__any(loose)) {
+      // ---- exact pass 1: row max of S'^T = K Q'^T (lane (q,h) sees keys (r&3) + 8*(r>>2) + 4h of each tile)
+      float m0 = -INFINITY, m1 = -INFINITY;
+      int kt = 0;
+      for (; kt + 1 < nfull; kt += 2) {
+        const f32x16_t sa = qk_tile(Ks, kt, ql, h, qf, zero16);
+        const f32x16_t sb = qk_tile(Ks, kt + 1, ql, h, qf, zero16);
+        m0 = tile_max(sa, m0);
+        m1 = tile_max(sb, m1);
+      }
+      for (; kt < nkt; ++kt) {
+        f32x16_t s = qk_tile(Ks, kt, ql, h, qf, zero16);
+        if (kt >= nfull) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[r] = -INFINITY;
+        }
+        m0 = tile_max(s, m0);
+      }
+      float m = fmaxf(m0, m1);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      o = exp_pv_pass(m);
     }
     // ---- epilogue: O^T rows (r&3) + 8*(r>>2) + 4h; row 16 (lane h=0, r=8) is the denominator
     const float lsum = __shfl(o[8], ql, 64);

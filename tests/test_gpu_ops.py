@@ -704,3 +704,36 @@ def test_batched_plan_kernels_equal_single_calls(ops, name):
     for (od, a, b, K, npad), (g, w) in zip(items, got):
         g1, w1 = ops.pad_plan(od, a, b, K, npad)
         assert torch.equal(g, g1) and torch.equal(w, w1)
+
+
+def test_attention_bf16_loose_score_bound_falls_back_to_exact_max(ops):
+    """The bf16 kernel takes m_i = |q_i| max_j |k_j| (Cauchy-Schwarz) instead of the row max; rows where that bound is
+    more than 2^60 above the scores are redone with the exact max.  Build exactly that: huge, nearly orthogonal q / k."""
+    g = torch.Generator().manual_seed(3)
+    n, H = 1500, 2
+    C = 16 * H
+    q = torch.randn(n, C, generator=g) * 0.05
+    k = torch.randn(n, C, generator=g) * 0.05
+    v = torch.randn(n, C, generator=g)
+    q[:, 0::16] += 60.0   # every head: q mostly along dim 0 ...
+    k[:, 1::16] += 60.0   # ... k mostly along dim 1: scores are O(10), |q||k| * scale ~ 900
+    q[::7, 1::16] += 1.0  # a few rows with real structure
+    q, k, v = _bf16_round(q), _bf16_round(k), _bf16_round(v)
+    order = torch.randperm(n, generator=g).numpy()
+    inverse = np.empty(n, dtype=np.int64)
+    inverse[order] = np.arange(n)
+    t_order = torch.from_numpy(order)
+    starts = np.array([0, 1024, n])
+    ref = torch.cat([OM._patch_attention(q[t_order][a:b], k[t_order][a:b], v[t_order][a:b], np.array([0, b - a]), H, 0.25)
+                     for a, b in ((0, 1024), (1024 - (2048 - n), n))])
+    # padded second patch borrows the tail of the first (ptv3.py:218-228): use the library's own plan for the layout
+    offs = dev(np.array([0, n], dtype=np.int32))
+    offs_pad = dev(np.array([0, 2048], dtype=np.int32))
+    gq, wq = ops.pad_plan(dev(order.astype(np.int32)), offs, offs_pad, 1024, 2048)
+    ps = dev(np.array([0, 1024, 2048], dtype=np.int32))
+    out = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
+    ops.attention(dev(q, torch.bfloat16), dev(k, torch.bfloat16), dev(v, torch.bfloat16), gq, gq, wq, ps, H, 1024, 0.25, out)
+    got = out.float().cpu()[t_order]
+    want = torch.cat([ref[:1024], ref[1024 + (2048 - n):]])
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() < 0.03 * (1 + want.abs().max().item())
