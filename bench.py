@@ -8,7 +8,8 @@ A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-
 fusion) over one synthetic ScanNet-shaped scene per GPU (BASELINE.json configs[1]: ~120k voxels,
 6-ch features, 20 classes, bf16), inputs already resident in HBM.  Scenes are independent units:
 each rank runs its own scenes, no data-path collective ("scaling": "weak"); within a rank the K
-steps go through DefaultSegmentorV2.inference_many, which keeps up to --lanes scenes in flight on
+steps (= K scenes) go through DefaultSegmentorV2.inference_many, which collates --scenes-per-forward
+scenes per forward (the reference's collate_fn batching) and keeps up to --lanes forwards in flight on
 separate HIP streams (every scene still runs the full path; `single_scene_latency_ms` reports the
 one-scene-at-a-time latency next to the throughput).  RCCL is used once to
 broadcast the weights from rank 0 and for the final timing / counter reductions.
@@ -43,8 +44,8 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--dataset", default="scannet", choices=["scannet", "scannet200", "nuscenes"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -55,7 +56,9 @@ def parse():
     ap.add_argument("--time-in-region", action="store_true",
                     help="also record HIP events around the attention launches INSIDE the timed region (costs ~5 %% "
                          "throughput: the run is host-issue bound and every launch gets two hipEventCreate/Record)")
-    ap.add_argument("--lanes", type=int, default=4,
+    ap.add_argument("--scenes-per-forward", type=int, default=4,
+                    help="scenes collated into one forward (the reference's collate_fn batching); a step is still ONE scene")
+    ap.add_argument("--lanes", type=int, default=3,
                     help="independent scenes in flight per GPU (HIP streams); 1 = strictly one scene at a time")
     return ap.parse_args()
 
@@ -109,7 +112,7 @@ def main():
 
     def run(k):
         """k steps = k independent scene inferences, up to --lanes of them in flight (DefaultSegmentorV2.inference_many)."""
-        return model.inference_many([dict(inp) for _ in range(k)], lanes=args.lanes,
+        return model.inference_many([dict(inp) for _ in range(k)], lanes=args.lanes, batch=args.scenes_per_forward,
                                     threads=os.environ.get("CDSEG_LANE_THREADS", "0") != "0")[-1]["seg_logits"]
 
     if args.warmup:
@@ -185,7 +188,8 @@ def main():
             "config": {"workload": f"{args.dataset}-shape {n}-point scene per GPU, CDSegNet 1-step inference "
                                    f"(PT-v3m1 dual backbone, 101.4M params, random-init), 1 scene/step/GPU",
                        "points_per_scene": n, "precision": args.precision, "scenes_per_step_per_gpu": 1,
-                       "scenes_in_flight_per_gpu": args.lanes, "noise": "device Philox"},
+                       "scenes_per_forward": args.scenes_per_forward, "forwards_in_flight_per_gpu": args.lanes,
+                       "noise": "device Philox"},
         }
         if timer and iso and iso["ms"] > 0:
             peak = PEAK_TFLOPS[args.precision]

@@ -347,6 +347,24 @@ def diffusion_betas(kind, start, stop, T):
     raise NotImplementedError(f"noise_schedule={kind!r}")
 
 
+def collate_device(dicts):
+    """Pointcept's collate_fn for already-resident scenes (datasets/utils.py:34-39): concatenate along the point axis,
+    offsets become cumulative.  Host-side sizes ride along in ``offset_host`` (no device sync)."""
+    if len(dicts) == 1:
+        return dicts[0]
+    out = {}
+    for k in ("coord", "grid_coord", "feat"):
+        out[k] = torch.cat([d[k] for d in dicts], 0)
+    ends, base = [], 0
+    for d in dicts:
+        oh = d["offset_host"] if "offset_host" in d else d["offset"].cpu().tolist()
+        ends += [base + int(v) for v in oh]
+        base = ends[-1]
+    out["offset"] = torch.tensor(ends, dtype=torch.int64, device=dicts[0]["feat"].device)
+    out["offset_host"] = ends
+    return out
+
+
 @MODELS.register_module()
 class DefaultSegmentorV2(nn.Module):
     """CNF wrapper (ref: default.py:13-494).  ``inference`` is the single-step path (SSI)."""
@@ -407,7 +425,7 @@ class DefaultSegmentorV2(nn.Module):
         return dict(seg_logits=self.engine().inference(input_dict, noise_level=noise_level, draws=draws))
 
     @torch.no_grad()
-    def inference_many(self, input_dicts, lanes=4, noise_level=None, draws=None, threads=False):
+    def inference_many(self, input_dicts, lanes=4, noise_level=None, draws=None, threads=False, batch=1):
         """Throughput form of ``inference`` for a sequence of INDEPENDENT scenes (the tester's loop over scenes /
         fragments, ref: engines/test.py:197-279): scene i runs on HIP stream ``lane[i % lanes]``, so up to ``lanes``
         scenes are in flight on the GPU.  The deep, latency-bound stages of one scene (a few hundred points, tens of
@@ -416,10 +434,27 @@ class DefaultSegmentorV2(nn.Module):
         own host thread; measured SLOWER on CPython 3.10 (4.97 vs 4.24 ms per scene: ~500 short library calls per
         scene make the threads convoy on the GIL), so the default is one issuing thread.  Same kernels, same results
         as calling ``inference`` scene by scene: the random draws are taken up front, in scene order.
-        Returns the list of output dicts, valid on the caller's current stream."""
+        ``batch`` > 1 additionally collates every ``batch`` consecutive scenes into ONE forward with cumulative
+        ``offset`` s - the reference's own batching (datasets/utils.py:34-39; its nuScenes config tests 8 sweeps per
+        GPU): launches and host work per scene drop by ``batch``.  A batched scene gets the logits the reference
+        gives it inside that batch (the serialization depth and the order shuffles are per batch), not bit-for-bit
+        those of a stand-alone call.
+        Returns the list of output dicts (one per input scene), valid on the caller's current stream."""
         dicts = list(input_dicts)
         if not dicts:
             return []
+        if batch > 1:
+            groups = [dicts[i:i + batch] for i in range(0, len(dicts), batch)]
+            outs = self.inference_many([collate_device(g) for g in groups], lanes=lanes, noise_level=noise_level,
+                                       draws=draws, threads=threads)
+            res = []
+            for g, o in zip(groups, outs):
+                pos = 0
+                for d in g:
+                    n = d["feat"].shape[0]
+                    res.append(dict(seg_logits=o["seg_logits"][pos:pos + n]))
+                    pos += n
+            return res
         dev = dicts[0]["feat"].device
         eng = self.engine()
         if dev.type != "cuda" or lanes <= 1:
@@ -429,10 +464,9 @@ class DefaultSegmentorV2(nn.Module):
         all_draws = [draws[i] if draws is not None else eng.predraw(d, noise_level) for i, d in enumerate(dicts)]
         cur = torch.cuda.current_stream(dev)
         nl = min(int(lanes), len(dicts))
-        key = (dev.index, int(lanes))
-        streams = self._lanes.get(key)
-        if streams is None:
-            streams = self._lanes[key] = [torch.cuda.Stream(device=dev) for _ in range(int(lanes))]
+        streams = self._lanes.setdefault(dev.index, [])  # one pool per device: lanes must not outnumber hardware queues
+        while len(streams) < nl:
+            streams.append(torch.cuda.Stream(device=dev))
         ready = torch.cuda.Event()
         ready.record(cur)
         outs = [None] * len(dicts)

@@ -338,3 +338,30 @@ def test_inference_many_equals_scene_by_scene(precision):
             assert torch.equal(got, ref[0]), fs
     finally:
         eng.fork_stage = keep
+
+
+def test_inference_many_batched_equals_collated_forward():
+    """batch=2: every pair of scenes is one forward with cumulative offsets (the reference's collate_fn); the
+    per-scene logits are the slices of that forward's output."""
+    from cdsegnet_amd.models import collate_device
+    cfg = configs.mini_config()
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=4), strict=True)
+    model = model.to("cuda").eval()
+    model.precision = "fp32"
+    scenes = [synth.room_scene(40 + i, n) for i, n in enumerate((3000, 1800, 2500, 900, 2000))]
+    dicts = [{k: torch.as_tensor(sc[k]).cuda() for k in ("coord", "grid_coord", "feat", "offset")} for sc in scenes]
+    torch.manual_seed(9)
+    want = []
+    for g in (dicts[0:2], dicts[2:4], dicts[4:5]):
+        o = model.inference(dict(collate_device([dict(d) for d in g])), eval=False)["seg_logits"]
+        pos = 0
+        for d in g:
+            want.append(o[pos:pos + d["feat"].shape[0]].clone())
+            pos += d["feat"].shape[0]
+    torch.manual_seed(9)
+    got = model.inference_many([dict(d) for d in dicts], lanes=2, batch=2)
+    torch.cuda.synchronize()
+    assert len(got) == len(dicts)
+    for a, b in zip(got, want):
+        assert torch.equal(a["seg_logits"], b)
