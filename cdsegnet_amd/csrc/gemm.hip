@@ -556,6 +556,10 @@ int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// (A persistent weight-stationary variant for the short-K linears of the big stages - W slice resident in LDS /
+// registers, the next row tile's A in flight during the epilogue - was measured and dropped: 41 us vs 29 us on the
+// 120k x 32 -> 128 linear; four block barriers per tile at 3 workgroups / CU cost more than the reloads they save.
+// What those launches were actually paying for was libm's erff in the GELU epilogue, see common.h.)
 template <typename CT, int NCH, bool GATHER>
 int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   constexpr int BK = NCH * (16 / (int)sizeof(CT));
@@ -622,8 +626,8 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
 
 template <typename CT, bool GATHER>
 int launch(const GemmP& p, size_t ws_bytes, hipStream_t s) {
-  // narrow K step (one 32-wide MFMA block) only when the whole reduction is that short
   const long ktot = (long)p.kvol * p.K;
+  // narrow K step (one 32-wide MFMA block) only when the whole reduction is that short
   if (ktot <= 64) {
     if constexpr (sizeof(CT) == 2) return launch_bn<CT, 4, GATHER>(p, ws_bytes, s);
     else return launch_bn<CT, 8, GATHER>(p, ws_bytes, s);
