@@ -290,6 +290,43 @@ __global__ void nbr_table_kernel(const int64_t* __restrict__ zc, const int32_t* 
   nbr[kmajor ? (long)o * n + i : t] = res;
 }
 
+// ---- kernel map from the parent level's map (pooling depth 1).  The target cell g + d (|d| <= ksize/2 <= 2) lies in
+// one of the 27 parent cells around the point's own parent; if that parent cell is empty so is the target, otherwise
+// the target is one of its <= 8 children, which are contiguous in z-order (one cache line of codes) and identified by
+// the octant bits.  Replaces a log2(n)-deep binary search per (point, offset) by ~3 dependent, mostly cached reads.
+__global__ void nbr_from_parent_kernel(const int64_t* __restrict__ zc, const int32_t* __restrict__ grid,
+                                       const int32_t* __restrict__ cluster, const int32_t* __restrict__ pnbr /* (27,m) */,
+                                       const int32_t* __restrict__ seg, long n, long m, int depth, int ksize, int kmajor,
+                                       int32_t* __restrict__ nbr) {
+  const int kv = ksize * ksize * ksize;
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * kv) return;
+  const long i = kmajor ? t % n : t / kv;
+  const int o = kmajor ? (int)(t / n) : (int)(t - i * kv);
+  const int r = ksize >> 1;
+  const int a = o / (ksize * ksize), b = (o / ksize) % ksize, c = o % ksize;
+  const int gx = grid[3 * i], gy = grid[3 * i + 1], gz = grid[3 * i + 2];
+  const int x = gx + a - r, y = gy + b - r, z = gz + c - r;
+  const int lim = 1 << depth;
+  int res = -1;
+  if (o == kv / 2) {
+    res = (int)i;
+  } else if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+    const int dx = (x >> 1) - (gx >> 1), dy = (y >> 1) - (gy >> 1), dz = (z >> 1) - (gz >> 1);
+    const int par = pnbr[(long)((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)) * m + cluster[i]];
+    if (par >= 0) {
+      const int64_t oct = (int64_t)(((x & 1) << 2) | ((y & 1) << 1) | (z & 1));  // z-order: x -> bit 2, y -> 1, z -> 0
+      const int e = seg[par + 1];
+      for (int j = seg[par]; j < e; ++j) {
+        const int64_t cj = zc[j] & 7;
+        if (cj == oct) { res = j; break; }
+        if (cj > oct) break;
+      }
+    }
+  }
+  nbr[kmajor ? (long)o * n + i : t] = res;
+}
+
 // attention slot plan (ptv3.py:188-244 in scatter form).  For padded slot p of batch element b:
 //   local < n_b  : rank = local                       (real slot, its output is kept)
 //   local >= n_b : rank = local - K                   (borrowed from the previous patch's tail)
@@ -617,6 +654,20 @@ int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int3
   const long total = n * ksize * ksize * ksize;
   hipLaunchKernelGGL(nbr_table_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid, batch, n,
                      depth, ksize, kmajor, nbr);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// Same table as cdseg_nbr_table, derived from the parent level (pooling depth 1): cluster (n) fine point -> parent,
+// parent_nbr3 (27, m) OFFSET-MAJOR 3x3x3 map of the parent level, seg_start (m + 1) children runs.
+int cdseg_nbr_table_from_parent(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* cluster,
+                                const int32_t* parent_nbr3, const int32_t* seg_start, long n, long m, int depth, int ksize,
+                                int kmajor, int32_t* nbr, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if ((ksize != 3 && ksize != 5) || m <= 0) return CDSEG_ERR_ARG;
+  const long total = n * ksize * ksize * ksize;
+  hipLaunchKernelGGL(nbr_from_parent_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid,
+                     cluster, parent_nbr3, seg_start, n, m, depth, ksize, kmajor, nbr);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

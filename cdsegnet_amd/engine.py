@@ -62,6 +62,7 @@ class Level:
         self.cum, self.depth, self.n = cum, depth, n
         self.grid, self.batch, self.code4 = grid, batch, code4
         self.offs_host = offs_host  # (B+1) python ints
+        self.parent = None  # (parent Level, (cluster, seg_start)) when the next pooled level is one octree step up
         self._order = {}
         self._nbr = {}
         self._pad = {}
@@ -81,8 +82,13 @@ class Level:
     def nbr(self, ksize, kmajor=False):
         # offset-major tables: a wave searches one offset of 64 consecutive z-ordered points (same cache lines);
         # an open-addressing hash table was measured and is NOT faster (two dependent random reads per lookup)
-        return _shared(self._nbr, (ksize, kmajor),
-                       lambda: ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor))
+        def build():
+            if self.parent is not None:  # derive from the parent level's 3x3x3 map: ~3 cached reads per lookup
+                par, (cluster, seg) = self.parent
+                return ops.nbr_table_from_parent(self.code4[0], self.grid, cluster, par.nbr(3, True), seg, par.n,
+                                                 self.depth, ksize, kmajor)
+            return ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
+        return _shared(self._nbr, (ksize, kmajor), build)
 
     def pad_host(self, patch_size, enable_flash):
         """Host side of the padding plan (ref: ptv3.py:188-250): K, offs, offs_pad, patch_start (int32 arrays)."""
@@ -385,6 +391,11 @@ class Engine:
                 g, b, c4 = ops.pool_gather(tmp[i][1], m, n, cum, grid0, bat0, code0)
                 plan.levels[cum] = Level(cum, depth - cum, m, g, b, c4, [0] + [v + 1 for v in e])
                 plan.links[(0, cum)] = ((tmp[i][0], tmp[i][1]), ops.current_stream_id(), None)
+            # kernel maps are derived top-down (coarsest level by search, every finer one from its parent's map)
+            cums = sorted(plan.levels)
+            for fa, co in zip(cums[:-1], cums[1:]):
+                if co - fa == 1:
+                    plan.levels[fa].parent = (plan.levels[co], plan.link(fa, co))
             # curve orders of the pooled levels: derived from the level-0 orders (hierarchical keys), not sorted
             used = sorted({CURVES.index(o) for o in bb.order} - {0})
             if used:

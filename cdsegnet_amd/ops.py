@@ -337,6 +337,17 @@ def nbr_table(zcode_sorted, grid_i32, batch_i32, depth, ksize, kmajor=False):
     return nbr
 
 
+def nbr_table_from_parent(zcode_sorted, grid_i32, cluster, parent_nbr3, seg_start, m, depth, ksize, kmajor=False):
+    """Kernel map of a level from its parent level's (27, m) offset-major 3x3x3 map (pooling depth 1)."""
+    n = zcode_sorted.numel()
+    kv = ksize ** 3
+    nbr = torch.empty((kv, n) if kmajor else (n, kv), dtype=torch.int32, device=zcode_sorted.device)
+    check(_lib.load().cdseg_nbr_table_from_parent(_ptr(zcode_sorted), _ptr(grid_i32), _ptr(cluster), _ptr(parent_nbr3),
+                                                   _ptr(seg_start), n, int(m), int(depth), int(ksize),
+                                                   1 if kmajor else 0, _ptr(nbr), _stream()), "nbr_table_from_parent")
+    return nbr
+
+
 def pad_plan(order, offs, offs_pad, patch, n_pad):
     dev = offs.device
     gidx = torch.empty(n_pad, dtype=torch.int32, device=dev)

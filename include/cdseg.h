@@ -121,6 +121,13 @@ int cdseg_pool_gather(const int32_t* seg_start, long m, long n_fine, int pooling
 int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* batch, long n, int depth,
                     int ksize, int kmajor, int32_t* nbr, void* stream);
 
+/* The same kernel map derived from the PARENT level's 3x3x3 map (pooling depth 1) instead of searching: a target
+ * cell lies in one of the 27 parent cells around the point's parent; empty parent cell => empty target, else the target
+ * is one of its <= 8 z-contiguous children.  cluster (n): point -> parent; parent_nbr3 (27, m) offset-major;
+ * seg_start (m + 1): children runs of the parents. */
+int cdseg_nbr_table_from_parent(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* cluster,
+                                const int32_t* parent_nbr3, const int32_t* seg_start, long n, long m, int depth, int ksize,
+                                int kmajor, int32_t* nbr, void* stream);
 /* ------------------------------------------------------------------ attention padding plan
  * ref: ptv3.py:188-244 (get_padding_and_inverse) in gather/scatter form: for every padded slot
  * the row to read (gidx) and the row to write (widx, -1 for the borrowed duplicates).

@@ -128,6 +128,11 @@ def nbr_table(zs, grid, batch, depth, ksize, kmajor=False):
     return t.t().contiguous() if kmajor else t
 
 
+def nbr_table_from_parent(zs, grid, cluster, parent_nbr3, seg_start, m, depth, ksize, kmajor=False):
+    batch = (zs >> (3 * depth)).int()
+    return nbr_table(zs, grid, batch, depth, ksize, kmajor)
+
+
 def pad_plan(order, offs, offs_pad, patch, n_pad):
     offs, offs_pad = offs.numpy().astype(np.int64), offs_pad.numpy().astype(np.int64)
     gidx = np.empty(n_pad, dtype=np.int32)
