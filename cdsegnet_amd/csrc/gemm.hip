@@ -12,6 +12,10 @@
 // A / W K-tiles are staged through LDS in 16-byte chunks with an XOR swizzle that makes every
 // ds_read_b128 of an MFMA fragment bank-conflict free (tools/lds_conflicts.py); global loads of
 // step k+1 are in flight during the MFMAs of step k (register double buffering).
+// (Measured on the 480k-point stage-0 conv, profiles/r01l_pmc_conv_attention_raw.txt: HBM traffic = the compulsory
+// 82 MB, VALU 11 %, ~60 % of the wave cycles idle: a tile is a chain of dependent index -> row round trips.  Issuing
+// the loads of 2-4 K steps at once shortened the chain (196 -> 180 us) but the extra registers cost more overlap
+// with the other streams than that gained (37.5 -> 34.3 M points/s end to end), so the loop keeps one step in flight.)
 // Sparse conv: the block first compacts the kernel offsets that ANY of its 64 rows has a
 // neighbour at (on z-ordered points: ~10-15 of 27) and reduces over those only; A chunks are
 // gathered through the neighbour table per 16-byte chunk, so one K step can span several offsets
@@ -369,11 +373,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      int c = 0;
-      for (int o = 0; o < g.kvol; ++o)
-        if ((smask[o >> 6] >> (o & 63)) & 1ull) live[1 + c++] = o;
-      live[0] = c;
+    if (tid < g.kvol) {  // compaction by population count: offset tid goes to slot (#live offsets below it)
+      const unsigned long long m0 = smask[0], m1 = smask[1];
+      const bool on = ((tid < 64 ? m0 >> tid : m1 >> (tid - 64)) & 1ull) != 0ull;
+      const int below = tid < 64 ? __popcll(m0 & ((1ull << tid) - 1ull))
+                                 : __popcll(m0) + __popcll(m1 & ((1ull << (tid - 64)) - 1ull));
+      if (on) live[1 + below] = tid;
+      if (tid == 0) live[0] = __popcll(m0) + __popcll(m1);
     }
     __syncthreads();
     nlive = __builtin_amdgcn_readfirstlane(live[0]);

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One sparse-conv (gathered-A GEMM) shape of the real scene plan, for rocprofv3 --pmc passes.
+usage: python tools/bench_conv.py [level=0] [scenes=1] [iters=20]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cdsegnet_amd import ops, synth
+from tools.bench_gemm import time_op
+
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+dev = torch.device("cuda")
+sc = synth.collate([synth.room_scene(i, 120000) for i in range(scenes)])
+grid = torch.as_tensor(sc["grid_coord"]).to(dev).int().contiguous()
+offs = np.concatenate([[0], sc["offset"]])
+batch = torch.as_tensor(np.repeat(np.arange(scenes), np.diff(offs))).to(dev).int().contiguous()
+depth = int(grid.max().item()).bit_length()
+code = ops.encode4(grid, batch, depth)
+zs, perm = ops.sort_pairs(code[0].contiguous())
+gz, bz = ops.gather_rows(grid, perm), ops.gather_rows(batch, perm)
+code4 = ops.encode4(gz, bz, depth)
+chans = [32, 64, 128, 256, 512]
+n, d = len(grid), depth
+for lvl in range(level):
+    cl, seg, cnt = ops.pool_level(zs, 3)
+    m = int(cnt.item())
+    gz, bz, code4 = ops.pool_gather(seg, m, n, 1, gz, bz, code4)
+    zs, n, d = code4[0].contiguous(), m, d - 1
+c = chans[level]
+nbr = ops.nbr_table(zs, gz, bz, d, 3, True)
+occ = float((nbr >= 0).float().mean()) * 27
+x = torch.randn(n, c, device=dev).to(torch.bfloat16)
+w = (torch.randn(c, 27 * c, device=dev) / (27 * c) ** 0.5).to(torch.bfloat16)
+b = torch.randn(c, device=dev)
+o = torch.empty(n, c, dtype=torch.bfloat16, device=dev)
+us = time_op(lambda: ops.gemm(x, w, o, bias=b, nbr=nbr, kvol=27, nbr_kmajor=True), iters)
+print(f"conv level {level}: n={n} C={c} occupied neighbours/point={occ:.2f}: {us:.1f} us/launch, "
+      f"{2.0 * n * occ * c * c / us / 1e6:.1f} TFLOP/s (occupied), gathered bytes {n * occ * c * 2 / 1e6:.1f} MB, "
+      f"index bytes {n * 27 * 4 / 1e6:.1f} MB")
