@@ -15,7 +15,10 @@
 // (Measured on the 480k-point stage-0 conv, profiles/r01l_pmc_conv_attention_raw.txt: HBM traffic = the compulsory
 // 82 MB, VALU 11 %, ~60 % of the wave cycles idle: a tile is a chain of dependent index -> row round trips.  Issuing
 // the loads of 2-4 K steps at once shortened the chain (196 -> 180 us) but the extra registers cost more overlap
-// with the other streams than that gained (37.5 -> 34.3 M points/s end to end), so the loop keeps one step in flight.)
+// with the other streams than that gained (37.5 -> 34.3 M points/s end to end), so the loop keeps one step in flight.
+// 128-row tiles (512 threads, half the W re-reads per row; every conv level of a 4-scene batch moves ~700 MB from
+// L2 into LDS at ~4.5 TB/s) were 10-18 % faster on levels 0 and 2 in isolation and 8 % SLOWER end to end
+// (38.1 -> 34.9 M points/s, same box): with three forwards sharing the CUs, resource-time per block is what counts.)
 // Sparse conv: the block first compacts the kernel offsets that ANY of its 64 rows has a
 // neighbour at (on z-ordered points: ~10-15 of 27) and reduces over those only; A chunks are
 // gathered through the neighbour table per 16-byte chunk, so one K step can span several offsets
