@@ -159,3 +159,29 @@ def test_coarse_orders_need_no_sort(name):
             keep = np.ones(len(v), dtype=bool)
             keep[1:] = v[1:] != v[:-1]
             assert np.array_equal(v[keep], ref), (name, pd, order)
+
+
+def test_inference_many_host_logic(emulated):
+    """inference_many on the emulated ops (CPU tensors: no lanes): batch=2 collates pairs of scenes into one forward
+    with cumulative offsets (the reference's collate_fn) and hands every scene its slice of the logits."""
+    from cdsegnet_amd.models import collate_device
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    cfg = configs.mini_config()
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=3), strict=True)
+    model.eval()
+    model.precision = "fp32"
+    scenes = [synth.room_scene(60 + i, n) for i, n in enumerate((700, 500, 900))]
+    dicts = [{k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")} for sc in scenes]
+    col = collate_device([dict(d) for d in dicts[:2]])
+    assert col["offset"].tolist() == [len(scenes[0]["coord"]), len(scenes[0]["coord"]) + len(scenes[1]["coord"])]
+    assert col["offset_host"] == col["offset"].tolist() and col["feat"].shape[0] == col["offset_host"][-1]
+    torch.manual_seed(1)
+    a = model.inference(dict(col), eval=False)["seg_logits"]
+    b = model.inference(dict(dicts[2]), eval=False)["seg_logits"]
+    torch.manual_seed(1)
+    outs = model.inference_many([dict(d) for d in dicts], lanes=3, batch=2)
+    n0 = len(scenes[0]["coord"])
+    assert torch.equal(outs[0]["seg_logits"], a[:n0]) and torch.equal(outs[1]["seg_logits"], a[n0:])
+    assert torch.equal(outs[2]["seg_logits"], b)
