@@ -16,9 +16,8 @@
 // 82 MB, VALU 11 %, ~60 % of the wave cycles idle: a tile is a chain of dependent index -> row round trips.  Issuing
 // the loads of 2-4 K steps at once shortened the chain (196 -> 180 us) but the extra registers cost more overlap
 // with the other streams than that gained (37.5 -> 34.3 M points/s end to end), so the loop keeps one step in flight.
-// 128-row tiles (512 threads, half the W re-reads per row; every conv level of a 4-scene batch moves ~700 MB from
-// L2 into LDS at ~4.5 TB/s) were 10-18 % faster on levels 0 and 2 in isolation and 8 % SLOWER end to end
-// (38.1 -> 34.9 M points/s, same box): with three forwards sharing the CUs, resource-time per block is what counts.)
+// What did help: 128-row tiles (8 waves, same per-wave tile), see launch_bn - but only once the LayerNorm epilogue
+// was compiled out of that variant: with it the kernel spilled 165 VGPRs and lost 8 % end to end.)
 // Sparse conv: the block first compacts the kernel offsets that ANY of its 64 rows has a
 // neighbour at (on z-ordered points: ~10-15 of 27) and reduces over those only; A chunks are
 // gathered through the neighbour table per 16-byte chunk, so one K step can span several offsets
@@ -306,21 +305,30 @@ __global__ __launch_bounds__(256) void row_finish_kernel(GemmP g) {
 }
 
 // CT: compute/storage type of A and W.  BN: tile width.  NCH: 16-byte chunks per LDS row.
-template <typename CT, int BN, int NCH, bool GATHER>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
-  constexpr int BM = 64;
-  constexpr int TN = BN / 32;  // 16-wide column tiles per wave (a wave owns 32 rows x BN/2 columns)
+// BM: rows per tile = 64 (4 waves) or 128 (8 waves); a wave always owns 32 rows x BN/2 columns.  The 128-row form
+// moves a third less A + W through L2 -> LDS per FLOP (the deep-stage linears are bound by that path, ~5 TB/s).
+template <typename CT, int BN, int NCH, bool GATHER, int BM = 64>
+__global__ __launch_bounds__(4 * BM, BM == 128 ? 4 : 1) void gemm_kernel(GemmP g) {
+  constexpr int NT = 4 * BM;   // threads
+  constexpr int TN = BN / 32;  // 16-wide column tiles per wave
   constexpr int RB = NCH * 16;
   constexpr int EPC = 16 / (int)sizeof(CT);  // elements per chunk
   constexpr int BK = NCH * EPC;
   constexpr int A_CH = BM * NCH, B_CH = BN * NCH;
-  constexpr int A_PT = (A_CH + 255) / 256, B_PT = (B_CH + 255) / 256;
+  constexpr int A_PT = (A_CH + NT - 1) / NT, B_PT = (B_CH + NT - 1) / NT;
   constexpr int CLD = BN + 4;  // padded fp32 C tile row (conflict-free MFMA-layout writes)
   constexpr int AB_BYTES = (BM + BN) * RB;
-  constexpr int C_BYTES = BM * CLD * 4;
+  constexpr int C_BYTES = 64 * CLD * 4;  // the epilogue goes through LDS 64 rows at a time
   constexpr int SM_BYTES = (AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES) + 1024;
 
-  __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+  char* smem;
+  if constexpr (SM_BYTES <= 65536) {
+    __shared__ __attribute__((aligned(16))) char static_smem[SM_BYTES];
+    smem = static_smem;
+  } else {  // launched with gemm_smem_bytes() of dynamic LDS
+    extern __shared__ __attribute__((aligned(16))) char dynamic_smem[];
+    smem = dynamic_smem;
+  }
   char* As = smem;
   char* Bs = smem + BM * RB;
   constexpr int TAILB = 1024;
@@ -362,8 +370,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
   if (GATHER) {
     if (tid < 2) smask[tid] = 0ull;
     __syncthreads();
-    {
-      const int r = tid >> 2;
+    for (int r = tid >> 2; r < BM; r += NT / 4) {
       const long m = m0 + r;
       if (m < g.M) {
         unsigned long long lo = 0ull, hi = 0ull;
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
   auto load_tiles = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      const int id = i * 256 + tid;
+      const int id = i * NT + tid;
       const int row = id / NCH, ch = id % NCH;
       const long m = m0 + row;
       const int kv = kc * BK + ch * EPC;
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
-      const int id = i * 256 + tid;
+      const int id = i * NT + tid;
       const int row = id / NCH, ch = id % NCH;
       const int kv = kc * BK + ch * EPC;
       b_reg[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -432,12 +439,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
   auto store_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      const int id = i * 256 + tid;
+      const int id = i * NT + tid;
       if (id < A_CH) *reinterpret_cast<uint4*>(As + lds_off<NCH>(id / NCH, id % NCH)) = a_reg[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
-      const int id = i * 256 + tid;
+      const int id = i * NT + tid;
       if (id < B_CH) *reinterpret_cast<uint4*>(Bs + lds_off<NCH>(id / NCH, id % NCH)) = b_reg[i];
     }
   };
@@ -508,23 +515,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
     __syncthreads();
   }
 
-  // ---- accumulators -> LDS C tile.  MFMA C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+  // ---- accumulators -> LDS C tile -> epilogue, 64 rows at a time.  MFMA C layout: col = lane & 15,
+  // row = (lane >> 4) * 4 + r
   float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+  for (int hh = 0; hh < BM / 64; ++hh) {
+    if (hh) __syncthreads();  // the previous 64 rows have left the C tile
+    int zcol = 0;  // opaque zero in the column index: keeps the per-column epilogue vectors from being hoisted out of
+    if constexpr (BM > 64) asm volatile("v_mov_b32 %0, 0" : "=v"(zcol));  // the loop (and into 100+ extra VGPRs)
+    if ((wm >> 1) == hh) {
+      const int rbase = (wm & 1) * 32;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
-  __syncthreads();
-
-  if (g.fix == 0) {
-    if (g.ln_pre_g || g.ln_post_g) {
-      // fused LayerNorm: the block holds complete rows; 4 lanes own one row, values stay in registers
+          for (int r = 0; r < 4; ++r)
+            Cs[(rbase + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    const long mb = m0 + 64 * hh;
+    constexpr int GPR = BN / 4;  // float4 groups per row
+    if (g.fix) {
+      // raw partial tile -> workspace; a second launch sums the splits and runs the (row) epilogue
+      for (int item = tid; item < 64 * GPR; item += NT) {
+        const int row = item / GPR, cg = item % GPR;
+        const long m = mb + row;
+        const int n = n0 + 4 * cg;
+        if (m >= g.M || n >= g.N) continue;
+        *reinterpret_cast<float4*>(g.ws + ((long)zs * g.M + m) * g.N + n) =
+            *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
+      }
+    } else if (BM == 64 && (g.ln_pre_g || g.ln_post_g)) {
+      // fused LayerNorm (64-row launches only): the block holds complete rows; 4 lanes own one row, values stay
+      // in registers
       constexpr int MAXG = BN / 16;
-      const int row = tid >> 2, part = tid & 3;
-      const long m = m0 + row;
+      const int row = (tid >> 2) & 63, part = tid & 3;
+      const long m = mb + row;
       const int ng = g.N >> 2;
       float4 v[MAXG];
 #pragma unroll
@@ -532,32 +559,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
         v[i] = (part + 4 * i < ng) ? *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * (part + 4 * i))
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
       finish_row<MAXG>(g, m, m < g.M, part, 4, ng, 0, v);
-      return;
+    } else {
+      // epilogue on row-contiguous groups of 4 columns
+      for (int item = tid; item < 64 * GPR; item += NT) {
+        const int row = item / GPR, cg = item % GPR;
+        const long m = mb + row;
+        const int n = n0 + 4 * cg + zcol;
+        if (m >= g.M || n >= g.N) continue;
+        epilogue4(g, m, n, *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg));
+      }
     }
-    // epilogue on row-contiguous groups of 4 columns
-    constexpr int GPR = BN / 4;  // groups per row
-    for (int item = tid; item < BM * GPR; item += 256) {
-      const int row = item / GPR, cg = item % GPR;
-      const long m = m0 + row;
-      const int n = n0 + 4 * cg;
-      if (m >= g.M || n >= g.N) continue;
-      epilogue4(g, m, n, *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg));
-    }
-    return;
   }
+}
 
-  // ---- raw partial tile -> workspace; a second launch sums the splits and runs the (row) epilogue
-  {
-    constexpr int GPR = BN / 4;
-    for (int item = tid; item < BM * GPR; item += 256) {
-      const int row = item / GPR, cg = item % GPR;
-      const long m = m0 + row;
-      const int n = n0 + 4 * cg;
-      if (m >= g.M || n >= g.N) continue;
-      *reinterpret_cast<float4*>(g.ws + ((long)zs * g.M + m) * g.N + n) =
-          *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
-    }
-  }
+template <typename CT, int BN, int NCH, int BM>
+constexpr int gemm_smem_bytes() {
+  constexpr int ab = (BM + BN) * NCH * 16, c = 64 * (BN + 4) * 4;
+  return (ab > c ? ab : c) + 1024;
 }
 
 int env_int(const char* name, int dflt) {
@@ -575,8 +593,14 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   static const int split_target = env_int("CDSEG_GEMM_SPLIT_TARGET", 512);
   static const int split_max = env_int("CDSEG_GEMM_SPLIT_MAX", 32);
   static const int xmode_env = env_int("CDSEG_GEMM_XMODE", -1);
-  const int gm = (int)((p.M + 63) / 64);
   const bool ln = p.ln_pre_g || p.ln_post_g;
+  // sparse convs: 128-row tiles (8 waves): half the W re-reads per row through L2 -> LDS, the path every conv level is
+  // bound by (stage-0 conv of a 4-scene batch 196 -> 123 us, +2 % end to end).  The same tiles for the wide deep-stage
+  // linears were neutral (-1 %) and are not instantiated.
+  static const int conv_bm = env_int("CDSEG_CONV_BM", 128);
+  const bool tall = GATHER && NCH == 16 && conv_bm == 128 && p.M > 64 && !ln;
+  const int bm = tall ? 128 : 64;
+  const int gm = (int)((p.M + bm - 1) / bm);
   // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
   const int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
   const int gn = (p.N + bn - 1) / bn;
@@ -618,9 +642,32 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   else if (p.xmode == 2) nblk = 8u * (unsigned)((gm + 7) / 8) * (unsigned)slices;
   else nblk = (unsigned)gm * (unsigned)slices;
   const dim3 grid(nblk);
-  if (bn == 32) hipLaunchKernelGGL((gemm_kernel<CT, 32, NCH, GATHER>), grid, dim3(256), 0, s, p);
-  else if (bn == 64) hipLaunchKernelGGL((gemm_kernel<CT, 64, NCH, GATHER>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<CT, 128, NCH, GATHER>), grid, dim3(256), 0, s, p);
+  bool launched = false;
+  if constexpr (GATHER && NCH == 16) {
+    if (tall) {
+      launched = true;
+      if (bn == 32) {
+        hipLaunchKernelGGL((gemm_kernel<CT, 32, 16, GATHER, 128>), grid, dim3(512), 0, s, p);
+      } else if (bn == 64) {
+        hipLaunchKernelGGL((gemm_kernel<CT, 64, 16, GATHER, 128>), grid, dim3(512), 0, s, p);
+      } else {
+        constexpr int smem = gemm_smem_bytes<CT, 128, 16, 128>();  // 65 KB: above the static LDS limit
+        static bool attr_done = false;
+        if (!attr_done) {
+          if (hipFuncSetAttribute((const void*)gemm_kernel<CT, 128, 16, GATHER, 128>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return CDSEG_ERR_LAUNCH;
+          attr_done = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<CT, 128, 16, GATHER, 128>), grid, dim3(512), smem, s, p);
+      }
+    }
+  }
+  if (!launched) {
+    if (bn == 32) hipLaunchKernelGGL((gemm_kernel<CT, 32, NCH, GATHER>), grid, dim3(256), 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((gemm_kernel<CT, 64, NCH, GATHER>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<CT, 128, NCH, GATHER>), grid, dim3(256), 0, s, p);
+  }
   if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
   if (p.fix == 2) {
     hipLaunchKernelGGL(row_finish_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
