@@ -12,7 +12,7 @@
 // A / W K-tiles are staged through LDS in 16-byte chunks with an XOR swizzle that makes every
 // ds_read_b128 of an MFMA fragment bank-conflict free (tools/lds_conflicts.py); global loads of
 // step k+1 are in flight during the MFMAs of step k (register double buffering).
-// (Measured on the 480k-point stage-0 conv, profiles/r01l_pmc_conv_attention_raw.txt: HBM traffic = the compulsory
+// (Measured on the 480k-point stage-0 conv, profiles/r01l_pmc_conv_attention.txt: HBM traffic = the compulsory
 // 82 MB, VALU 11 %, ~60 % of the wave cycles idle: a tile is a chain of dependent index -> row round trips.  Issuing
 // the loads of 2-4 K steps at once shortened the chain (196 -> 180 us) but the extra registers cost more overlap
 // with the other streams than that gained (37.5 -> 34.3 M points/s end to end), so the loop keeps one step in flight.
