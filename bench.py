@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-baseline", dest="cpu_baseline", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
-    ap.add_argument("--cpu-points", type=int, default=12000)
+    ap.add_argument("--cpu-points", type=int, default=24000)
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the roofline pass after the timed region")
     ap.add_argument("--time-in-region", action="store_true",
                     help="also record HIP events around the attention launches INSIDE the timed region (costs ~5 %% "
