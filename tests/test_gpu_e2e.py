@@ -365,3 +365,54 @@ def test_inference_many_batched_equals_collated_forward():
     assert len(got) == len(dicts)
     for a, b in zip(got, want):
         assert torch.equal(a["seg_logits"], b)
+
+
+def test_inference_many_full_scale_streams_are_race_free():
+    """Full-width model, 30k-120k-point scenes: three lanes x batches of two must reproduce the sequential
+    collated forwards bit for bit (kernels long enough that a missing stream dependency would show), twice."""
+    from cdsegnet_amd.models import collate_device
+    cfg = configs.cdsegnet_config("scannet")
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0), strict=True)
+    model = model.to("cuda").eval()
+    model.precision = "bf16"
+    model.noise_source = "device"
+    sizes = (120000, 30000, 60000, 120000, 45000, 90000, 120000)
+    scenes = [synth.room_scene(70 + i, n) for i, n in enumerate(sizes)]
+    dicts = []
+    for sc in scenes:
+        d = {k: torch.as_tensor(sc[k]).cuda() for k in ("coord", "grid_coord", "feat", "offset")}
+        d["offset_host"] = [int(v) for v in sc["offset"]]
+        dicts.append(d)
+    eng = model.engine()
+    torch.manual_seed(3)
+    eng.rng_offset = 0
+    want = []
+    for i in range(0, len(dicts), 2):
+        g = dicts[i:i + 2]
+        o = model.inference_many([collate_device([dict(d) for d in g])], lanes=1)[0]["seg_logits"]
+        pos = 0
+        for d in g:
+            want.append(o[pos:pos + d["feat"].shape[0]].clone())
+            pos += d["feat"].shape[0]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        torch.manual_seed(3)
+        eng.rng_offset = 0
+        got = model.inference_many([dict(d) for d in dicts], lanes=3, batch=2)
+        torch.cuda.synchronize()
+        for j, (a, b) in enumerate(zip(got, want)):
+            assert torch.isfinite(a["seg_logits"]).all()
+            assert torch.equal(a["seg_logits"], b), (rep, j)
+    # and the single-scene fork (side stream) against the serial order at full scale
+    keep = eng.fork_stage
+    try:
+        outs = []
+        for fs in (None, 1):
+            eng.fork_stage = fs
+            torch.manual_seed(4)
+            eng.rng_offset = 0
+            outs.append(model.inference(dict(dicts[0]), eval=False)["seg_logits"].clone())
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        eng.fork_stage = keep
