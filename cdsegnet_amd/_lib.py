@@ -99,6 +99,8 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cdseg_iou_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "cdseg_mlp_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                c_long, c_int, c_int, c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
     "cdseg_stem_conv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,

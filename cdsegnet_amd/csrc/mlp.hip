@@ -1,0 +1,185 @@
+// Fused PTv3 MLP for the wide-and-shallow stages (C = 32 / 64 at 55k - 120k points per scene):
+//     x += fc2(GELU(fc1(h))) ;  xc = T(x)              ref: ptv3.py:299-322 (MLP), :423-427 (Block tail)
+// As two GEMM launches the 4C-wide hidden activation makes a round trip through HBM (write + read: 246 MB per
+// launch pair for a 4-scene batch at C = 64), which is most of what those launches move.  Here a workgroup owns 64
+// rows: the hidden tile (64 x 128) is produced by MFMA from the h rows in LDS, passed through bias + GELU, rounded to
+// bf16 (exactly what the unfused path stored) and consumed from LDS as the A operand of the second product; only
+// h, the residual and the two outputs touch HBM.  bf16 only (the fp32 parity mode keeps the two-GEMM form).
+#include "common.h"
+
+namespace {
+
+struct MlpP {
+  const bf16_t* h;   // (n, ldh) LayerNorm output
+  const bf16_t* w1;  // (4C, C)
+  const float* b1;   // (4C)
+  const bf16_t* w2;  // (C, 4C)
+  const float* b2;   // (C)
+  float* x;          // (n, ldx) fp32 residual stream, updated in place
+  bf16_t* xc;        // (n, ldxc) bf16 shadow of x, or nullptr
+  long n;
+  int ldh, ldx, ldxc;
+};
+
+template <int NCH>
+__device__ __forceinline__ int mlp_lds_off(int row, int chunk) {
+  constexpr int RB = NCH * 16;
+  const int sw = NCH == 16 ? (row & 15) : ((row >> 1) & (NCH - 1));
+  return row * RB + ((chunk ^ sw) << 4);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
+  constexpr int HID = 4 * C;
+  constexpr int NJ = HID / 128;   // hidden tiles of 128
+  constexpr int NCA = C / 8;      // 16-byte chunks per h / W1 row (4 or 8)
+  constexpr int TN2 = C / 32;     // 16-wide output column tiles per wave (wave: 32 rows x C/2 columns)
+  constexpr int A_BYTES = 64 * C * 2, W1_BYTES = 128 * C * 2, H_BYTES = 64 * 256, W2_BYTES = C * 256;
+  constexpr int CLD = C + 4;
+  static_assert(64 * CLD * 4 <= H_BYTES + W2_BYTES, "C tile must fit the H + W2 region");
+  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W1_BYTES + H_BYTES + W2_BYTES];
+  char* As = smem;
+  char* W1s = smem + A_BYTES;
+  char* Hs = W1s + W1_BYTES;
+  char* W2s = Hs + H_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const long m0 = (long)blockIdx.x * 64;
+
+  // h rows -> LDS (once)
+  for (int id = tid; id < 64 * NCA; id += 256) {
+    const int row = id / NCA, ch = id % NCA;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (m0 + row < p.n) v = *reinterpret_cast<const uint4*>(p.h + (m0 + row) * p.ldh + ch * 8);
+    *reinterpret_cast<uint4*>(As + mlp_lds_off<NCA>(row, ch)) = v;
+  }
+
+  f32x4_t acc2[2][TN2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < TN2; ++t) acc2[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int j = 0; j < NJ; ++j) {
+    // W1 rows [128 j, 128 j + 128) and W2 columns [128 j, 128 j + 128) -> LDS
+    for (int id = tid; id < 128 * NCA; id += 256) {
+      const int row = id / NCA, ch = id % NCA;
+      *reinterpret_cast<uint4*>(W1s + mlp_lds_off<NCA>(row, ch)) =
+          *reinterpret_cast<const uint4*>(p.w1 + (long)(128 * j + row) * C + ch * 8);
+    }
+    for (int id = tid; id < C * 16; id += 256) {
+      const int row = id / 16, ch = id % 16;
+      *reinterpret_cast<uint4*>(W2s + mlp_lds_off<16>(row, ch)) =
+          *reinterpret_cast<const uint4*>(p.w2 + (long)row * HID + 128 * j + ch * 8);
+    }
+    __syncthreads();
+
+    // ---- hidden tile = h W1_j^T : wave (wm, wn) owns rows 32 wm .. +32, hidden columns 64 wn .. +64
+    f32x4_t acc1[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc1[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NCA / 4; ++kk) {
+      bf16x8_t a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const bf16x8_t*>(As + mlp_lds_off<NCA>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        b[t] = *reinterpret_cast<const bf16x8_t*>(W1s + mlp_lds_off<NCA>(wn * 64 + t * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc1[i][t], 0, 0, 0);
+    }
+    // bias + GELU + bf16 -> Hs in A-operand layout.  MFMA C layout: col = lane & 15, row = 4 (lane >> 4) + r
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = wn * 64 + t * 16 + fr;
+      const float bias = p.b1[128 * j + col];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 32 + i * 16 + fg * 4 + r;
+          *reinterpret_cast<bf16_t*>(Hs + mlp_lds_off<16>(row, col >> 3) + (col & 7) * 2) =
+              f32_to_bf16(gelu_erf(acc1[i][t][r] + bias));
+        }
+    }
+    __syncthreads();
+
+    // ---- acc2 += H_j W2_j^T : K = 128
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t a[2], b[TN2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const bf16x8_t*>(Hs + mlp_lds_off<16>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int t = 0; t < TN2; ++t)
+        b[t] = *reinterpret_cast<const bf16x8_t*>(W2s + mlp_lds_off<16>(wn * (C / 2) + t * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < TN2; ++t) acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc2[i][t], 0, 0, 0);
+    }
+    __syncthreads();  // W1s / W2s / Hs are rewritten by the next hidden tile (or become the C tile)
+  }
+
+  // ---- epilogue through an fp32 C tile (aliases Hs + W2s): + b2 + residual, row-contiguous 16-byte accesses
+  float* Cs = reinterpret_cast<float*>(Hs);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < TN2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (C / 2) + t * 16 + fr] = acc2[i][t][r];
+  __syncthreads();
+  constexpr int GPR = C / 4;
+  for (int item = tid; item < 64 * GPR; item += 256) {
+    const int row = item / GPR, cg = item % GPR;
+    const long m = m0 + row;
+    if (m >= p.n) continue;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
+    const float4 b = *reinterpret_cast<const float4*>(p.b2 + 4 * cg);
+    float* xr = p.x + m * p.ldx + 4 * cg;
+    const float4 r = *reinterpret_cast<const float4*>(xr);
+    v.x += b.x + r.x; v.y += b.y + r.y; v.z += b.z + r.z; v.w += b.w + r.w;
+    *reinterpret_cast<float4*>(xr) = v;
+    if (p.xc) {
+      uint2 u;
+      u.x = pack_bf16x2(v.x, v.y);
+      u.y = pack_bf16x2(v.z, v.w);
+      *reinterpret_cast<uint2*>(p.xc + m * p.ldxc + 4 * cg) = u;
+    }
+  }
+}
+
+}  // namespace
+
+// x (n, ldx) fp32 += fc2(GELU(fc1(h))) with h (n, ldh) bf16; xc (n, ldxc) bf16 copy of the new x, or NULL.
+// Supported: bf16, C = 32 or 64 (hidden 4C), row strides multiples of 8 (h) / 4 (x, xc), 16-byte aligned pointers.
+extern "C" int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const float* b1, const void* w2, const float* b2,
+                               float* x, int ldx, void* xc, int ldxc, long n, int channels, int dtype, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (!h || !w1 || !b1 || !w2 || !b2 || !x) return CDSEG_ERR_ARG;
+  if (dtype != CDSEG_BF16 || (channels != 32 && channels != 64)) return CDSEG_ERR_UNSUPPORTED;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if ((ldh & 7) || (ldx & 3) || (xc && (ldxc & 3)) || !al16(h) || !al16(w1) || !al16(w2) || !al16(x) || !al16(b2) ||
+      (xc && (((uintptr_t)xc) & 7)))
+    return CDSEG_ERR_ARG;
+  MlpP p;
+  p.h = (const bf16_t*)h; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2;
+  p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldh = ldh; p.ldx = ldx; p.ldxc = ldxc;
+  const dim3 grid((unsigned)((n + 63) / 64));
+  if (channels == 32) hipLaunchKernelGGL(mlp_fused_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(mlp_fused_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}

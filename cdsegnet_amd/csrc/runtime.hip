@@ -1,6 +1,7 @@
 // Native executor for one PTv3 Block (ref: ptv3.py:399-428): issues all launches of the block
 // from C++ so the Python binding pays one call instead of ~10 (the per-launch host cost of the
 // binding, ~10 us, was the step's critical path once the kernels were fast).
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -138,6 +139,15 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
       return rc;
   }
   // ---- MLP: x += fc2(GELU(fc1(h)));  xc = T(x)                            (ptv3.py:423-427)
+  static const bool fused_mlp = []() { const char* e = getenv("CDSEG_FUSED_MLP"); return !(e && e[0] == '0'); }();
+  if (fused_mlp && T == CDSEG_BF16 && (C == 32 || C == 64) && d->hidden == 4 * C) {
+    // big stages: one kernel, the 4C hidden activation stays in LDS (mlp.hip)
+    void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
+    if ((rc = cdseg_mlp_fused(L.h, C, d->fc1_w, (const float*)d->fc1_b, d->fc2_w, (const float*)d->fc2_b, (float*)io->x, C,
+                              xc, C, n, C, T, stream)) != CDSEG_OK)
+      return rc;
+    return CDSEG_OK;
+  }
   {
     cdseg_gemm_args a = base_args(d, L, n);
     a.A = L.h; a.lda = C; a.W = d->fc1_w; a.bias = d->fc1_b; a.N = d->hidden; a.K = C; a.act = CDSEG_ACT_GELU;

@@ -471,6 +471,10 @@ class Engine:
             h = self._buf(n, c, self.T)
             ops.layernorm(st.x, w[pre_norm + ".g"], w[pre_norm + ".b"], h)
         hid = w[pre_fc + "1.w"].shape[0]
+        if ops.mlp_fused_ok(h, hid):  # big stages (C = 32 / 64): one kernel, the hidden activation stays in LDS
+            st.xc = self._buf(n, c, self.T)
+            ops.mlp_fused(h, w[pre_fc + "1.w"], w[pre_fc + "1.b"], w[pre_fc + "2.w"], w[pre_fc + "2.b"], st.x, st.xc)
+            return
         u = self._buf(n, hid, self.T)
         ops.gemm(h, w[pre_fc + "1.w"], u, bias=w[pre_fc + "1.b"], act=ops.ACT_GELU)
         if self.T == torch.float32:

@@ -5,6 +5,7 @@ marshalling layer: PyTorch provides device memory and the stream, every computat
 the hand-written HIP kernels of libcdseg_hip.so.  No fallbacks: tensors must live on a GPU.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -455,6 +456,25 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     if tok is not None:
         TIMER.end(tok, 2.0 * a.M * a.N * a.K * a.kvol)
     return out
+
+
+FUSED_MLP_CHANNELS = (32, 64)
+
+
+def mlp_fused_ok(h, hidden):
+    """The fused MLP kernel covers bf16 with C = 32 / 64 and the standard 4x hidden width."""
+    c = h.shape[1]
+    return (h.dtype == torch.bfloat16 and c in FUSED_MLP_CHANNELS and hidden == 4 * c and
+            os.environ.get("CDSEG_FUSED_MLP", "1") != "0")
+
+
+def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
+    """x += fc2(GELU(fc1(h))), xc = bf16(x); the hidden activation never leaves the CU."""
+    _need_gpu(h, x)
+    check(_lib.load().cdseg_mlp_fused(_ptr(h), h.stride(0), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(x), x.stride(0),
+                                       _ptr(xc), xc.stride(0) if xc is not None else 0, h.shape[0], h.shape[1], _DT[h.dtype],
+                                       _stream()), "mlp_fused")
+    return x
 
 
 def _dp(t):

@@ -199,6 +199,19 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     return out
 
 
+def mlp_fused_ok(h, hidden):
+    c = h.shape[1]
+    return h.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c
+
+
+def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
+    u = F.gelu(h.float() @ w1.float().t() + b1).to(torch.bfloat16)
+    x += u.float() @ w2.float().t() + b2
+    if xc is not None:
+        xc.copy_(x.to(xc.dtype))
+    return x
+
+
 def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):
     kvol, cin, cout = w_packed.shape
     v = torch.zeros(x.shape[0], cout)
