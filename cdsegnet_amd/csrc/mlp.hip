@@ -1,8 +1,8 @@
-// Fused PTv3 MLP for the wide-and-shallow stages (C = 32 / 64 at 55k - 120k points per scene):
+// Fused PTv3 MLP for the big stages (C = 32 / 64 / 128 at 14k - 120k points per scene):
 //     x += fc2(GELU(fc1(h))) ;  xc = T(x)              ref: ptv3.py:299-322 (MLP), :423-427 (Block tail)
 // As two GEMM launches the 4C-wide hidden activation makes a round trip through HBM (write + read: 246 MB per
 // launch pair for a 4-scene batch at C = 64), which is most of what those launches move.  Here a workgroup owns 64
-// rows: the hidden tile (64 x 128) is produced by MFMA from the h rows in LDS, passed through bias + GELU, rounded to
+// rows: the hidden tile (64 x 64) is produced by MFMA from the h rows in LDS, passed through bias + GELU, rounded to
 // bf16 (exactly what the unfused path stored) and consumed from LDS as the A operand of the second product; only
 // h, the residual and the two outputs touch HBM.  bf16 only (the fp32 parity mode keeps the two-GEMM form).
 #include "common.h"
@@ -28,15 +28,18 @@ __device__ __forceinline__ int mlp_lds_off(int row, int chunk) {
   return row * RB + ((chunk ^ sw) << 4);
 }
 
-template <int C>
+// HT: hidden columns per tile
+template <int C, int HT>
 __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
   constexpr int HID = 4 * C;
-  constexpr int NJ = HID / 128;   // hidden tiles of 128
-  constexpr int NCA = C / 8;      // 16-byte chunks per h / W1 row (4 or 8)
+  constexpr int NJ = HID / HT;    // hidden tiles
+  constexpr int NCA = C / 8;      // 16-byte chunks per h / W1 row (4, 8 or 16)
+  constexpr int NCH = HT / 8;     // 16-byte chunks per H / W2-tile row (16 or 8)
+  constexpr int TN1 = HT / 32;    // 16-wide hidden column tiles per wave (wave: 32 rows x HT/2 hidden columns)
   constexpr int TN2 = C / 32;     // 16-wide output column tiles per wave (wave: 32 rows x C/2 columns)
-  constexpr int A_BYTES = 64 * C * 2, W1_BYTES = 128 * C * 2, H_BYTES = 64 * 256, W2_BYTES = C * 256;
+  constexpr int A_BYTES = 64 * C * 2, W1_BYTES = HT * C * 2, H_BYTES = 64 * HT * 2, W2_BYTES = C * HT * 2;
   constexpr int CLD = C + 4;
-  static_assert(64 * CLD * 4 <= H_BYTES + W2_BYTES, "C tile must fit the H + W2 region");
+  static_assert(64 * CLD * 4 <= W1_BYTES + H_BYTES + W2_BYTES, "C tile must fit the W1 + H + W2 region");
   __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W1_BYTES + H_BYTES + W2_BYTES];
   char* As = smem;
   char* W1s = smem + A_BYTES;
@@ -64,65 +67,66 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
 
 #pragma unroll 1
   for (int j = 0; j < NJ; ++j) {
-    // W1 rows [128 j, 128 j + 128) and W2 columns [128 j, 128 j + 128) -> LDS
-    for (int id = tid; id < 128 * NCA; id += 256) {
+    // W1 rows [HT j, HT j + HT) and W2 columns [HT j, HT j + HT) -> LDS
+    for (int id = tid; id < HT * NCA; id += 256) {
       const int row = id / NCA, ch = id % NCA;
       *reinterpret_cast<uint4*>(W1s + mlp_lds_off<NCA>(row, ch)) =
-          *reinterpret_cast<const uint4*>(p.w1 + (long)(128 * j + row) * C + ch * 8);
+          *reinterpret_cast<const uint4*>(p.w1 + (long)(HT * j + row) * C + ch * 8);
     }
-    for (int id = tid; id < C * 16; id += 256) {
-      const int row = id / 16, ch = id % 16;
-      *reinterpret_cast<uint4*>(W2s + mlp_lds_off<16>(row, ch)) =
-          *reinterpret_cast<const uint4*>(p.w2 + (long)row * HID + 128 * j + ch * 8);
+    for (int id = tid; id < C * NCH; id += 256) {
+      const int row = id / NCH, ch = id % NCH;
+      *reinterpret_cast<uint4*>(W2s + mlp_lds_off<NCH>(row, ch)) =
+          *reinterpret_cast<const uint4*>(p.w2 + (long)row * HID + HT * j + ch * 8);
     }
     __syncthreads();
 
-    // ---- hidden tile = h W1_j^T : wave (wm, wn) owns rows 32 wm .. +32, hidden columns 64 wn .. +64
-    f32x4_t acc1[2][4];
+    // ---- hidden tile = h W1_j^T : wave (wm, wn) owns rows 32 wm .. +32, hidden columns (HT/2) wn .. +HT/2
+    f32x4_t acc1[2][TN1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc1[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < TN1; ++t) acc1[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < NCA / 4; ++kk) {
-      bf16x8_t a[2], b[4];
+      bf16x8_t a[2], b[TN1];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         a[i] = *reinterpret_cast<const bf16x8_t*>(As + mlp_lds_off<NCA>(wm * 32 + i * 16 + fr, 4 * kk + fg));
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        b[t] = *reinterpret_cast<const bf16x8_t*>(W1s + mlp_lds_off<NCA>(wn * 64 + t * 16 + fr, 4 * kk + fg));
+      for (int t = 0; t < TN1; ++t)
+        b[t] = *reinterpret_cast<const bf16x8_t*>(W1s + mlp_lds_off<NCA>(wn * (HT / 2) + t * 16 + fr, 4 * kk + fg));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc1[i][t], 0, 0, 0);
+        for (int t = 0; t < TN1; ++t)
+          acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc1[i][t], 0, 0, 0);
     }
     // bias + GELU + bf16 -> Hs in A-operand layout.  MFMA C layout: col = lane & 15, row = 4 (lane >> 4) + r
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = wn * 64 + t * 16 + fr;
-      const float bias = p.b1[128 * j + col];
+    for (int t = 0; t < TN1; ++t) {
+      const int col = wn * (HT / 2) + t * 16 + fr;
+      const float bias = p.b1[HT * j + col];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wm * 32 + i * 16 + fg * 4 + r;
-          *reinterpret_cast<bf16_t*>(Hs + mlp_lds_off<16>(row, col >> 3) + (col & 7) * 2) =
+          *reinterpret_cast<bf16_t*>(Hs + mlp_lds_off<NCH>(row, col >> 3) + (col & 7) * 2) =
               f32_to_bf16(gelu_erf(acc1[i][t][r] + bias));
         }
     }
     __syncthreads();
 
-    // ---- acc2 += H_j W2_j^T : K = 128
+    // ---- acc2 += H_j W2_j^T : K = HT
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < NCH / 4; ++kk) {
       bf16x8_t a[2], b[TN2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        a[i] = *reinterpret_cast<const bf16x8_t*>(Hs + mlp_lds_off<16>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+        a[i] = *reinterpret_cast<const bf16x8_t*>(Hs + mlp_lds_off<NCH>(wm * 32 + i * 16 + fr, 4 * kk + fg));
 #pragma unroll
       for (int t = 0; t < TN2; ++t)
-        b[t] = *reinterpret_cast<const bf16x8_t*>(W2s + mlp_lds_off<16>(wn * (C / 2) + t * 16 + fr, 4 * kk + fg));
+        b[t] = *reinterpret_cast<const bf16x8_t*>(W2s + mlp_lds_off<NCH>(wn * (C / 2) + t * 16 + fr, 4 * kk + fg));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -131,8 +135,8 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
     __syncthreads();  // W1s / W2s / Hs are rewritten by the next hidden tile (or become the C tile)
   }
 
-  // ---- epilogue through an fp32 C tile (aliases Hs + W2s): + b2 + residual, row-contiguous 16-byte accesses
-  float* Cs = reinterpret_cast<float*>(Hs);
+  // ---- epilogue through an fp32 C tile (aliases W1s + Hs + W2s): + b2 + residual, row-contiguous 16-byte accesses
+  float* Cs = reinterpret_cast<float*>(W1s);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -164,12 +168,12 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
 }  // namespace
 
 // x (n, ldx) fp32 += fc2(GELU(fc1(h))) with h (n, ldh) bf16; xc (n, ldxc) bf16 copy of the new x, or NULL.
-// Supported: bf16, C = 32 or 64 (hidden 4C), row strides multiples of 8 (h) / 4 (x, xc), 16-byte aligned pointers.
+// Supported: bf16, C = 32, 64 or 128 (hidden 4C), row strides multiples of 8 (h) / 4 (x, xc), 16-byte aligned pointers.
 extern "C" int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const float* b1, const void* w2, const float* b2,
                                float* x, int ldx, void* xc, int ldxc, long n, int channels, int dtype, void* stream) {
   if (n <= 0) return CDSEG_OK;
   if (!h || !w1 || !b1 || !w2 || !b2 || !x) return CDSEG_ERR_ARG;
-  if (dtype != CDSEG_BF16 || (channels != 32 && channels != 64)) return CDSEG_ERR_UNSUPPORTED;
+  if (dtype != CDSEG_BF16 || (channels != 32 && channels != 64 && channels != 128)) return CDSEG_ERR_UNSUPPORTED;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   if ((ldh & 7) || (ldx & 3) || (xc && (ldxc & 3)) || !al16(h) || !al16(w1) || !al16(w2) || !al16(x) || !al16(b2) ||
       (xc && (((uintptr_t)xc) & 7)))
@@ -178,8 +182,11 @@ extern "C" int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const flo
   p.h = (const bf16_t*)h; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2;
   p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldh = ldh; p.ldx = ldx; p.ldxc = ldxc;
   const dim3 grid((unsigned)((n + 63) / 64));
-  if (channels == 32) hipLaunchKernelGGL(mlp_fused_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(mlp_fused_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  // 64-wide hidden tiles: 20 / 32 / 56 KB of LDS per workgroup (C = 32 / 64 / 128).  128-wide tiles were measured 2-3 %
+  // slower end to end at C = 64 (56 KB: two workgroups per CU instead of five) and equal at C = 32.
+  if (channels == 32) hipLaunchKernelGGL((mlp_fused_kernel<32, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (channels == 64) hipLaunchKernelGGL((mlp_fused_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((mlp_fused_kernel<128, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

@@ -140,7 +140,8 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
   }
   // ---- MLP: x += fc2(GELU(fc1(h)));  xc = T(x)                            (ptv3.py:423-427)
   static const bool fused_mlp = []() { const char* e = getenv("CDSEG_FUSED_MLP"); return !(e && e[0] == '0'); }();
-  if (fused_mlp && T == CDSEG_BF16 && (C == 32 || C == 64) && d->hidden == 4 * C) {
+  static const int fused_maxc = []() { const char* e = getenv("CDSEG_FUSED_MLP_MAXC"); return e ? atoi(e) : 128; }();
+  if (fused_mlp && T == CDSEG_BF16 && (C == 32 || C == 64 || C == 128) && C <= fused_maxc && d->hidden == 4 * C) {
     // big stages: one kernel, the 4C hidden activation stays in LDS (mlp.hip)
     void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
     if ((rc = cdseg_mlp_fused(L.h, C, d->fc1_w, (const float*)d->fc1_b, d->fc2_w, (const float*)d->fc2_b, (float*)io->x, C,

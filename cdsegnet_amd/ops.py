@@ -458,14 +458,14 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     return out
 
 
-FUSED_MLP_CHANNELS = (32, 64)
+FUSED_MLP_CHANNELS = (32, 64, 128)
 
 
 def mlp_fused_ok(h, hidden):
-    """The fused MLP kernel covers bf16 with C = 32 / 64 and the standard 4x hidden width."""
+    """The fused MLP kernel covers bf16 with C = 32 / 64 / 128 and the standard 4x hidden width."""
     c = h.shape[1]
     return (h.dtype == torch.bfloat16 and c in FUSED_MLP_CHANNELS and hidden == 4 * c and
-            os.environ.get("CDSEG_FUSED_MLP", "1") != "0")
+            c <= int(os.environ.get("CDSEG_FUSED_MLP_MAXC", "128")) and os.environ.get("CDSEG_FUSED_MLP", "1") != "0")
 
 
 def mlp_fused(h, w1, b1, w2, b2, x, xc=None):

@@ -275,7 +275,7 @@ int cdseg_iou_counts(const int32_t* pred, const int32_t* pred_idx, const int32_t
 
 /* ------------------------------------------------------------------ fused MLP (ref: ptv3.py:299-322, :423-427)
  * x (n, ldx) fp32 += fc2(GELU(fc1(h))), h (n, ldh); xc (n, ldxc) = typed copy of the new x or NULL.  The 4C hidden
- * activation stays in LDS.  Supported: dtype bf16, channels 32 or 64 (hidden = 4 * channels); else
+ * activation stays in LDS.  Supported: dtype bf16, channels 32, 64 or 128 (hidden = 4 * channels); else
  * CDSEG_ERR_UNSUPPORTED (callers fall back to two cdseg_gemm launches). */
 int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
                     int ldx, void* xc, int ldxc, long n, int channels, int dtype, void* stream);

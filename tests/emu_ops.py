@@ -201,7 +201,7 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
 
 def mlp_fused_ok(h, hidden):
     c = h.shape[1]
-    return h.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c
+    return h.dtype == torch.bfloat16 and c in (32, 64, 128) and hidden == 4 * c
 
 
 def mlp_fused(h, w1, b1, w2, b2, x, xc=None):

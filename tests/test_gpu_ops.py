@@ -756,7 +756,7 @@ def test_kernel_map_from_parent_equals_search(ops, name):
             assert torch.equal(got, want), (ksize, kmajor)
 
 
-@pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 32), (70, 64), (120000, 32)])
+@pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 32), (70, 64), (120000, 32), (4097, 128), (14293, 128)])
 def test_mlp_fused_vs_two_gemms_and_fp64(ops, M, C):
     """cdseg_mlp_fused (hidden activation kept in LDS) against the two-GEMM form and an fp64 reference that rounds
     the hidden activation to bf16 at the same place (ptv3.py:299-322, :423-427)."""
