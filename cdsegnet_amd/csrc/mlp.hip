@@ -19,6 +19,12 @@ struct MlpP {
   bf16_t* xc;        // (n, ldxc) bf16 shadow of x, or nullptr
   long n;
   int ldh, ldx, ldxc;
+  // PROJ form (attention tail fused in front): h is the attention output o; x += proj(o); h' = LN2(x) feeds the MLP
+  const bf16_t* wp;   // (C, C)
+  const float* bp;    // (C)
+  const float* ln_g;  // (C)
+  const float* ln_b;
+  float ln_eps;
 };
 
 template <int NCH>
@@ -29,7 +35,10 @@ __device__ __forceinline__ int mlp_lds_off(int row, int chunk) {
 }
 
 // HT: hidden columns per tile
-template <int C, int HT>
+// PROJ: the block's tail after attention in one kernel (ptv3.py:416-427):
+//     x += proj(o) ;  h = LN2(x) ;  x += fc2(GELU(fc1(h))) ;  xc = T(x)
+// the updated residual rows wait in LDS (fp32) while the MLP runs, h never exists in HBM.
+template <int C, int HT, bool PROJ>
 __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
   constexpr int HID = 4 * C;
   constexpr int NJ = HID / HT;    // hidden tiles
@@ -40,11 +49,14 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
   constexpr int A_BYTES = 64 * C * 2, W1_BYTES = HT * C * 2, H_BYTES = 64 * HT * 2, W2_BYTES = C * HT * 2;
   constexpr int CLD = C + 4;
   static_assert(64 * CLD * 4 <= W1_BYTES + H_BYTES + W2_BYTES, "C tile must fit the W1 + H + W2 region");
-  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W1_BYTES + H_BYTES + W2_BYTES];
+  constexpr int X_BYTES = PROJ ? 64 * CLD * 4 : 0;
+  static_assert(!PROJ || C * C * 2 <= W1_BYTES + H_BYTES + W2_BYTES, "proj weight must fit the W1 + H + W2 region");
+  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W1_BYTES + H_BYTES + W2_BYTES + X_BYTES];
   char* As = smem;
   char* W1s = smem + A_BYTES;
   char* Hs = W1s + W1_BYTES;
   char* W2s = Hs + H_BYTES;
+  float* Xs = reinterpret_cast<float*>(smem + A_BYTES + W1_BYTES + H_BYTES + W2_BYTES);  // PROJ: x rows after the proj add
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -64,6 +76,84 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int t = 0; t < TN2; ++t) acc2[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (PROJ) {
+    // ---- x' = x + o Wp^T + bp  (As holds o; Wp sits in the W1 / H / W2 region, free until the MLP loop)
+    for (int id = tid; id < C * NCA; id += 256) {
+      const int row = id / NCA, ch = id % NCA;
+      *reinterpret_cast<uint4*>(W1s + mlp_lds_off<NCA>(row, ch)) =
+          *reinterpret_cast<const uint4*>(p.wp + (long)row * C + ch * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < NCA / 4; ++kk) {
+      bf16x8_t a[2], b[TN2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const bf16x8_t*>(As + mlp_lds_off<NCA>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int t = 0; t < TN2; ++t)
+        b[t] = *reinterpret_cast<const bf16x8_t*>(W1s + mlp_lds_off<NCA>(wn * (C / 2) + t * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < TN2; ++t) acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc2[i][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < TN2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Xs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (C / 2) + t * 16 + fr] = acc2[i][t][r];
+        acc2[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    __syncthreads();  // all waves done with o in As and with Wp; Xs complete
+    // rows: + bias + residual, LayerNorm, h -> As (A-operand layout).  4 lanes per row, float4 groups part + 4 i
+    {
+      constexpr int MAXG = C / 16;
+      const int row = tid >> 2, part = tid & 3;
+      const long m = m0 + row;
+      const bool act = m < p.n;
+      float4 v[MAXG];
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) {
+        const int cg = part + 4 * i;
+        v[i] = *reinterpret_cast<const float4*>(Xs + row * CLD + 4 * cg);
+        const float4 b = *reinterpret_cast<const float4*>(p.bp + 4 * cg);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) r = *reinterpret_cast<const float4*>(p.x + m * p.ldx + 4 * cg);
+        v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w;  // same order as the GEMM epilogue: + bias, + res
+        v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
+        *reinterpret_cast<float4*>(Xs + row * CLD + 4 * cg) = v[i];
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      const float mean = sum * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / C) + p.ln_eps);
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) {
+        const int cg = part + 4 * i;
+        const float4 ga = *reinterpret_cast<const float4*>(p.ln_g + 4 * cg);
+        const float4 be = *reinterpret_cast<const float4*>(p.ln_b + 4 * cg);
+        uint2 u;
+        u.x = pack_bf16x2((v[i].x - mean) * rstd * ga.x + be.x, (v[i].y - mean) * rstd * ga.y + be.y);
+        u.y = pack_bf16x2((v[i].z - mean) * rstd * ga.z + be.z, (v[i].w - mean) * rstd * ga.w + be.w);
+        *reinterpret_cast<uint2*>(As + mlp_lds_off<NCA>(row, cg >> 1) + (cg & 1) * 8) = u;
+      }
+    }
+    // (the MLP loop's first barrier orders these As / Xs writes before their readers)
+  }
 
 #pragma unroll 1
   for (int j = 0; j < NJ; ++j) {
@@ -153,7 +243,8 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
     float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
     const float4 b = *reinterpret_cast<const float4*>(p.b2 + 4 * cg);
     float* xr = p.x + m * p.ldx + 4 * cg;
-    const float4 r = *reinterpret_cast<const float4*>(xr);
+    const float4 r = PROJ ? *reinterpret_cast<const float4*>(Xs + row * CLD + 4 * cg)
+                          : *reinterpret_cast<const float4*>(xr);
     v.x += b.x + r.x; v.y += b.y + r.y; v.z += b.z + r.z; v.w += b.w + r.w;
     *reinterpret_cast<float4*>(xr) = v;
     if (p.xc) {
@@ -181,12 +272,38 @@ extern "C" int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const flo
   MlpP p;
   p.h = (const bf16_t*)h; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2;
   p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldh = ldh; p.ldx = ldx; p.ldxc = ldxc;
+  p.wp = nullptr; p.bp = nullptr; p.ln_g = nullptr; p.ln_b = nullptr; p.ln_eps = 0.f;
   const dim3 grid((unsigned)((n + 63) / 64));
   // 64-wide hidden tiles: 20 / 32 / 56 KB of LDS per workgroup (C = 32 / 64 / 128).  128-wide tiles were measured 2-3 %
   // slower end to end at C = 64 (56 KB: two workgroups per CU instead of five) and equal at C = 32.
-  if (channels == 32) hipLaunchKernelGGL((mlp_fused_kernel<32, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else if (channels == 64) hipLaunchKernelGGL((mlp_fused_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((mlp_fused_kernel<128, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (channels == 32) hipLaunchKernelGGL((mlp_fused_kernel<32, 64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (channels == 64) hipLaunchKernelGGL((mlp_fused_kernel<64, 64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((mlp_fused_kernel<128, 64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// Block tail after attention in one launch (ptv3.py:416-427):
+//   x (n, ldx) fp32 += proj(o) ; h = LayerNorm(x; ln_g, ln_b, eps) ; x += fc2(GELU(fc1(h))) ; xc = typed copy of x.
+// Supported: bf16, channels 32 or 64; else CDSEG_ERR_UNSUPPORTED.
+extern "C" int cdseg_attn_tail_fused(const void* o, int ldo, const void* wp, const float* bp, const float* ln_g,
+                                     const float* ln_b, float ln_eps, const void* w1, const float* b1, const void* w2,
+                                     const float* b2, float* x, int ldx, void* xc, int ldxc, long n, int channels,
+                                     int dtype, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (!o || !wp || !bp || !ln_g || !ln_b || !w1 || !b1 || !w2 || !b2 || !x) return CDSEG_ERR_ARG;
+  if (dtype != CDSEG_BF16 || (channels != 32 && channels != 64)) return CDSEG_ERR_UNSUPPORTED;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if ((ldo & 7) || (ldx & 3) || (xc && (ldxc & 3)) || !al16(o) || !al16(wp) || !al16(w1) || !al16(w2) || !al16(x) ||
+      !al16(bp) || !al16(b2) || !al16(ln_g) || !al16(ln_b) || (xc && (((uintptr_t)xc) & 7)))
+    return CDSEG_ERR_ARG;
+  MlpP p;
+  p.h = (const bf16_t*)o; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2;
+  p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldh = ldo; p.ldx = ldx; p.ldxc = ldxc;
+  p.wp = (const bf16_t*)wp; p.bp = bp; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps;
+  const dim3 grid((unsigned)((n + 63) / 64));
+  if (channels == 32) hipLaunchKernelGGL((mlp_fused_kernel<32, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((mlp_fused_kernel<64, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

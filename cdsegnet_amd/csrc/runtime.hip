@@ -125,6 +125,18 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
                               T, stream)) != CDSEG_OK)
       return rc;
   }
+  static const bool fused_tail = []() {
+    const char* e = getenv("CDSEG_FUSED_TAIL");
+    const char* m = getenv("CDSEG_FUSED_MLP");
+    return !(e && e[0] == '0') && !(m && m[0] == '0');
+  }();
+  if (fused_tail && T == CDSEG_BF16 && (C == 32 || C == 64) && d->hidden == 4 * C) {
+    // big stages: proj + residual + LN2 + MLP in one launch (mlp.hip); h and the hidden activation never leave the CU
+    void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
+    return cdseg_attn_tail_fused(L.o, C, d->proj_w, (const float*)d->proj_b, (const float*)d->norm2_g,
+                                 (const float*)d->norm2_b, d->ln_eps, d->fc1_w, (const float*)d->fc1_b, d->fc2_w,
+                                 (const float*)d->fc2_b, (float*)io->x, C, xc, C, n, C, T, stream);
+  }
   {
     cdseg_gemm_args a = base_args(d, L, n);
     a.A = L.o; a.lda = C; a.W = d->proj_w; a.bias = d->proj_b; a.N = C; a.K = C;

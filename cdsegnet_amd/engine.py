@@ -515,6 +515,12 @@ class Engine:
         o = self._buf(n, c, self.T)
         ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
                       att.scale, o, work=64.0 * att.num_heads * sum_l2)
+        hid = w[pre + ".fc1.w"].shape[0]
+        if ops.attn_tail_fused_ok(o, hid):  # big stages: proj + LN2 + MLP in one launch
+            st.xc = self._buf(n, c, self.T)
+            ops.attn_tail_fused(o, w[pre + ".proj.w"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
+                                w[pre + ".fc1.w"], w[pre + ".fc1.b"], w[pre + ".fc2.w"], w[pre + ".fc2.b"], st.x, st.xc)
+            return
         if c <= self.FUSE_LN_MAX_C:
             h2 = self._buf(n, c, self.T)
             ops.gemm(o, w[pre + ".proj.w"], st.x, bias=w[pre + ".proj.b"], res=st.x,

@@ -477,6 +477,23 @@ def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
     return x
 
 
+def attn_tail_fused_ok(o, hidden):
+    """proj + LayerNorm + MLP in one launch: bf16, C = 32 / 64."""
+    c = o.shape[1]
+    return (o.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c and
+            os.environ.get("CDSEG_FUSED_TAIL", "1") != "0" and os.environ.get("CDSEG_FUSED_MLP", "1") != "0")
+
+
+def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5):
+    """x += proj(o); h = LN(x); x += fc2(GELU(fc1(h))); xc = bf16(x) - the Block's tail after attention."""
+    _need_gpu(o, x)
+    check(_lib.load().cdseg_attn_tail_fused(_ptr(o), o.stride(0), _ptr(wp), _ptr(bp), _ptr(ln_g), _ptr(ln_b), float(eps),
+                                             _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(x), x.stride(0), _ptr(xc),
+                                             xc.stride(0) if xc is not None else 0, o.shape[0], o.shape[1], _DT[o.dtype],
+                                             _stream()), "attn_tail_fused")
+    return x
+
+
 def _dp(t):
     return None if t is None else t.data_ptr()
 

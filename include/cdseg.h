@@ -280,6 +280,13 @@ int cdseg_iou_counts(const int32_t* pred, const int32_t* pred_idx, const int32_t
 int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
                     int ldx, void* xc, int ldxc, long n, int channels, int dtype, void* stream);
 
+/* Block tail after attention in ONE launch (ptv3.py:416-427): x += proj(o); h = LayerNorm(x); x += fc2(GELU(fc1(h)));
+ * xc = typed copy of x.  o (n, ldo); the updated residual rows stay in LDS while the MLP runs, h never exists in HBM.
+ * Supported: bf16, channels 32 or 64; else CDSEG_ERR_UNSUPPORTED. */
+int cdseg_attn_tail_fused(const void* o, int ldo, const void* wp, const float* bp, const float* ln_g, const float* ln_b,
+                          float ln_eps, const void* w1, const float* b1, const void* w2, const float* b2, float* x, int ldx,
+                          void* xc, int ldxc, long n, int channels, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
  * block itself (sparse-conv CPE, Linear+LayerNorms, QKV, window attention, proj, MLP), carving its

@@ -199,6 +199,17 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     return out
 
 
+def attn_tail_fused_ok(o, hidden):
+    c = o.shape[1]
+    return o.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c
+
+
+def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5):
+    x += o.float() @ wp.float().t() + bp
+    h = F.layer_norm(x, (x.shape[1],), ln_g, ln_b, eps).to(torch.bfloat16)
+    return mlp_fused(h, w1, b1, w2, b2, x, xc)
+
+
 def mlp_fused_ok(h, hidden):
     c = h.shape[1]
     return h.dtype == torch.bfloat16 and c in (32, 64, 128) and hidden == 4 * c

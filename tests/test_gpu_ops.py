@@ -786,3 +786,34 @@ def test_mlp_fused_vs_two_gemms_and_fp64(ops, M, C):
     # value sitting on a bf16 rounding boundary once in ~2^15 elements: isolated 1e-3 differences, nothing systematic
     d = (x - x2).abs()
     assert d.max().item() < 1e-2 and d.mean().item() < 2e-6
+
+
+@pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 64), (120000, 32)])
+def test_attn_tail_fused_equals_proj_ln_mlp_sequence(ops, M, C):
+    """cdseg_attn_tail_fused == proj GEMM (+ residual, LN2 in its epilogue) followed by the fused MLP, bit for bit:
+    same MFMA products, same row-wise LayerNorm arithmetic (ptv3.py:416-427)."""
+    g = torch.Generator().manual_seed(M * 3 + C)
+    bf = torch.bfloat16
+    o = dev(_bf16_round(torch.randn(M, C, generator=g)), bf)
+    wp = dev(_bf16_round(torch.randn(C, C, generator=g) / C ** 0.5), bf)
+    w1 = dev(_bf16_round(torch.randn(4 * C, C, generator=g) / C ** 0.5), bf)
+    w2 = dev(_bf16_round(torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5), bf)
+    bp, b1, b2 = dev(torch.randn(C, generator=g)), dev(torch.randn(4 * C, generator=g)), dev(torch.randn(C, generator=g))
+    lg, lb = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    x0 = torch.randn(M, C, generator=g)
+    xa = dev(x0)
+    xca = torch.empty(M, C, dtype=bf, device="cuda")
+    assert ops.attn_tail_fused_ok(o, 4 * C)
+    ops.attn_tail_fused(o, wp, bp, lg, lb, w1, b1, w2, b2, xa, xca)
+    xb = dev(x0)
+    h = torch.empty(M, C, dtype=bf, device="cuda")
+    ops.gemm(o, wp, xb, bias=bp, res=xb, ln_post=(lg, lb), ln_out=h)
+    xcb = torch.empty(M, C, dtype=bf, device="cuda")
+    ops.mlp_fused(h, w1, b1, w2, b2, xb, xcb)
+    assert torch.equal(xa, xb) and torch.equal(xca, xcb)
+    # and against plain torch
+    xr = x0 + (o.float().cpu() @ wp.float().cpu().t() + bp.cpu())
+    hr = _bf16_round(F.layer_norm(xr, (C,), lg.cpu(), lb.cpu(), 1e-5))
+    u = _bf16_round(F.gelu(hr @ w1.float().cpu().t() + b1.cpu()))
+    ref = xr + u @ w2.float().cpu().t() + b2.cpu()
+    assert (xa.cpu() - ref).abs().max().item() < 3e-2
