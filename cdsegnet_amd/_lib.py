@@ -103,6 +103,9 @@ SIGNATURES = {
                                 c_long, c_int, c_int, c_void_p]),
     "cdseg_attn_tail_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
+    "cdseg_cpe_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int,
+                                     c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
     "cdseg_stem_conv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,

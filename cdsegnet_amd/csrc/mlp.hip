@@ -307,3 +307,206 @@ extern "C" int cdseg_attn_tail_fused(const void* o, int ldo, const void* wp, con
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Block head after the sparse conv in one launch (ptv3.py:401-414):
+//     x += LN_cpe(y Wl^T + bl) [+ t bias] ;  h = LN1(x) ;  qkv = h Wqkv^T + bqkv
+// y = conv output (n, C).  h lives only in LDS; x is read and written once.
+namespace {
+
+struct HeadP {
+  const bf16_t* y;
+  const bf16_t* wl;     // (C, C)
+  const float* bl;
+  const float* lnp_g;   // LayerNorm of the linear's output (before the residual add)
+  const float* lnp_b;
+  float* x;             // (n, ldx) fp32 residual stream, updated in place
+  const float* colbias; // (C) timestep bias or nullptr
+  const float* ln1_g;   // LayerNorm of the updated x -> h
+  const float* ln1_b;
+  const bf16_t* wqkv;   // (3C, C)
+  const float* bqkv;    // (3C)
+  bf16_t* qkv;          // (n, ldqkv)
+  long n;
+  int ldy, ldx, ldqkv;
+  float eps;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void cpe_head_fused_kernel(HeadP p) {
+  constexpr int NCA = C / 8;   // 16-byte chunks per row of y / h / W tiles
+  constexpr int TN = C / 32;   // 16-wide column tiles per wave (wave: 32 rows x C/2 columns of a C-wide tile)
+  constexpr int CLD = C + 4;
+  constexpr int A_BYTES = 64 * C * 2, W_BYTES = C * C * 2;
+  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W_BYTES + 64 * CLD * 4];
+  char* As = smem;
+  char* Ws = smem + A_BYTES;
+  float* Cs = reinterpret_cast<float*>(smem + A_BYTES + W_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const long m0 = (long)blockIdx.x * 64;
+
+  auto load_w = [&](const bf16_t* w) {  // C rows x C
+    for (int id = tid; id < C * NCA; id += 256) {
+      const int row = id / NCA, ch = id % NCA;
+      *reinterpret_cast<uint4*>(Ws + mlp_lds_off<NCA>(row, ch)) = *reinterpret_cast<const uint4*>(w + (long)row * C + ch * 8);
+    }
+  };
+  auto mma_to_cs = [&]() {  // Cs (64 x C) = As (64 x C) Ws^T
+    f32x4_t acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NCA / 4; ++kk) {
+      bf16x8_t a[2], b[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const bf16x8_t*>(As + mlp_lds_off<NCA>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        b[t] = *reinterpret_cast<const bf16x8_t*>(Ws + mlp_lds_off<NCA>(wn * (C / 2) + t * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (C / 2) + t * 16 + fr] = acc[i][t][r];
+  };
+
+  for (int id = tid; id < 64 * NCA; id += 256) {
+    const int row = id / NCA, ch = id % NCA;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (m0 + row < p.n) v = *reinterpret_cast<const uint4*>(p.y + (m0 + row) * p.ldy + ch * 8);
+    *reinterpret_cast<uint4*>(As + mlp_lds_off<NCA>(row, ch)) = v;
+  }
+  load_w(p.wl);
+  __syncthreads();
+  mma_to_cs();
+  __syncthreads();
+
+  // ---- rows (4 lanes each): + bl, LN_cpe, + x, + t bias -> x ;  LN1 -> h (bf16, A-operand layout in As)
+  {
+    constexpr int MAXG = C / 16;
+    const int row = tid >> 2, part = tid & 3;
+    const long m = m0 + row;
+    const bool act = m < p.n;
+    float4 v[MAXG];
+    auto row_stats = [&](float& mean, float& rstd) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      mean = s * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      rstd = 1.0f / sqrtf(q * (1.0f / C) + p.eps);
+    };
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int cg = part + 4 * i;
+      v[i] = *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
+      const float4 b = *reinterpret_cast<const float4*>(p.bl + 4 * cg);
+      v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w;
+    }
+    float mean, rstd;
+    row_stats(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int cg = part + 4 * i;
+      const float4 ga = *reinterpret_cast<const float4*>(p.lnp_g + 4 * cg);
+      const float4 be = *reinterpret_cast<const float4*>(p.lnp_b + 4 * cg);
+      v[i].x = (v[i].x - mean) * rstd * ga.x + be.x;
+      v[i].y = (v[i].y - mean) * rstd * ga.y + be.y;
+      v[i].z = (v[i].z - mean) * rstd * ga.z + be.z;
+      v[i].w = (v[i].w - mean) * rstd * ga.w + be.w;
+      if (act) {
+        float* xr = p.x + m * p.ldx + 4 * cg;
+        const float4 r = *reinterpret_cast<const float4*>(xr);
+        v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
+        if (p.colbias) {
+          const float4 t = *reinterpret_cast<const float4*>(p.colbias + 4 * cg);
+          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        }
+        *reinterpret_cast<float4*>(xr) = v[i];
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    row_stats(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int cg = part + 4 * i;
+      const float4 ga = *reinterpret_cast<const float4*>(p.ln1_g + 4 * cg);
+      const float4 be = *reinterpret_cast<const float4*>(p.ln1_b + 4 * cg);
+      uint2 u;
+      u.x = pack_bf16x2((v[i].x - mean) * rstd * ga.x + be.x, (v[i].y - mean) * rstd * ga.y + be.y);
+      u.y = pack_bf16x2((v[i].z - mean) * rstd * ga.z + be.z, (v[i].w - mean) * rstd * ga.w + be.w);
+      *reinterpret_cast<uint2*>(As + mlp_lds_off<NCA>(row, cg >> 1) + (cg & 1) * 8) = u;
+    }
+  }
+
+  // ---- qkv: three C-wide column tiles (q, k, v)
+  constexpr int GPR = C / 4;
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+    __syncthreads();  // As = h complete / previous tile's Cs and Ws consumed
+    load_w(p.wqkv + (long)j * C * C);
+    __syncthreads();
+    mma_to_cs();
+    __syncthreads();
+    for (int item = tid; item < 64 * GPR; item += 256) {
+      const int row = item / GPR, cg = item % GPR;
+      const long m = m0 + row;
+      if (m >= p.n) continue;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
+      const float4 b = *reinterpret_cast<const float4*>(p.bqkv + j * C + 4 * cg);
+      uint2 u;
+      u.x = pack_bf16x2(v.x + b.x, v.y + b.y);
+      u.y = pack_bf16x2(v.z + b.z, v.w + b.w);
+      *reinterpret_cast<uint2*>(p.qkv + m * p.ldqkv + j * C + 4 * cg) = u;
+    }
+  }
+}
+
+}  // namespace
+
+// Supported: bf16, channels 32 or 64; else CDSEG_ERR_UNSUPPORTED.  colbias may be NULL.
+extern "C" int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, const float* bl, const float* lnp_g,
+                                    const float* lnp_b, float* x, int ldx, const float* colbias, const float* ln1_g,
+                                    const float* ln1_b, float eps, const void* wqkv, const float* bqkv, void* qkv,
+                                    int ldqkv, long n, int channels, int dtype, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (!y || !wl || !bl || !lnp_g || !lnp_b || !x || !ln1_g || !ln1_b || !wqkv || !bqkv || !qkv) return CDSEG_ERR_ARG;
+  if (dtype != CDSEG_BF16 || (channels != 32 && channels != 64)) return CDSEG_ERR_UNSUPPORTED;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if ((ldy & 7) || (ldx & 3) || (ldqkv & 3) || !al16(y) || !al16(wl) || !al16(wqkv) || !al16(x) || !al16(bl) ||
+      !al16(lnp_g) || !al16(lnp_b) || !al16(ln1_g) || !al16(ln1_b) || !al16(bqkv) || (colbias && !al16(colbias)) ||
+      (((uintptr_t)qkv) & 7))
+    return CDSEG_ERR_ARG;
+  HeadP p;
+  p.y = (const bf16_t*)y; p.wl = (const bf16_t*)wl; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
+  p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.wqkv = (const bf16_t*)wqkv; p.bqkv = bqkv;
+  p.qkv = (bf16_t*)qkv; p.n = n; p.ldy = ldy; p.ldx = ldx; p.ldqkv = ldqkv; p.eps = eps;
+  const dim3 grid((unsigned)((n + 63) / 64));
+  if (channels == 32) hipLaunchKernelGGL(cpe_head_fused_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(cpe_head_fused_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}

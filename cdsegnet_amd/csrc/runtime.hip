@@ -1,4 +1,5 @@
-// Native executor for one PTv3 Block (ref: ptv3.py:399-428): issues all launches of the block
+// Native executor for one PTv3 Block (ref: ptv3.py:399-428; big stages: conv, fused head, attention, fused tail;
+// deep stages: conv, cpe linear, qkv, attention, proj, fc1, fc2 + their second-pass kernels): issues all launches of the block
 // from C++ so the Python binding pays one call instead of ~10 (the per-launch host cost of the
 // binding, ~10 us, was the step's critical path once the kernels were fast).
 #include <cstdlib>
@@ -91,7 +92,16 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
     a.N = C; a.K = C; a.out = L.y; a.ldo = C; a.out_dtype = T;
     if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
   }
-  if (fuse) {
+  static const bool fused_head = []() { const char* e = getenv("CDSEG_FUSED_HEAD"); return !(e && e[0] == '0'); }();
+  const bool head = fused_head && T == CDSEG_BF16 && (C == 32 || C == 64);
+  if (head) {
+    // big stages: cpe linear + LN + residual (+ t bias) + LN1 + qkv in one launch (mlp.hip); h never leaves the CU
+    if ((rc = cdseg_cpe_head_fused(L.y, C, d->cpe_lin_w, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
+                                   (const float*)d->cpe_ln_b, (float*)io->x, C, (const float*)io->tbias,
+                                   (const float*)d->norm1_g, (const float*)d->norm1_b, d->ln_eps, d->qkv_w,
+                                   (const float*)d->qkv_b, L.qkv, 3 * C, n, C, T, stream)) != CDSEG_OK)
+      return rc;
+  } else if (fuse) {
     cdseg_gemm_args a = base_args(d, L, n);
     a.A = L.y; a.lda = C; a.W = d->cpe_lin_w; a.bias = d->cpe_lin_b; a.N = C; a.K = C;
     a.ln_pre_g = d->cpe_ln_g; a.ln_pre_b = d->cpe_ln_b; a.res = io->x; a.ldres = C; a.colbias = io->tbias;
@@ -111,7 +121,7 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
       return rc;
   }
   // ---- attention: x += proj(attn(qkv(h)));  h = LN2(x)                    (ptv3.py:413-421)
-  {
+  if (!head) {
     cdseg_gemm_args a = base_args(d, L, n);
     a.A = L.h; a.lda = C; a.W = d->qkv_w; a.bias = d->qkv_b; a.N = 3 * C; a.K = C;
     a.out = L.qkv; a.ldo = 3 * C; a.out_dtype = T;

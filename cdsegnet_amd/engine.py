@@ -504,9 +504,15 @@ class Engine:
                               patch_start.numel() - 1, max_len, self.scratch(sb))
             st.xc = xc_out
             return
-        h = self._cpe(st, pre + ".cpe", st.xc, tbias, next_norm=pre + ".norm1")
         qkv = self._buf(n, 3 * c, self.T)
-        ops.gemm(h, w[pre + ".qkv.w"], qkv, bias=w[pre + ".qkv.b"])
+        if ops.cpe_head_fused_ok(st.xc):  # big stages: cpe linear + LN + residual + LN1 + qkv in one launch
+            y = self._buf(n, c, self.T)
+            ops.gemm(st.xc, w[pre + ".cpe0.w"], y, bias=w[pre + ".cpe0.b"], nbr=lv.nbr(3, True), nbr_kmajor=True, kvol=27)
+            ops.cpe_head_fused(y, w[pre + ".cpe1.w"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
+                               tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.w"], w[pre + ".qkv.b"], qkv)
+        else:
+            h = self._cpe(st, pre + ".cpe", st.xc, tbias, next_norm=pre + ".norm1")
+            ops.gemm(h, w[pre + ".qkv.w"], qkv, bias=w[pre + ".qkv.b"])
         att = mod.attn
         curve = st.curves[att.order_index]
         gidx, widx = lv.slots(curve, att.patch_size, att.enable_flash)

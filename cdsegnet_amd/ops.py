@@ -477,6 +477,21 @@ def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
     return x
 
 
+def cpe_head_fused_ok(y):
+    """cpe linear + LN + residual + LN1 + qkv in one launch: bf16, C = 32 / 64."""
+    return (y.dtype == torch.bfloat16 and y.shape[1] in (32, 64) and os.environ.get("CDSEG_FUSED_HEAD", "1") != "0")
+
+
+def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
+    """x += LN_cpe(y Wl^T + bl) [+ colbias]; h = LN1(x); qkv = h Wqkv^T + bqkv."""
+    _need_gpu(y, x)
+    check(_lib.load().cdseg_cpe_head_fused(_ptr(y), y.stride(0), _ptr(wl), _ptr(bl), _ptr(lnp[0]), _ptr(lnp[1]), _ptr(x),
+                                            x.stride(0), _ptr(colbias), _ptr(ln1[0]), _ptr(ln1[1]), float(eps), _ptr(wqkv),
+                                            _ptr(bqkv), _ptr(qkv), qkv.stride(0), y.shape[0], y.shape[1], _DT[y.dtype],
+                                            _stream()), "cpe_head_fused")
+    return qkv
+
+
 def attn_tail_fused_ok(o, hidden):
     """proj + LayerNorm + MLP in one launch: bf16, C = 32 / 64."""
     c = o.shape[1]

@@ -287,6 +287,14 @@ int cdseg_attn_tail_fused(const void* o, int ldo, const void* wp, const float* b
                           float ln_eps, const void* w1, const float* b1, const void* w2, const float* b2, float* x, int ldx,
                           void* xc, int ldxc, long n, int channels, int dtype, void* stream);
 
+/* Block head after the sparse conv in ONE launch (ptv3.py:401-414): x += LN_cpe(y Wl^T + bl) [+ colbias];
+ * h = LN1(x); qkv (n, ldqkv) = h Wqkv^T + bqkv.  y (n, ldy) = conv output; h never exists in HBM.
+ * Supported: bf16, channels 32 or 64; else CDSEG_ERR_UNSUPPORTED. */
+int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, const float* bl, const float* lnp_g, const float* lnp_b,
+                         float* x, int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps,
+                         const void* wqkv, const float* bqkv, void* qkv, int ldqkv, long n, int channels, int dtype,
+                         void* stream);
+
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
  * block itself (sparse-conv CPE, Linear+LayerNorms, QKV, window attention, proj, MLP), carving its

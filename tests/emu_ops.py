@@ -199,6 +199,21 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     return out
 
 
+def cpe_head_fused_ok(y):
+    return y.dtype == torch.bfloat16 and y.shape[1] in (32, 64)
+
+
+def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
+    c = x.shape[1]
+    v = F.layer_norm(y.float() @ wl.float().t() + bl, (c,), lnp[0], lnp[1], eps)
+    x += v
+    if colbias is not None:
+        x += colbias
+    h = F.layer_norm(x, (c,), ln1[0], ln1[1], eps).to(torch.bfloat16)
+    qkv.copy_((h.float() @ wqkv.float().t() + bqkv).to(qkv.dtype))
+    return qkv
+
+
 def attn_tail_fused_ok(o, hidden):
     c = o.shape[1]
     return o.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c

@@ -817,3 +817,29 @@ def test_attn_tail_fused_equals_proj_ln_mlp_sequence(ops, M, C):
     u = _bf16_round(F.gelu(hr @ w1.float().cpu().t() + b1.cpu()))
     ref = xr + u @ w2.float().cpu().t() + b2.cpu()
     assert (xa.cpu() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("M,C,tb", [(1000, 32, True), (4097, 64, False), (64, 64, True), (120000, 32, False)])
+def test_cpe_head_fused_equals_linear_ln_qkv_sequence(ops, M, C, tb):
+    """cdseg_cpe_head_fused == cpe linear GEMM (LN_cpe + residual + t bias + LN1 in its epilogue) followed by the qkv
+    GEMM, bit for bit (ptv3.py:401-414)."""
+    g = torch.Generator().manual_seed(M * 5 + C)
+    bf = torch.bfloat16
+    y = dev(_bf16_round(torch.randn(M, C, generator=g)), bf)
+    wl = dev(_bf16_round(torch.randn(C, C, generator=g) / C ** 0.5), bf)
+    wq = dev(_bf16_round(torch.randn(3 * C, C, generator=g) / C ** 0.5), bf)
+    bl, bq = dev(torch.randn(C, generator=g)), dev(torch.randn(3 * C, generator=g))
+    g1, b1 = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    g2, b2 = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    cb = dev(torch.randn(C, generator=g)) if tb else None
+    x0 = torch.randn(M, C, generator=g)
+    xa = dev(x0)
+    qa = torch.empty(M, 3 * C, dtype=bf, device="cuda")
+    assert ops.cpe_head_fused_ok(y)
+    ops.cpe_head_fused(y, wl, bl, (g1, b1), xa, cb, (g2, b2), wq, bq, qa)
+    xb = dev(x0)
+    h = torch.empty(M, C, dtype=bf, device="cuda")
+    ops.gemm(y, wl, xb, bias=bl, ln_pre=(g1, b1), res=xb, colbias=cb, ln_post=(g2, b2), ln_out=h)
+    qb = torch.empty(M, 3 * C, dtype=bf, device="cuda")
+    ops.gemm(h, wq, qb, bias=bq)
+    assert torch.equal(xa, xb) and torch.equal(qa, qb)
