@@ -8,8 +8,8 @@ A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-
 fusion) over one synthetic ScanNet-shaped scene per GPU (BASELINE.json configs[1]: ~120k voxels,
 6-ch features, 20 classes, bf16), inputs already resident in HBM.  Scenes are independent units:
 each rank runs its own scenes, no data-path collective ("scaling": "weak").  One step = one batch of
---scenes-per-forward x --lanes (4 x 3 = 12) scenes through DefaultSegmentorV2.inference_many: every lane
-(HIP stream) gets one collated forward of 4 scenes (the reference's collate_fn batching), three forwards
+--scenes-per-forward x --lanes (8 x 3 = 24) scenes through DefaultSegmentorV2.inference_many: every lane
+(HIP stream) gets one collated forward of 8 scenes (the reference's collate_fn batching), three forwards
 are in flight.  Every scene runs the full path; `value` counts all of them; `single_scene_latency_ms`
 reports the one-scene-at-a-time latency next to the throughput.  RCCL is used once to
 broadcast the weights from rank 0 and for the final timing / counter reductions.
@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--time-in-region", action="store_true",
                     help="also record HIP events around the attention launches INSIDE the timed region (costs ~5 %% "
                          "throughput: the run is host-issue bound and every launch gets two hipEventCreate/Record)")
-    ap.add_argument("--scenes-per-forward", type=int, default=4,
+    ap.add_argument("--scenes-per-forward", type=int, default=8,
                     help="scenes collated into one forward (the reference's collate_fn batching); one step = "
                          "scenes-per-forward x lanes scenes (one batch per lane)")
     ap.add_argument("--lanes", type=int, default=3,
