@@ -369,3 +369,31 @@ def softmax_vote(logits, idx, pred):
 
 def argmax_rows(x):
     return x.argmax(1).int()
+
+
+# ---- evaluator ops (cdsegnet_amd/csrc/testtime.hip)
+def knn1(ref_xyz, ref_offset, qry_xyz, qry_offset, origin, cell, want_dist=False):
+    idx = torch.full((qry_xyz.shape[0],), -1, dtype=torch.int32)
+    d2 = torch.full((qry_xyz.shape[0],), 1e10, dtype=torch.float32)
+    rs = qs = 0
+    for re, qe in zip(ref_offset.tolist(), qry_offset.tolist()):
+        if re > rs and qe > qs:
+            d = torch.cdist(qry_xyz[qs:qe].double(), ref_xyz[rs:re].double()) ** 2
+            v, j = d.min(1)
+            idx[qs:qe] = (j + rs).int()
+            d2[qs:qe] = v.float()
+        rs, qs = re, qe
+    return (idx, d2) if want_dist else idx
+
+
+def iou_counts(pred, target, num_classes, ignore_index=-1, pred_idx=None):
+    p = pred.long() if pred_idx is None else pred.long()[pred_idx.long()]
+    t = target.long()
+    keep = t != ignore_index
+    p, t = p[keep], t[keep]
+    out = torch.zeros((3, num_classes), dtype=torch.int64)
+    out[1] = torch.bincount(p[(p >= 0) & (p < num_classes)], minlength=num_classes)[:num_classes]
+    out[2] = torch.bincount(t[(t >= 0) & (t < num_classes)], minlength=num_classes)[:num_classes]
+    hit = t[p == t]
+    out[0] = torch.bincount(hit[(hit >= 0) & (hit < num_classes)], minlength=num_classes)[:num_classes]
+    return out

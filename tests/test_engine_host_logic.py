@@ -185,3 +185,28 @@ def test_inference_many_host_logic(emulated):
     n0 = len(scenes[0]["coord"])
     assert torch.equal(outs[0]["seg_logits"], a[:n0]) and torch.equal(outs[1]["seg_logits"], a[n0:])
     assert torch.equal(outs[2]["seg_logits"], b)
+
+
+def test_evaluate_scene_host_logic(monkeypatch):
+    """cdsegnet_amd.evaluate (arg-max -> 1-NN label transfer -> IoU counters) on the emulated ops against the oracle
+    restatement of evaluator.py:128-146 + utils/misc.py:38-50."""
+    import cdsegnet_amd.evaluate as ev
+    from oracle import testtime as OT
+    monkeypatch.setattr(ev, "ops", emu_ops)
+    rng = np.random.default_rng(11)
+    raw = (rng.random((4000, 3)) * np.array([3.0, 2.0, 0.3])).astype(np.float32)
+    keep = rng.random(4000) < 0.4
+    coord, k = raw[keep], 9
+    logits = rng.normal(size=(len(coord), k)).astype(np.float32)
+    seg = rng.integers(-1, k, size=len(raw))
+    d = dict(coord=torch.as_tensor(coord), offset=torch.tensor([len(coord)]), origin_coord=torch.as_tensor(raw),
+             origin_offset=torch.tensor([len(raw)]), origin_segment=torch.as_tensor(seg))
+    counts = ev.evaluate_scene(torch.as_tensor(logits), d, k, ignore_index=-1, reduce=False).numpy()
+    idx, _ = OT.knn1_bruteforce(coord, [len(coord)], raw, [len(raw)])
+    i, u, t = OT.intersection_and_union(logits.argmax(1)[idx], seg, k, -1)
+    assert np.array_equal(counts[0], i) and np.array_equal(counts[1], u) and np.array_equal(counts[2], t)
+    # without origin_coord: counters straight on the voxelised points
+    d2 = dict(segment=torch.as_tensor(seg[keep]))
+    c2 = ev.evaluate_scene(torch.as_tensor(logits), d2, k, ignore_index=-1, reduce=False).numpy()
+    i, u, t = OT.intersection_and_union(logits.argmax(1), seg[keep], k, -1)
+    assert np.array_equal(c2[0], i) and np.array_equal(c2[1], u) and np.array_equal(c2[2], t)
