@@ -297,9 +297,10 @@ int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, const float* bl
 
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
- * block itself (sparse-conv CPE, Linear+LayerNorms, QKV, window attention, proj, MLP), carving its
- * temporaries from the caller's scratch buffer.  Replaces ~10 host round trips through the binding
- * by one.  Weights are described once (cdseg_block_desc), the per-scene tensors per call
+ * block itself, carving its temporaries from the caller's scratch buffer: sparse-conv CPE, then for bf16 with
+ * C = 32 / 64 the fused head (cdseg_cpe_head_fused), window attention and the fused tail (cdseg_attn_tail_fused);
+ * otherwise Linear+LayerNorms, QKV, attention, proj, MLP (cdseg_mlp_fused for bf16 C = 128) as separate launches.
+ * Replaces ~10 host round trips through the binding by one.  Weights are described once (cdseg_block_desc), the per-scene tensors per call
  * (cdseg_block_io). */
 typedef struct cdseg_block_desc {
   int dtype;       /* compute dtype T of weights / operand activations */
