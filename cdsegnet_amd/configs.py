@@ -103,6 +103,34 @@ def cdsegnet_config(dataset="scannet"):
     return m
 
 
+def model_config(dataset="scannet", variant="CDSegNet"):
+    """``model`` dict of configs/<dataset>/<variant>.py for the four model variants the reference ships
+    (criteria dropped).  Differences to CDSegNet.py (diffed from the reference's config files):
+
+      PTv3_CNF  n_enc_depths (2,2,2,6,2); linear schedule (scannet 1e-4..5e-4, nuscenes 2e-3..3e-3)
+      PTv3      condition=False, dm=False, skip_connection_mode="add", n_enc_depths (2,2,2,6,2)
+      Baseline  dm=False (the c-branch sees the input itself at t = 0)
+    """
+    m = cdsegnet_config(dataset)
+    b = m["backbone"]
+    if variant == "CDSegNet":
+        return m
+    if variant == "Baseline":  # configs/scannet/Baseline.py:18
+        m["dm"] = False
+        return m
+    if variant not in ("PTv3_CNF", "PTv3"):
+        raise KeyError(variant)
+    b["n_enc_depths"] = (2, 2, 2, 6, 2)  # configs/scannet/PTv3_CNF.py:75
+    m["noise_schedule"] = "linear"
+    m["beta_start"], m["beta_end"] = (0.002, 0.003) if dataset == "nuscenes" else (0.0001, 0.0005)
+    if variant == "PTv3":  # configs/scannet/PTv3.py:17-18,33,46
+        m["condition"] = b["condition"] = False
+        m["dm"] = False
+        m["loss_type"] = "EW"
+        b["skip_connection_mode"] = "add"
+    return m
+
+
 def mini_config(num_classes=13, in_channels=6, T_dim=64):
     """Same architecture, reduced widths/depths (head dim stays 16): the end-to-end
     golden fixture that fits in a few hundred KB."""

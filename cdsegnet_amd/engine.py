@@ -157,6 +157,7 @@ class Engine:
         self.device = None
         self.w = None
         self.rng_offset = 0
+        self._rng_seed = None  # torch.initial_seed() the device-RNG cursor belongs to
         self.use_native_blocks = True  # one library call per Block instead of ~8 binding calls
         self._pad_keys = None
         self._side = {}
@@ -618,6 +619,12 @@ class Engine:
         ops.layernorm(nst.x, w["x.q_norm1.g"], w["x.q_norm1.b"], hq)
         hkv = self._buf(n, cst.x.shape[1], self.T)
         ops.layernorm(cst.x, w["x.kv_norm1.g"], w["x.kv_norm1.b"], hkv)
+        # the kv point LEAVES the block holding kv_norm1(c + kv_cpe(c)) in feat and sparse_conv_feat (PointSequential
+        # assigns the LayerNorm output in place, ptv3.py:1190-1196, modules.py:68-73): that is what the c-decoder of the
+        # multi-step path reads next (oracle/model.py: cross_block, `kvp.feat = hkv`)
+        cst.xc = hkv
+        if self.T == torch.float32:
+            cst.x = hkv
         q = self._buf(n, cq, self.T)
         ops.gemm(hq, w["x.q.w"], q, bias=w["x.q.b"])
         kv = self._buf(n, 2 * cq, self.T)
@@ -643,7 +650,13 @@ class Engine:
         m = self.model
         d = {}
         if noise_level is not None:
-            d["feat_noise"] = torch.randn(feat_shape) if m.noise_source == "torch_cpu" else None
+            # the reference's add_gaussian_noise (default.py:228-236) calls randn_like on the input tensor: torch's CPU
+            # generator when the reference runs on CPU (the golden vectors), the CUDA generator - which does NOT advance
+            # the CPU one - when it runs on a GPU (test.py moves the inputs first).  feat_noise_source="device" takes the
+            # jitter from the device Philox stream instead, so the CPU-generator order of the later draws (c-noise,
+            # randperms) is the one a GPU run of the reference has for the same torch.manual_seed.
+            on_cpu_gen = m.noise_source == "torch_cpu" and getattr(m, "feat_noise_source", "torch_cpu") == "torch_cpu"
+            d["feat_noise"] = torch.randn(feat_shape) if on_cpu_gen else None
         if m.condition and (always_noise or (m.dm and m.dm_input == "xt")):
             d["noise"] = (torch.normal(0, 1, size=(n, c_ch), dtype=torch.float32)
                           if m.noise_source == "torch_cpu" else None)
@@ -672,6 +685,9 @@ class Engine:
     def reserve_rng(self, k=None):
         """Reserve a block of device-RNG stream ids (call in scene order from ONE thread: keeps the device noise
         of scene i independent of which lane / thread runs it)."""
+        seed = torch.initial_seed()
+        if seed != self._rng_seed:  # torch.manual_seed(s) restarts the device-noise sequence: same seed, same logits
+            self._rng_seed, self.rng_offset = seed, 0
         base = self.rng_offset
         self.rng_offset += self.RNG_RESERVE if k is None else int(k)
         return base

@@ -149,6 +149,18 @@ class SerializedUnpooling(nn.Module):
         self.skip_connection_scale_i = skip_connection_scale_i
         if skip_connection_mode == "cat":
             self.proj_cat = PointSequential(nn.Linear(out_channels * 2, out_channels))
+        elif skip_connection_mode == "add":
+            # skip scaling (ptv3.py:607-611; note skip_connection_scale_i=False still scales by 0.8^(0-1) = 1.25) is folded
+            # into proj_cat's weight in 'cat' mode; the 'add' epilogue has no post-activation scalar, so the combination
+            # (off in every shipped config) is rejected HERE and not in the middle of a forward
+            f = (2 ** -0.5 if skip_connection_scale else 1.0)
+            if skip_connection_scale_i is not None:
+                f *= 0.8 ** (int(skip_connection_scale_i) - 1)
+            if f != 1.0:
+                raise NotImplementedError("skip-connection scaling with skip_connection_mode='add' "
+                                          "(no shipped CDSegNet / PTv3 config uses it)")
+        else:
+            raise ValueError(f"skip_connection_mode={skip_connection_mode!r}")
 
 
 class Embedding(nn.Module):
@@ -392,6 +404,9 @@ class DefaultSegmentorV2(nn.Module):
         self.precision = "bf16"        # "bf16" (MFMA bf16, fp32 accumulate/residual) | "fp32" (exact-fp32 MFMA)
         self._lanes = {}
         self.noise_source = "torch_cpu"  # "torch_cpu" replays the reference's CPU-generator draws | "device"
+        # noise_level jitter: "torch_cpu" = the CPU-run reference's draw order (golden vectors) | "device" = device
+        # Philox, leaves the CPU generator alone like a GPU run of the reference does (engine.draw)
+        self.feat_noise_source = "torch_cpu"
         self._engine = None
 
     # -- engine cache management -------------------------------------------------------------

@@ -92,6 +92,39 @@ def ref_model(ref, cfg, seed=0):
     return model, new
 
 
+def save_fixture(path, **arrays):
+    """np.savez_compressed, skipped when the file already holds exactly these arrays (zip bytes are not
+    reproducible, array contents are): re-running the recipe leaves an unchanged fixture untouched in git."""
+    if os.path.exists(path):
+        with np.load(path, allow_pickle=False) as f:
+            same = set(f.files) == set(arrays) and all(
+                np.asarray(arrays[k]).shape == f[k].shape and np.asarray(arrays[k]).dtype == f[k].dtype and
+                np.array_equal(np.asarray(arrays[k]), f[k], equal_nan=np.asarray(arrays[k]).dtype.kind == "f")
+                for k in f.files)
+        if same:
+            print("  unchanged:", os.path.basename(path))
+            return False
+        print("  CHANGED:", os.path.basename(path))
+    np.savez_compressed(path, **arrays)
+    return True
+
+
+REGEN_INPUTS = "--regen-inputs" in sys.argv  # default: inputs of an existing fixture are FROZEN (read back from it)
+
+
+def frozen(tag, make):
+    """Inputs of fixture `tag`: read back from the committed .npz when it exists, so that re-running the recipe
+    reproduces the committed data even if cdsegnet_amd.synth has changed since (the generators are free to evolve;
+    the pinned vectors are not).  ``--regen-inputs`` draws fresh inputs from synth instead."""
+    path = os.path.join(OUT, f"{tag}.npz")
+    if os.path.exists(path) and not REGEN_INPUTS:
+        with np.load(path, allow_pickle=False) as f:
+            sc = {k: f[k] for k in ("coord", "grid_coord", "feat", "offset")}
+        sc["segment"] = np.zeros(len(sc["coord"]), dtype=np.int64)
+        return sc
+    return make()
+
+
 def to_torch_input(scene):
     return dict(
         coord=torch.from_numpy(scene["coord"]),
@@ -120,12 +153,15 @@ def _random_cloud(seed, sizes, extent):
 def gen_serialization(ref):
     """Point.serialization before the shuffle + padding plans + pooling structure."""
     clouds = {
-        "tiny64": synth.room_scene(11, 64),
-        "room1500": synth.room_scene(12, 1500),
-        "batch2": synth.collate([synth.room_scene(13, 2300), synth.room_scene(14, 1200)]),
-        "lidar5000": synth.lidar_scene(15, 5000),
-        "rand16": _random_cloud(16, (700, 1030, 270), 65536),
+        "tiny64": lambda: synth.room_scene(11, 64),
+        "room1500": lambda: synth.room_scene(12, 1500),
+        "batch2": lambda: synth.collate([synth.room_scene(13, 2300), synth.room_scene(14, 1200)]),
+        "lidar5000": lambda: synth.lidar_scene(15, 5000),
+        "rand16": lambda: _random_cloud(16, (700, 1030, 270), 65536),
+        # 8 LiDAR sweeps in one batch (the nuScenes test config: batch_size_test_per_gpu = 8): depth 11 + 4 batch bits
+        "lidar8": lambda: synth.collate([synth.lidar_scene(40 + i, 380 + 67 * i) for i in range(8)]),
     }
+    clouds = {k: frozen(f"serialization_{k}", mk) for k, mk in clouds.items()}
     orders = ("z", "z-trans", "hilbert", "hilbert-trans")
     for name, sc in clouds.items():
         p = ref.structure.Point(dict(coord=torch.from_numpy(sc["coord"]),
@@ -166,7 +202,7 @@ def gen_serialization(ref):
             out[f"pool{stride}_coord"] = q.coord.numpy()
             for k, v in sdp.items():
                 out[f"pool{stride}_sd.{k}"] = v.numpy()
-        np.savez_compressed(os.path.join(OUT, f"serialization_{name}.npz"), **out)
+        save_fixture(os.path.join(OUT, f"serialization_{name}.npz"), **out)
         print("serialization", name, sc["coord"].shape, "depth", int(p.serialized_depth))
     # known answers + calc_t_emb row
     g = torch.tensor([[1, 2, 3], [7, 0, 5], [300, 2, 9]])
@@ -178,7 +214,7 @@ def gen_serialization(ref):
     ts = torch.tensor([[0], [1], [500], [999]], dtype=torch.int64)
     ka["t_emb_multi_128"] = ref.comm.calc_t_emb(ts, 128).numpy()
     ka["grid"] = g.numpy()
-    np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **ka)
+    save_fixture(os.path.join(OUT, "known_answers.npz"), **ka)
 
 
 def run_e2e(ref, cfg, scene, seed, sd_seed, tag, keep_sd, noise_level=None, capture=()):
@@ -201,11 +237,12 @@ def run_e2e(ref, cfg, scene, seed, sd_seed, tag, keep_sd, noise_level=None, capt
     for h in hooks:
         h.remove()
     kinds = [k for k, _ in rec.log]
-    expect = (["randn_like"] if noise_level is not None else []) + ["normal"] + ["randperm"] * 8
+    has_noise = bool(cfg.get("dm")) and cfg.get("dm_input") == "xt"
+    expect = (["randn_like"] if noise_level is not None else []) + (["normal"] if has_noise else []) + ["randperm"] * 8
     assert kinds == expect, kinds
     fx = dict(coord=scene["coord"], grid_coord=scene["grid_coord"], feat=scene["feat"], offset=scene["offset"],
               logits=logits, seed=np.int64(seed), sd_seed=np.int64(sd_seed),
-              noise=[v for k, v in rec.log if k == "normal"][0].numpy(),
+              noise=([v for k, v in rec.log if k == "normal"] or [torch.zeros(0, 0)])[0].numpy(),
               perms=np.stack([v.numpy() for k, v in rec.log if k == "randperm"]),
               cfg_json=np.array(json.dumps(cfg)))
     if noise_level is not None:
@@ -221,7 +258,7 @@ def run_e2e(ref, cfg, scene, seed, sd_seed, tag, keep_sd, noise_level=None, capt
         fx["sd_checksum"] = np.float64(sum(float(v.double().abs().sum()) for v in sd.values()))
         fx["sd_keys"] = np.array(list(sd.keys()))
         fx["sd_shapes"] = np.array([json.dumps(list(v.shape)) for v in sd.values()])
-    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **fx)
+    save_fixture(os.path.join(OUT, f"{tag}.npz"), **fx)
     print(tag, scene["coord"].shape, "logits", logits.shape, float(np.abs(logits).mean()),
           "params", sum(v.numel() for v in sd.values()))
     return model
@@ -231,18 +268,20 @@ def gen_e2e(ref):
     cap = ("backbone._n_embedding", "backbone._n_enc.enc0", "backbone._c_enc.enc2", "backbone._n_enc.enc4",
            "backbone._tm_dec0", "backbone._n_dec.dec3", "backbone._n_dec.dec0")
     # mini model, one scene (3 patches at stage 0, padded last patch; short single patches deeper)
-    run_e2e(ref, configs.mini_config(), synth.room_scene(21, 2600), 54421566, 1, "mini_e2e_room", False, capture=cap)
+    run_e2e(ref, configs.mini_config(), frozen("mini_e2e_room", lambda: synth.room_scene(21, 2600)), 54421566, 1,
+            "mini_e2e_room", False, capture=cap)
     # mini model, batch of two scenes (both > 1024 points so non-flash K == 1024)
-    sc = synth.collate([synth.room_scene(22, 1500), synth.room_scene(23, 1100)])
+    sc = frozen("mini_e2e_batch2", lambda: synth.collate([synth.room_scene(22, 1500), synth.room_scene(23, 1100)]))
     run_e2e(ref, configs.mini_config(), sc, 7, 2, "mini_e2e_batch2", False, capture=cap)
     # mini nuScenes-like (4-ch input, c target = feat)
-    run_e2e(ref, configs.mini_config(num_classes=16, in_channels=4, T_dim=32), synth.lidar_scene(24, 3000), 99, 3,
-            "mini_e2e_lidar", False, capture=cap)
+    run_e2e(ref, configs.mini_config(num_classes=16, in_channels=4, T_dim=32),
+            frozen("mini_e2e_lidar", lambda: synth.lidar_scene(24, 3000)), 99, 3, "mini_e2e_lidar", False, capture=cap)
     # mini with the reference's feature-noise knob (default.py:373-374)
-    run_e2e(ref, configs.mini_config(), synth.room_scene(25, 1300), 5, 4, "mini_e2e_noise", False, noise_level=0.1)
+    run_e2e(ref, configs.mini_config(), frozen("mini_e2e_noise", lambda: synth.room_scene(25, 1300)), 5, 4,
+            "mini_e2e_noise", False, noise_level=0.1)
     # full width (101 M parameters are regenerated by name; only data is stored)
-    model = run_e2e(ref, configs.cdsegnet_config("scannet"), synth.room_scene(31, 8000), 54421566, 0,
-                    "full_e2e_8k", False, capture=("backbone._n_enc.enc4", "backbone._tm_dec0"))
+    model = run_e2e(ref, configs.cdsegnet_config("scannet"), frozen("full_e2e_8k", lambda: synth.room_scene(31, 8000)),
+                    54421566, 0, "full_e2e_8k", False, capture=("backbone._n_enc.enc4", "backbone._tm_dec0"))
     schema = {k: list(v.shape) for k, v in model.state_dict().items()}
     with open(os.path.join(OUT, "state_dict_schema_scannet.json"), "w") as f:
         json.dump(schema, f, indent=0)
@@ -256,12 +295,35 @@ def gen_e2e(ref):
             json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, f, indent=0)
 
 
+def gen_configs(ref):
+    """The BASELINE.json workload shapes and the other shipped model variants, through the reference (mini widths)."""
+    # nuScenes test shape (configs/nuscenes/CDSegNet.py: batch_size_test_per_gpu = 8): EIGHT LiDAR sweeps collated
+    # into one forward - grid depth 11 (0.05 m voxels over +-50 m), 4 batch bits on top of the 33 code bits, ragged
+    # sweep sizes, seven of them below K = 1024 and one above (non-flash K = min n_b)
+    sc = frozen("mini_e2e_lidar8", lambda: synth.collate(
+        [synth.lidar_scene(50 + i, 700 + 97 * i if i else 1400) for i in range(8)]))
+    run_e2e(ref, configs.mini_config(num_classes=16, in_channels=4, T_dim=32), sc, 123, 8, "mini_e2e_lidar8", False)
+    # robustness shape (BASELINE config 5): coord noise sigma = 0.05 m + 50 % drop + re-voxelisation -> scattered,
+    # mostly isolated voxels (few conv neighbours, different pooling ratios)
+    sc = frozen("mini_e2e_robust", lambda: synth.perturb_scene(synth.room_scene(26, 5000), seed=3, sigma=0.05, drop=0.5))
+    run_e2e(ref, configs.mini_config(), sc, 31, 9, "mini_e2e_robust", False)
+    # configs/*/PTv3_CNF.py: CNF on the PTv3 depths (n_enc_depths (2,2,2,6,2)), linear schedule
+    cfg = configs.mini_config()
+    cfg["backbone"]["n_enc_depths"] = (1, 1, 2, 2, 1)
+    cfg.update(beta_start=0.0001, beta_end=0.0005, noise_schedule="linear")
+    run_e2e(ref, cfg, frozen("mini_cnf_room", lambda: synth.room_scene(29, 2200)), 41, 10, "mini_cnf_room", False)
+    # configs/*/Baseline.py: condition=True, dm=False -> the c-branch sees the input features, t = 0, no noise draw
+    cfg = configs.mini_config()
+    cfg["dm"] = False
+    run_e2e(ref, cfg, frozen("mini_baseline_room", lambda: synth.room_scene(30, 1900)), 43, 11, "mini_baseline_room", False)
+
+
 def gen_ddim(ref):
     """Multi-step inference (MSAI mode="avg", MSFI mode="final"), default.py:278-369."""
     for tag, step, mode, seed in (("mini_ddim_avg2", 2, "avg", 17), ("mini_ddim_final1", 1, "final", 18)):
         cfg = configs.mini_config()
         model, sd = ref_model(ref, cfg, seed=6)
-        scene = synth.room_scene(27, 1800)
+        scene = frozen(tag, lambda: synth.room_scene(27, 1800))
         torch.manual_seed(seed)
         with DrawRecorder() as rec, torch.no_grad():
             out = model.inference_ddim(to_torch_input(scene), T=cfg["T"], step=step, eval=False, mode=mode)
@@ -275,7 +337,7 @@ def gen_ddim(ref):
                   sd_checksum=np.float64(sum(float(v.double().abs().sum()) for v in sd.values())),
                   sd_keys=np.array(list(sd.keys())),
                   sd_shapes=np.array([json.dumps(list(v.shape)) for v in sd.values()]))
-        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **fx)
+        save_fixture(os.path.join(OUT, f"{tag}.npz"), **fx)
         print(tag, out["seg_logits"].shape, float(out["seg_logits"].abs().mean()))
 
 
@@ -284,7 +346,7 @@ def gen_ptv3(ref):
     cfg = configs.mini_config()
     cfg["condition"] = cfg["backbone"]["condition"] = False
     cfg["dm"] = False
-    run_e2e_nocond(ref, cfg, synth.room_scene(28, 2100), 21, 7, "mini_ptv3_room")
+    run_e2e_nocond(ref, cfg, frozen("mini_ptv3_room", lambda: synth.room_scene(28, 2100)), 21, 7, "mini_ptv3_room")
 
 
 def run_e2e_nocond(ref, cfg, scene, seed, sd_seed, tag):
@@ -300,7 +362,7 @@ def run_e2e_nocond(ref, cfg, scene, seed, sd_seed, tag):
               noise=np.zeros((0, 0), dtype=np.float32), cfg_json=np.array(json.dumps(cfg)),
               sd_checksum=np.float64(sum(float(v.double().abs().sum()) for v in sd.values())),
               sd_keys=np.array(list(sd.keys())), sd_shapes=np.array([json.dumps(list(v.shape)) for v in sd.values()]))
-    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **fx)
+    save_fixture(os.path.join(OUT, f"{tag}.npz"), **fx)
     print(tag, out["seg_logits"].shape, float(out["seg_logits"].abs().mean()), "params", len(sd))
 
 
@@ -324,7 +386,7 @@ def gen_gridsample(ref):
             assert np.array_equal(p["coord"], coord[p["index"]]) and np.array_equal(p["color"], color[p["index"]])
         idx = np.stack([p["index"] for p in parts]).astype(np.int64)
         gc = np.stack([p["grid_coord"] for p in parts]).astype(np.int64)
-        np.savez_compressed(os.path.join(OUT, f"gridsample_test_{tag}.npz"), coord=coord, grid_size=np.float64(gsize),
+        save_fixture(os.path.join(OUT, f"gridsample_test_{tag}.npz"), coord=coord, grid_size=np.float64(gsize),
                             index=idx, grid_coord=gc)
         print("gridsample", tag, idx.shape)
 
@@ -344,7 +406,7 @@ def gen_iou(ref):
         i, u, t = M.intersection_and_union(pred, target, k, -1)
         fx.update({f"{tag}_pred": pred, f"{tag}_target": target, f"{tag}_k": np.int64(k), f"{tag}_inter": i,
                    f"{tag}_union": u, f"{tag}_tgt": t})
-    np.savez_compressed(os.path.join(OUT, "iou_counts.npz"), **fx)
+    save_fixture(os.path.join(OUT, "iou_counts.npz"), **fx)
     print("iou fixture", {k: v.shape for k, v in fx.items() if k.endswith("inter")})
 
 
@@ -352,11 +414,13 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["ser", "e2e", "ddim", "ptv3"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "iou"]
     if "ser" in which:
         gen_serialization(ref)
     if "e2e" in which:
         gen_e2e(ref)
+    if "cfg" in which:
+        gen_configs(ref)
     if "ddim" in which:
         gen_ddim(ref)
     if "ptv3" in which:

@@ -453,9 +453,11 @@ def backbone_forward(cfg, sd, c_in, n_in, perms, run_dead=True, trace=None):
 
 
 def inference(cfg, sd, input_dict, draws, T=1000, noise_level=None, run_dead=False, trace=None,
-              flash_semantics=True):
-    """DefaultSegmentorV2.inference (default.py:371-422) with condition=True, dm=True,
-    dm_input='xt', eval=False.  input_dict: coord, grid_coord, offset, feat (torch/numpy).
+              flash_semantics=True, dm=True):
+    """DefaultSegmentorV2.inference (default.py:371-422) with condition=True, dm_input='xt', eval=False.
+    dm=True (CDSegNet / PTv3_CNF configs): the c-branch input is N(0,1) noise at t = T-1;
+    dm=False (configs/*/Baseline.py): the c-branch sees the conditioning target itself at t = 0, no draw
+    (default.py:391-394).  input_dict: coord, grid_coord, offset, feat (torch/numpy).
     Returns seg_logits (N, num_classes) fp32."""
     feat = torch.as_tensor(input_dict["feat"], dtype=torch.float32)
     coord = torch.as_tensor(input_dict["coord"], dtype=torch.float32)
@@ -466,9 +468,12 @@ def inference(cfg, sd, input_dict, draws, T=1000, noise_level=None, run_dead=Fal
     c_in_ch = cfg.get("c_in_channels", 6)
     target = feat if c_in_ch == feat.shape[-1] else coord  # default.py:386-389
     N = len(target)
-    noise = draws["noise"]
-    assert tuple(noise.shape) == tuple(target.shape)
-    t = T - 1
+    if dm:
+        noise = draws["noise"]
+        assert tuple(noise.shape) == tuple(target.shape)
+        t = T - 1
+    else:
+        noise, t = target, 0
     ts = t * torch.ones((N, 1), dtype=torch.int64)
     T_dim = cfg.get("T_dim", 128)
     c_in = dict(coord=coord, grid=grid, offset=offset, feat=noise)

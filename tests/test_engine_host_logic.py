@@ -35,7 +35,8 @@ def _run(name, precision, enable_flash):
     return out, fx["logits"], model
 
 
-@pytest.mark.parametrize("name", ["mini_e2e_room", "mini_e2e_batch2", "mini_e2e_lidar", "mini_e2e_noise"])
+@pytest.mark.parametrize("name", ["mini_e2e_room", "mini_e2e_batch2", "mini_e2e_lidar", "mini_e2e_noise", "mini_e2e_lidar8",
+                                  "mini_e2e_robust", "mini_cnf_room", "mini_baseline_room"])
 def test_engine_host_logic_fp32(emulated, name):
     out, ref, _ = _run(name, "fp32", enable_flash=False)
     err = np.abs(out - ref).max()
@@ -84,11 +85,15 @@ def test_engine_inference_ddim(emulated, name):
     draws = dict(noise=torch.from_numpy(fx["noise"]), perms=[p for p in fx["perms"]])
     out = model.inference_ddim(inp, T=cfg["T"], step=int(fx["step"]), eval=False, mode=str(fx["mode"]),
                                draws=draws)["seg_logits"].numpy()
-    assert np.abs(out - fx["logits"]).max() < 5e-4
+    err = np.abs(out - fx["logits"]).max()
+    print(f"{name}: emulated engine vs reference {err:.3e}")
+    # single-step level: a wrong tensor handed to the c-decoder (the un-normed kv feature after the cross block) showed
+    # up as 1e-4 here while the SSI cases sat at 1e-6
+    assert err < 2e-5
     # seeded default draws replay the reference's (normal, then 8 randperm per backbone call)
     torch.manual_seed(int(fx["seed"]))
     out2 = model.inference_ddim(inp, T=cfg["T"], step=int(fx["step"]), eval=False, mode=str(fx["mode"]))["seg_logits"]
-    assert np.abs(out2.numpy() - fx["logits"]).max() < 5e-4
+    assert np.abs(out2.numpy() - fx["logits"]).max() < 2e-5
 
 
 def test_engine_ptv3_without_condition(emulated):
@@ -136,7 +141,7 @@ def test_testtime_pipeline_host_logic(emulated, monkeypatch):
     assert np.array_equal(labels.numpy(), ref_labels)
 
 
-@pytest.mark.parametrize("name", ["tiny64", "room1500", "batch2", "lidar5000", "rand16"])
+@pytest.mark.parametrize("name", ["tiny64", "room1500", "batch2", "lidar5000", "rand16", "lidar8"])
 def test_coarse_orders_need_no_sort(name):
     """The property the engine's plan relies on: z-order / Hilbert keys are hierarchical, so arg-sorting the shifted
     codes of a pooled level (ptv3.py:503-514) equals de-duplicating the cluster ids along the level-0 order."""

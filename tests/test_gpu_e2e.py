@@ -56,7 +56,10 @@ def report(name, logits, ref):
     return err, agree
 
 
-E2E = ["mini_e2e_room", "mini_e2e_batch2", "mini_e2e_lidar", "mini_e2e_noise"]
+E2E = ["mini_e2e_room", "mini_e2e_batch2", "mini_e2e_lidar", "mini_e2e_noise",
+       # round 2: the BASELINE workload shapes (8 collated LiDAR sweeps; noise + drop + re-voxelise) and the other
+       # shipped model variants (PTv3_CNF depths / linear schedule; Baseline dm=False), all from the reference
+       "mini_e2e_lidar8", "mini_e2e_robust", "mini_cnf_room", "mini_baseline_room"]
 
 
 @pytest.mark.parametrize("name", E2E)

@@ -13,7 +13,7 @@ from tests.helpers import load_fixture
 
 pytestmark = pytest.mark.gpu
 
-CLOUDS = ["tiny64", "room1500", "batch2", "lidar5000", "rand16"]
+CLOUDS = ["tiny64", "room1500", "batch2", "lidar5000", "rand16", "lidar8"]
 
 
 @pytest.fixture(scope="module")

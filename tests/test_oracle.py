@@ -7,7 +7,7 @@ from oracle import model as OM
 from oracle import serialization as S
 from tests.helpers import fixture_cfg, fixture_draws, fixture_input, fixture_state_dict, load_fixture
 
-CLOUDS = ["tiny64", "room1500", "batch2", "lidar5000", "rand16"]
+CLOUDS = ["tiny64", "room1500", "batch2", "lidar5000", "rand16", "lidar8"]
 
 
 def test_known_answers():
@@ -105,7 +105,10 @@ def test_subm_conv_matches_dense_conv3d():
         assert torch.allclose(out, ref, atol=1e-4), (k, float((out - ref).abs().max()))
 
 
-E2E = ["mini_e2e_room", "mini_e2e_batch2", "mini_e2e_lidar", "mini_e2e_noise"]
+E2E = ["mini_e2e_room", "mini_e2e_batch2", "mini_e2e_lidar", "mini_e2e_noise",
+       # round 2: the BASELINE workload shapes (8 collated LiDAR sweeps; noise + drop + re-voxelise) and the other
+       # shipped model variants (PTv3_CNF depths / linear schedule; Baseline dm=False), all from the reference
+       "mini_e2e_lidar8", "mini_e2e_robust", "mini_cnf_room", "mini_baseline_room"]
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -116,8 +119,9 @@ def test_e2e_mini_matches_reference(name):
     trace = {}
     nl = float(fx["noise_level"]) if "noise_level" in fx.files else None
     # the fixtures come from the reference's CPU (non-flash) branch: K = min(min_b n_b, 1024)
+    dm = bool(cfg["dm"])
     logits = OM.inference(cfg["backbone"], sd, fixture_input(fx), fixture_draws(fx), T=cfg["T"],
-                          noise_level=nl, run_dead=True, trace=trace, flash_semantics=False).numpy()
+                          noise_level=nl, run_dead=True, trace=trace, flash_semantics=False, dm=dm).numpy()
     err = np.abs(logits - fx["logits"]).max()
     assert err < 2e-4, err
     assert (logits.argmax(1) == fx["logits"].argmax(1)).mean() > 0.999
@@ -126,11 +130,11 @@ def test_e2e_mini_matches_reference(name):
         assert np.abs(trace["n_fused"].numpy() - fx["trace.backbone._tm_dec0"]).max() < 2e-4
     # the c-decoder / c-head are dead code in single-step inference
     logits2 = OM.inference(cfg["backbone"], sd, fixture_input(fx), fixture_draws(fx), T=cfg["T"],
-                           noise_level=nl, run_dead=False, flash_semantics=False).numpy()
+                           noise_level=nl, run_dead=False, flash_semantics=False, dm=dm).numpy()
     assert np.array_equal(logits, logits2)
     if len(fx["offset"]) == 1:  # one batch element: flash and non-flash patching coincide
         logits3 = OM.inference(cfg["backbone"], sd, fixture_input(fx), fixture_draws(fx), T=cfg["T"],
-                               noise_level=nl, flash_semantics=True).numpy()
+                               noise_level=nl, flash_semantics=True, dm=dm).numpy()
         assert np.array_equal(logits, logits3)
 
 
