@@ -45,7 +45,7 @@ class BlockDesc(Structure):
         ("cpe_ln_g", c_void_p), ("cpe_ln_b", c_void_p), ("norm1_g", c_void_p), ("norm1_b", c_void_p),
         ("qkv_w", c_void_p), ("qkv_b", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p),
         ("norm2_g", c_void_p), ("norm2_b", c_void_p), ("fc1_w", c_void_p), ("fc1_b", c_void_p),
-        ("fc2_w", c_void_p), ("fc2_b", c_void_p),
+        ("fc2_w", c_void_p), ("fc2_b", c_void_p), ("cpe_conv_wimg", c_void_p),
     ]
 
 
@@ -106,6 +106,9 @@ SIGNATURES = {
     "cdseg_cpe_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int,
                                      c_void_p]),
+    "cdseg_subm_conv3_wimg_bytes": (c_size_t, [c_int]),
+    "cdseg_subm_conv3_pack": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "cdseg_subm_conv3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
     "cdseg_stem_conv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,

@@ -1,0 +1,306 @@
+// Submanifold 3x3x3 sparse convolution for the wide, bandwidth-bound stages (C = 32 / 64, bf16) on gfx950.
+//
+//   y[i, :] = bias + sum_o W_o x[nbr[o, i], :]          (spconv.SubMConv3d; ref call sites ptv3.py:356-362 - the CPE
+//                                                         conv of every Block; nbr = the offset-major kernel map)
+//
+// The tiled gathered-A GEMM (gemm.hip) stages the gathered rows AND the weight columns of every 128-row tile through
+// LDS: per launch ~6x the compulsory bytes move L2 -> LDS, and a tile is a chain of barrier-separated
+// index -> row -> LDS round trips (PMC, profiles/r01l: VALU 11 %, matrix pipe 2 %, 60 % of the wave cycles idle).
+// This kernel turns the roles around:
+//   * W is STATIONARY: the whole 27 x C x C kernel lives in LDS for the lifetime of a persistent block (C = 32:
+//     55 KB, 2 blocks / CU; C = 64: the 19 face / edge / centre offsets = 152 KB, the 8 corner offsets - rarely
+//     occupied on scanned surfaces - are read from L2), laid out in MFMA A-fragment order (conflict-free b128 reads);
+//   * gathered rows go STRAIGHT into MFMA B-fragment registers: lane (j, c) of v_mfma_f32_16x16x32_bf16 holds
+//     channels 8c..8c+7 of point j, which is one 16-byte load from row nbr[o, j] - no LDS round trip, no barrier,
+//     no zero-filled slots for missing neighbours (the load is simply predicated off);
+//   * waves are independent (no __syncthreads in the main loop): latency is hidden by 4-6 waves per SIMD, each with
+//     the index loads of offset group g+2 and the row loads of group g+1 in flight behind the MFMAs of group g;
+//   * the product is computed transposed (D^T = W X^T) with the output channels permuted inside the A operand so
+//     that a lane ends up holding C/4 CONSECUTIVE channels of one point: the epilogue is bias + one (two) 16-byte
+//     store(s) per lane, 16 complete rows = 1 KB contiguous per store instruction - no LDS transpose;
+//   * offsets no point of the wave's 32 rows has (z-ordered points: 15-20 of 27) skip their MFMAs (wave-uniform).
+// HBM traffic = features once + kernel map once + output once; W never leaves the CU after the first tile.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+struct ConvP {
+  const bf16_t* x;      // (n, ldx) bf16
+  const float* bias;    // (C) or nullptr
+  const int32_t* nbr;   // (27, n) offset-major kernel map, -1 = no neighbour
+  bf16_t* y;            // (n, ldy) bf16
+  long n;
+  int ldx, ldy;
+  int row_shift;        // log2(ldx * 2): byte stride of a feature row (a power of two)
+  int tiles;            // ceil(n / ROWS_PER_BLOCK)
+};
+
+// offsets in LDS-residency priority order (C = 64 keeps the first 19 in LDS): centre, 6 faces, 12 edges, 8 corners
+__device__ __constant__ int8_t c_slot_of_offset[27] = {
+    // o = a*9 + b*3 + c, (a,b,c) in {0,1,2}^3; #ones = number of coordinates equal to 1 (centre = 3, face = 2, edge = 1)
+    19, 7, 20, 8, 1, 9, 21, 10, 22,   // a = 0
+    11, 2, 12, 3, 0, 4, 13, 5, 14,    // a = 1
+    23, 15, 24, 16, 6, 17, 25, 18, 26 // a = 2
+};
+
+template <int C>
+struct ConvCfg {
+  static constexpr int CT = C / 16;       // 16-channel output tiles
+  static constexpr int KS = C / 32;       // MFMA k steps per offset
+  static constexpr int KC = C / 8;        // 16-byte channel chunks per row
+  static constexpr int OFF_BYTES = C * C * 2;                // one offset's weights
+  static constexpr int LDS_OFFSETS = C <= 32 ? 27 : 19;      // offsets resident in LDS
+  static constexpr int LDS_BYTES = LDS_OFFSETS * OFF_BYTES;  // 55,296 / 155,648
+  static constexpr int WAVES = C <= 32 ? 8 : 16;             // C = 32: 2 blocks / CU, C = 64: 1 -> 4 waves / SIMD
+  static constexpr int RG = 2;                               // 16-row groups per wave
+  static constexpr int G = C <= 32 ? 3 : 1;                  // offsets per pipeline group (register budget 128)
+  static constexpr int ROWS_PER_WAVE = RG * 16;
+  static constexpr int ROWS_PER_BLOCK = WAVES * ROWS_PER_WAVE;
+};
+
+// Fragment-order weight image.  16-byte unit u = ((slot * CT + ct) * KC + kc) * 16 + i holds
+// W[channel(ct, i)][o * C + kc * 8 .. + 8] with channel(ct, i) = (i >> 2) * (C / 4) + ct * 4 + (i & 3):
+// lane l of the MFMA reads unit (.., kc = 4 * ks + (l >> 4), i = l & 15) -> a wave reads 1 KB contiguous.
+template <int C>
+__device__ __forceinline__ int frag_channel(int ct, int i) {
+  return (i >> 2) * (C / 4) + ct * 4 + (i & 3);
+}
+
+template <int C>
+__global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_pack_w_kernel(const bf16_t* w, uint4* img) {
+  // one-off repack (per weight tensor, cached by the caller): global image in the same fragment order, slot-major, so
+  // that the resident part is one contiguous copy and a corner offset is a 1 KB-per-wave contiguous read from L2
+  using K = ConvCfg<C>;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= 27 * K::CT * K::KC * 16) return;
+  const int i = u & 15, kc = (u >> 4) % K::KC, ct = (u >> 4) / K::KC % K::CT, slot = (u >> 4) / (K::KC * K::CT);
+  int o = slot;  // C = 32: everything is resident, slots in offset order
+  if (K::LDS_OFFSETS != 27)
+    for (int q = 0; q < 27; ++q)
+      if (c_slot_of_offset[q] == slot) o = q;
+  img[u] = *reinterpret_cast<const uint4*>(w + (long)frag_channel<C>(ct, i) * (27 * C) + o * C + kc * 8);
+}
+
+template <int C>
+__global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p, const uint4* __restrict__ wimg) {
+  using K = ConvCfg<C>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int jrow = lane & 15;  // point within a 16-row group (B operand column)
+  const int cgrp = lane >> 4;  // channel chunk of the k step (B operand k block) / channel group of the result
+
+  // ---- resident weights: one contiguous copy of the fragment image (L2 -> LDS), once per persistent block
+  {
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int u = tid; u < K::LDS_BYTES / 16; u += K::WAVES * 64) dst[u] = wimg[u];
+  }
+  __syncthreads();
+
+
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.n * p.ldx * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t nbr_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.nbr, 0, (int)(p.n * 27 * 4), 0x00020000);
+
+  // tiles: XCD x (block id mod 8, performance-only assumption) owns a contiguous range of row tiles so that the
+  // neighbour gathers of z-ordered rows stay in one L2
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = (gridDim.x + 7 - xcd) >> 3;
+  const int per = (p.tiles + 7) >> 3;
+  const int t_end = min(p.tiles, (xcd + 1) * per);
+  for (int tile = xcd * per + bx; tile < t_end; tile += nbx) {
+    const long row0 = (long)tile * K::ROWS_PER_BLOCK + wave * K::ROWS_PER_WAVE;
+    if (row0 >= p.n) continue;  // no barrier below: waves are independent
+    long myrow[K::RG];
+    bool rowok[K::RG];
+    unsigned idx_off[K::RG];
+#pragma unroll
+    for (int g = 0; g < K::RG; ++g) {
+      myrow[g] = row0 + g * 16 + jrow;
+      rowok[g] = myrow[g] < p.n;
+      idx_off[g] = (unsigned)((rowok[g] ? myrow[g] : p.n - 1) * 4);
+    }
+    f32x4_t acc[K::RG][K::CT];
+#pragma unroll
+    for (int g = 0; g < K::RG; ++g)
+#pragma unroll
+      for (int ct = 0; ct < K::CT; ++ct) acc[g][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // software pipeline over NS = 27 / G steps of G offsets, two buffer sets in ping-pong (static register names):
+    // while the MFMAs of step s run, the row loads of step s+1 and the index loads of step s+2 are in flight
+    constexpr int G = K::G, NS = 27 / G;
+    static_assert(NS * G == 27 && (NS & 1), "an odd number of steps: pairs + one tail step");
+    int idx[2][G][K::RG];
+    bf16x8_t xb[2][G][K::RG][K::KS];
+    // all gathers are BUFFER loads: an out-of-range offset returns zeros without touching memory and without a
+    // branch (a missing neighbour, index -1, wraps to an offset beyond the end of x)
+    auto load_idx = [&](int step, auto buf) {
+      constexpr int B = decltype(buf)::value;
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int g = 0; g < K::RG; ++g)  // rows past the end read the last row's map: computed, never stored
+          idx[B][q][g] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, idx_off[g], (step * G + q) * (int)(p.n * 4), 0);
+    };
+    auto load_rows = [&](auto buf) {
+      constexpr int B = decltype(buf)::value;
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int g = 0; g < K::RG; ++g)
+#pragma unroll
+          for (int ks = 0; ks < K::KS; ++ks) {
+            // -1 << row_shift wraps to the top of the 32-bit offset range: out of bounds -> zeros
+            const unsigned off = ((unsigned)idx[B][q][g] << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
+            const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
+            xb[B][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
+          }
+    };
+    // which of the step's offsets does ANY of the wave's 32 rows have (wave-uniform bit mask)
+    auto live_mask = [&](auto buf) {
+      constexpr int B = decltype(buf)::value;
+      unsigned m = 0;
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < K::RG; ++g) any |= idx[B][q][g] >= 0;
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) m |= 1u << q;
+      }
+      return m;
+    };
+    auto mfma_step = [&](int step, unsigned live, auto buf) {
+      constexpr int B = decltype(buf)::value;
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        if (!((live >> q) & 1u)) continue;  // wave-uniform: nobody in these 32 rows has this offset
+        const int slot = K::LDS_OFFSETS == 27 ? step * G + q : (int)c_slot_of_offset[step * G + q];
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < K::CT; ++ct) {
+            const int unit = ((slot * K::CT + ct) * K::KC + ks * 4 + cgrp) * 16 + jrow;
+            bf16x8_t wf;
+            if (K::LDS_OFFSETS == 27 || slot < K::LDS_OFFSETS)
+              wf = *reinterpret_cast<const bf16x8_t*>(smem + unit * 16);
+            else
+              wf = *reinterpret_cast<const bf16x8_t*>(wimg + unit);  // corner offset of the C = 64 kernel: L2
+#pragma unroll
+            for (int g = 0; g < K::RG; ++g)
+              acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[B][q][g][ks], acc[g][ct], 0, 0, 0);
+          }
+      }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    load_idx(0, B0{});
+    load_idx(1, B1{});
+    load_rows(B0{});
+#pragma unroll 1
+    for (int step = 0; step + 1 < NS; step += 2) {
+      {
+        const unsigned live = live_mask(B0{});
+        load_rows(B1{});            // step + 1
+        load_idx(step + 2, B0{});   // step + 2 <= NS - 1 (its row addresses / live bits of `step` are consumed)
+        mfma_step(step, live, B0{});
+      }
+      {
+        const unsigned live = live_mask(B1{});
+        load_rows(B0{});            // step + 2
+        if (step + 3 < NS) load_idx(step + 3, B1{});
+        mfma_step(step + 1, live, B1{});
+      }
+    }
+    mfma_step(NS - 1, live_mask(B0{}), B0{});
+    // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
+#pragma unroll
+    for (int g = 0; g < K::RG; ++g) {
+      if (!rowok[g]) continue;
+      bf16_t* dst = p.y + myrow[g] * p.ldy + cgrp * (C / 4);
+#pragma unroll
+      for (int h = 0; h < K::CT / 2; ++h) {
+        // the lane's channels cgrp * C/4 + 8h .. + 7 are consecutive: bias as two float4 (L1-resident)
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (p.bias) {
+          b0 = *reinterpret_cast<const float4*>(p.bias + cgrp * (C / 4) + 8 * h);
+          b1 = *reinterpret_cast<const float4*>(p.bias + cgrp * (C / 4) + 8 * h + 4);
+        }
+        uint4 u;
+        u.x = pack_bf16x2(acc[g][2 * h][0] + b0.x, acc[g][2 * h][1] + b0.y);
+        u.y = pack_bf16x2(acc[g][2 * h][2] + b0.z, acc[g][2 * h][3] + b0.w);
+        u.z = pack_bf16x2(acc[g][2 * h + 1][0] + b1.x, acc[g][2 * h + 1][1] + b1.y);
+        u.w = pack_bf16x2(acc[g][2 * h + 1][2] + b1.z, acc[g][2 * h + 1][3] + b1.w);
+        *reinterpret_cast<uint4*>(dst + 8 * h) = u;
+      }
+    }
+  }
+}
+
+template <int C>
+int launch_pack(const bf16_t* w, void* wimg, hipStream_t s) {
+  using K = ConvCfg<C>;
+  const int units = 27 * K::CT * K::KC * 16;
+  hipLaunchKernelGGL((conv_pack_w_kernel<C>), dim3((units + K::WAVES * 64 - 1) / (K::WAVES * 64)), dim3(K::WAVES * 64), 0, s,
+                     w, (uint4*)wimg);
+  return hipGetLastError() == hipSuccess ? CDSEG_OK : CDSEG_ERR_LAUNCH;
+}
+
+template <int C>
+int launch_conv(const ConvP& p0, const void* wimg, hipStream_t s) {
+  using K = ConvCfg<C>;
+  ConvP p = p0;
+  p.tiles = (int)((p.n + K::ROWS_PER_BLOCK - 1) / K::ROWS_PER_BLOCK);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)conv_rg_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) !=
+        hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  // persistent blocks: as many as are co-resident (LDS: 2 per CU at C = 32, 1 at C = 64), never more than tiles
+  static const int blocks_per_cu = []() { const char* e = getenv("CDSEG_CONV_RG_BLOCKS"); return e ? atoi(e) : 0; }();
+  int per_cu = K::LDS_BYTES > 80 * 1024 ? 1 : 2;
+  if (blocks_per_cu > 0) per_cu = blocks_per_cu;
+  int grid = 256 * per_cu;
+  if (grid > p.tiles) grid = (p.tiles + 7) / 8 * 8;  // every XCD keeps a block for its tile range
+  hipLaunchKernelGGL((conv_rg_kernel<C>), dim3(grid), dim3(K::WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
+  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
+  return CDSEG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t cdseg_subm_conv3_wimg_bytes(int channels) {
+  return (channels == 32 || channels == 64) ? (size_t)27 * channels * channels * 2 : 0;
+}
+
+extern "C" int cdseg_subm_conv3_pack(const void* w, int channels, void* wimg, void* stream) {
+  if (!w || !wimg || (((uintptr_t)w | (uintptr_t)wimg) & 15)) return CDSEG_ERR_ARG;
+  if (channels == 32) return launch_pack<32>((const bf16_t*)w, wimg, (hipStream_t)stream);
+  if (channels == 64) return launch_pack<64>((const bf16_t*)w, wimg, (hipStream_t)stream);
+  return CDSEG_ERR_UNSUPPORTED;
+}
+
+extern "C" int cdseg_subm_conv3(const void* x, int ldx, const void* wimg, const float* bias, const int32_t* nbr_kmajor,
+                                long n, int channels, void* y, int ldy, void* stream) {
+  if (!x || !nbr_kmajor || !y || !wimg) return CDSEG_ERR_ARG;
+  if (n <= 0) return CDSEG_OK;
+  if (channels != 32 && channels != 64) return CDSEG_ERR_UNSUPPORTED;
+  if (n * 27 * 4 >= (1l << 31) || n * (long)ldx * 2 >= (1l << 31) - 65536) return CDSEG_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+  if ((ldx & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wimg) & 15)) return CDSEG_ERR_ARG;
+  if (bias && (((uintptr_t)bias) & 15)) return CDSEG_ERR_ARG;
+  ConvP p;
+  p.x = (const bf16_t*)x; p.bias = bias; p.nbr = nbr_kmajor; p.y = (bf16_t*)y;
+  p.n = n; p.ldx = ldx; p.ldy = ldy; p.tiles = 0;
+  p.row_shift = 0;
+  while ((1 << p.row_shift) < ldx * 2) ++p.row_shift;
+  if ((1 << p.row_shift) != ldx * 2) return CDSEG_ERR_UNSUPPORTED;  // feature rows with a power-of-two stride only
+  hipStream_t s = (hipStream_t)stream;
+  return channels == 32 ? launch_conv<32>(p, wimg, s) : launch_conv<64>(p, wimg, s);
+}

@@ -86,7 +86,11 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
   int rc;
 
   // ---- CPE: x += LN(Linear(SubMConv3d(xc)))  [+ t bias];  h = LN1(x)      (ptv3.py:401-413)
-  {
+  if (d->cpe_conv_wimg && T == CDSEG_BF16 && (C == 32 || C == 64)) {
+    // wide stages: weight-stationary register-gather conv (conv.hip)
+    rc = cdseg_subm_conv3(io->xc_in, C, d->cpe_conv_wimg, (const float*)d->cpe_conv_b, io->nbr, n, C, L.y, C, stream);
+    if (rc != CDSEG_OK) return rc;
+  } else {
     cdseg_gemm_args a = base_args(d, L, n);
     a.A = io->xc_in; a.lda = C; a.W = d->cpe_conv_w; a.bias = d->cpe_conv_b; a.nbr = io->nbr; a.nbr_kmajor = 1; a.kvol = 27;
     a.N = C; a.K = C; a.out = L.y; a.ldo = C; a.out_dtype = T;

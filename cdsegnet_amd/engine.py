@@ -188,6 +188,11 @@ class Engine:
         def conv(mod, pre):
             w[pre + ".w"] = mod.weight.detach().reshape(mod.weight.shape[0], -1).to(device=device, dtype=T).contiguous()
             w[pre + ".b"] = f32(mod.bias) if mod.bias is not None else None
+            # wide bf16 stages (C = 32 / 64, k = 3): fragment-order image for the weight-stationary conv kernel
+            k, cin, cout = mod.kernel_size, mod.in_channels, mod.out_channels
+            if (k == 3 and cin == cout and hasattr(ops, "subm_conv3_pack") and
+                    ops.subm_conv3_ok(torch.empty((1, cin), dtype=T, device="meta"))):
+                w[pre + ".wimg"] = ops.subm_conv3_pack(w[pre + ".w"])
 
         def ln(mod, pre):
             w[pre + ".g"], w[pre + ".b"] = f32(mod.weight), f32(mod.bias)
@@ -315,6 +320,8 @@ class Engine:
                          qkv_b=w[pre + ".qkv.b"], proj_w=w[pre + ".proj.w"], proj_b=w[pre + ".proj.b"],
                          norm2_g=w[pre + ".norm2.g"], norm2_b=w[pre + ".norm2.b"], fc1_w=w[pre + ".fc1.w"],
                          fc1_b=w[pre + ".fc1.b"], fc2_w=w[pre + ".fc2.w"], fc2_b=w[pre + ".fc2.b"])
+                if hasattr(ops, "subm_conv3_pack") and ops.subm_conv3_ok(torch.empty((1, mod.channels), dtype=T, device="meta")):
+                    t["cpe_conv_wimg"] = w[pre + ".cpe0.wimg"]
                 self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
                                                            mod.attn.scale, 1e-5, t)
         self._scratch = {}
@@ -444,13 +451,22 @@ class Engine:
 
     FUSE_LN_MAX_C = 512  # rows up to this width are finished by one GEMM block -> LayerNorm in the epilogue
 
+    def _conv3(self, xc, pre, lv, y):
+        """y = SubMConv3d_k3(xc) (ref: ptv3.py:356-362): the weight-stationary kernel on the wide bf16 stages, the
+        gathered-A GEMM elsewhere."""
+        w = self.w
+        if (pre + ".wimg") in w and ops.subm_conv3_ok(xc):
+            ops.subm_conv3(xc, w[pre + ".wimg"], w[pre + ".b"], lv.nbr(3, True), y)
+        else:
+            ops.gemm(xc, w[pre + ".w"], y, bias=w[pre + ".b"], nbr=lv.nbr(3, True), nbr_kmajor=True, kvol=27)
+
     def _cpe(self, st, pre, xc, tbias=None, next_norm=None):
         """x += LN(Linear(SubMConv3d(xc)))  [+ t bias]   (ref: ptv3.py:401-411).
         next_norm: weight prefix of the LayerNorm that follows on x; returns its output h (dtype T)."""
         w, lv = self.w, st.level
         c = st.x.shape[1]
         y = self._buf(lv.n, c, self.T)
-        ops.gemm(xc, w[pre + "0.w"], y, bias=w[pre + "0.b"], nbr=lv.nbr(3, True), nbr_kmajor=True, kvol=27)
+        self._conv3(xc, pre + "0", lv, y)
         h = self._buf(lv.n, c, self.T) if next_norm else None
         if c <= self.FUSE_LN_MAX_C:
             ops.gemm(y, w[pre + "1.w"], st.x, bias=w[pre + "1.b"], ln_pre=(w[pre + "2.g"], w[pre + "2.b"]), res=st.x,
@@ -508,7 +524,7 @@ class Engine:
         qkv = self._buf(n, 3 * c, self.T)
         if ops.cpe_head_fused_ok(st.xc):  # big stages: cpe linear + LN + residual + LN1 + qkv in one launch
             y = self._buf(n, c, self.T)
-            ops.gemm(st.xc, w[pre + ".cpe0.w"], y, bias=w[pre + ".cpe0.b"], nbr=lv.nbr(3, True), nbr_kmajor=True, kvol=27)
+            self._conv3(st.xc, pre + ".cpe0", lv, y)
             ops.cpe_head_fused(y, w[pre + ".cpe1.w"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
                                tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.w"], w[pre + ".qkv.b"], qkv)
         else:
@@ -685,8 +701,13 @@ class Engine:
     def reserve_rng(self, k=None):
         """Reserve a block of device-RNG stream ids (call in scene order from ONE thread: keeps the device noise
         of scene i independent of which lane / thread runs it)."""
+        if self.model.noise_source == "device":
+            # device-noise mode: the stream ids come from torch's CPU generator itself (one draw per call, after the
+            # order shuffles), so the logits are a function of the generator state alone: torch.manual_seed(s) followed
+            # by the same calls reproduces them, whatever ran before in the process
+            return int(torch.randint(0, 2 ** 31 - 1024, (1,)).item())
         seed = torch.initial_seed()
-        if seed != self._rng_seed:  # torch.manual_seed(s) restarts the device-noise sequence: same seed, same logits
+        if seed != self._rng_seed:  # a new torch.manual_seed restarts the counter (used by feat_noise_source="device")
             self._rng_seed, self.rng_offset = seed, 0
         base = self.rng_offset
         self.rng_offset += self.RNG_RESERVE if k is None else int(k)

@@ -542,6 +542,30 @@ def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start
     check(_lib.load().cdseg_block_forward(desc[1], ref, _stream()), "block_forward")
 
 
+def subm_conv3_ok(x):
+    """The weight-stationary register-gather conv (csrc/conv.hip) covers the wide bf16 stages: C = 32 / 64."""
+    on = os.environ.get("CDSEG_CONV_RG", "1") != "0"
+    return on and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (32, 64) and x.stride(0) == x.shape[1]
+
+
+def subm_conv3_pack(w):
+    """(C, 27*C) bf16 weight of a k = 3 submanifold conv -> its MFMA-fragment-order image (built once per weight)."""
+    _need_gpu(w)
+    c = w.shape[0]
+    img = torch.empty(_lib.load().cdseg_subm_conv3_wimg_bytes(c), dtype=torch.uint8, device=w.device)
+    check(_lib.load().cdseg_subm_conv3_pack(_ptr(w), c, _ptr(img), _stream()), "subm_conv3_pack")
+    return img
+
+
+def subm_conv3(x, wimg, bias, nbr_kmajor, out):
+    """out (n, C) bf16 = bias + sum_o x[nbr[o]] W_o^T   (ref call sites: ptv3.py:356-362)."""
+    _need_gpu(x, wimg, nbr_kmajor, out)
+    n, c = x.shape
+    check(_lib.load().cdseg_subm_conv3(_ptr(x), x.stride(0), _ptr(wimg), _ptr(bias), _ptr(nbr_kmajor), n, c, _ptr(out),
+                                       out.stride(0), _stream()), "subm_conv3")
+    return out
+
+
 def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):
     """SubMConv3d(k=5, bias=False) + folded BN + GELU.  w_packed (kvol, Cin, Cout) fp32."""
     n, cin = x.shape

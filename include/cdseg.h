@@ -295,6 +295,17 @@ int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, const float* bl
                          const void* wqkv, const float* bqkv, void* qkv, int ldqkv, long n, int channels, int dtype,
                          void* stream);
 
+/* ------------------------------------------------------------------ 3x3x3 submanifold conv, wide stages
+ * ref: spconv.SubMConv3d call sites ptv3.py:356-362 (the CPE conv of every Block).  y (n, ldy) bf16 =
+ * bias + sum_o x[nbr[o, i]] W_o^T for C_in = C_out = channels in {32, 64}, bf16: weights stationary in LDS, gathered rows
+ * loaded straight into MFMA fragments (csrc/conv.hip).  wimg = fragment-order image of the (C, 27*C) weight, built once
+ * per weight tensor by cdseg_subm_conv3_pack into a caller-owned buffer of cdseg_subm_conv3_wimg_bytes(channels) bytes.
+ * nbr: OFFSET-MAJOR (27, n) kernel map.  Other shapes / dtypes: CDSEG_ERR_UNSUPPORTED (use cdseg_gemm with nbr). */
+size_t cdseg_subm_conv3_wimg_bytes(int channels);
+int cdseg_subm_conv3_pack(const void* w, int channels, void* wimg, void* stream);
+int cdseg_subm_conv3(const void* x, int ldx, const void* wimg, const float* bias, const int32_t* nbr_kmajor, long n,
+                     int channels, void* y, int ldy, void* stream);
+
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
  * block itself, carving its temporaries from the caller's scratch buffer: sparse-conv CPE, then for bf16 with
@@ -327,6 +338,7 @@ typedef struct cdseg_block_desc {
   const float* fc1_b;
   const void* fc2_w;       /* (C, hidden) T */
   const float* fc2_b;
+  const void* cpe_conv_wimg; /* cdseg_subm_conv3_pack image of cpe_conv_w, or NULL: the conv runs on cdseg_gemm */
 } cdseg_block_desc;
 
 typedef struct cdseg_block_io {

@@ -199,6 +199,18 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     return out
 
 
+def subm_conv3_ok(x):
+    return x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (32, 64)
+
+
+def subm_conv3_pack(w):
+    return w  # the emulation convolves with the plain (C, 27*C) weight
+
+
+def subm_conv3(x, wimg, bias, nbr_kmajor, out):
+    return gemm(x, wimg, out, bias=bias, nbr=nbr_kmajor, nbr_kmajor=True, kvol=27)
+
+
 def cpe_head_fused_ok(y):
     return y.dtype == torch.bfloat16 and y.shape[1] in (32, 64)
 

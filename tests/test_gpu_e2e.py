@@ -122,7 +122,7 @@ def test_native_block_executor_equals_binding_sequence(precision):
 
 
 @pytest.mark.parametrize("name", ["mini_ddim_avg2", "mini_ddim_final1"])
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.12)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16", 0.12)])
 def test_inference_ddim_matches_reference_golden(name, precision, tol):
     """SURVEY.md 8f row 2 (MSAI / MSFI, default.py:278-369): c-decoder + c-head + DDIM update on device,
     step-invariant plan built once."""
@@ -189,6 +189,96 @@ def test_other_configs_full_width_vs_oracle(ds, gen, npts):
     assert err < 1e-3 and agree > 0.999
 
 
+def test_robustness_config_full_width_vs_oracle():
+    """BASELINE config 5 (robustness): Gaussian coord noise sigma = 0.05 m + 50 % random drop, RE-VOXELISED - scattered,
+    mostly isolated voxels (kernel maps with ~1 live offset, other pooling ratios).  Full-width model vs the oracle;
+    the reference itself ran this shape for tests/golden/mini_e2e_robust.npz (mini widths, in E2E above)."""
+    cfg = configs.cdsegnet_config("scannet")
+    model = build_model(cfg)
+    sd = fill_state_dict(model.state_dict(), seed=12)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    sc = synth.perturb_scene(synth.room_scene(43, 8000), seed=5, sigma=0.05, drop=0.5)
+    n = len(sc["coord"])
+    assert 3000 < n <= 4000
+    inp = {k: sc[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    draws = OM.draw_rng(321, n, cfg["c_in_channels"])
+    ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"]).numpy()
+    model.precision = "fp32"
+    logits = run(model, inp, draws)
+    err, agree = report("robustness (sigma 0.05, drop 0.5) full width fp32 vs oracle", logits, ref)
+    assert err < 1e-3 and agree > 0.999
+    # the reference's own robustness knob (noise_level perturbs feat, default.py:373-374) on the same cloud
+    draws = OM.draw_rng(322, n, cfg["c_in_channels"], noise_level_like=sc["feat"].shape)
+    ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"], noise_level=0.1).numpy()
+    logits = run(model, inp, draws, noise_level=0.1)
+    err, agree = report("robustness + noise_level 0.1 fp32 vs oracle", logits, ref)
+    assert err < 1e-3 and agree > 0.999
+
+
+def test_nuscenes_eight_sweeps_collated_vs_oracle():
+    """BASELINE config 4's workload shape: EIGHT nuScenes-shape sweeps collated into one forward (configs/nuscenes/
+    CDSegNet.py batch_size_test_per_gpu = 8; datasets/utils.py:34-39), full-width nuScenes model, shipped
+    enable_flash=True patching (fixed K = 1024, per-element patches).  Grid depth 11 -> 33 code bits + 4 batch bits.
+    (a) vs the oracle on the collated batch; (b) inference_many(batch=8) returns exactly the slices of that forward.
+    The reference ran the same shape for tests/golden/mini_e2e_lidar8.npz (mini widths, in E2E above)."""
+    from cdsegnet_amd.models import collate_device
+    cfg = configs.cdsegnet_config("nuscenes")
+    model = build_model(cfg)
+    sd = fill_state_dict(model.state_dict(), seed=13)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    sweeps = [synth.lidar_scene(60 + i, 1500 + 111 * i) for i in range(8)]
+    both = synth.collate(sweeps)
+    n = len(both["coord"])
+    assert int(both["grid_coord"].max()).bit_length() >= 11 and len(both["offset"]) == 8
+    inp = {k: both[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    draws = OM.draw_rng(55, n, cfg["c_in_channels"])
+    ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"], flash_semantics=True).numpy()
+    model.precision = "fp32"
+    logits = run(model, inp, draws)
+    err, agree = report("nuScenes 8 sweeps collated, full width fp32 vs oracle", logits, ref)
+    assert logits.shape == (n, 16) and err < 1e-3 and agree > 0.999
+    dicts = [to_dev({k: s[k] for k in ("coord", "grid_coord", "feat", "offset")}) for s in sweeps]
+    torch.manual_seed(8)
+    want = model.inference(dict(collate_device([dict(d) for d in dicts])), eval=False)["seg_logits"]
+    torch.manual_seed(8)
+    got = model.inference_many([dict(d) for d in dicts], lanes=3, batch=8)
+    torch.cuda.synchronize()
+    pos = 0
+    for d, o in zip(dicts, got):
+        m = d["feat"].shape[0]
+        assert torch.equal(o["seg_logits"], want[pos:pos + m])
+        pos += m
+    model.precision = "bf16"
+    d16 = run(model, inp, draws)
+    err, agree = report("nuScenes 8 sweeps collated, bf16 vs oracle", d16, ref)
+    assert np.isfinite(d16).all() and err < 0.25 and agree > 0.9
+
+
+def test_device_noise_is_reproducible_under_reseed():
+    """noise_source="device": the Philox stream ids are drawn from torch's CPU generator, so torch.manual_seed(s)
+    followed by the same calls reproduces the logits whatever ran before (advisor finding, round 1)."""
+    cfg = configs.mini_config()
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=4), strict=True)
+    model = model.to("cuda").eval()
+    model.precision = "fp32"
+    model.noise_source = "device"
+    sc = synth.room_scene(3, 2500)
+    inp = to_dev({k: sc[k] for k in ("coord", "grid_coord", "feat", "offset")})
+    torch.manual_seed(11)
+    a = model.inference(dict(inp), eval=False)["seg_logits"].clone()
+    b = model.inference(dict(inp), eval=False)["seg_logits"].clone()
+    torch.manual_seed(11)
+    a2 = model.inference(dict(inp), eval=False)["seg_logits"].clone()
+    b2 = model.inference_many([dict(inp)], lanes=2)[0]["seg_logits"]
+    assert torch.equal(a, a2) and torch.equal(b, b2)
+    assert not torch.equal(a, b)  # consecutive calls draw different noise
+    a3 = model.inference(dict(inp), eval=False, noise_level=0.05)["seg_logits"]
+    assert torch.isfinite(a3).all()
+
+
 @pytest.fixture(scope="module")
 def full_model():
     cfg = configs.cdsegnet_config("scannet")
@@ -218,6 +308,29 @@ def test_full_size_properties_120k(full_model):
     full_model.precision = "bf16"
     d = run(full_model, inp, draws)
     err, agree = report("120k bf16 vs fp32 (HIP both)", d, a)
+    assert np.isfinite(d).all() and err < 0.3 and agree > 0.9
+
+
+def test_full_size_robustness_properties_120k(full_model):
+    """BASELINE config 5 at full size: the 120k scene after sigma = 0.05 m coordinate noise + 50 % drop + re-voxelisation
+    (~60k scattered voxels).  Size-independent properties: finite, deterministic, equivariant to the caller's point
+    order, bf16 close to fp32."""
+    sc = synth.perturb_scene(synth.room_scene(0, 120000), seed=1, sigma=0.05, drop=0.5)
+    n = len(sc["coord"])
+    assert 50000 < n <= 60000
+    inp = {k: sc[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    draws = OM.draw_rng(54421566, n, 6)
+    full_model.precision = "fp32"
+    a = run(full_model, inp, draws)
+    b = run(full_model, inp, draws)
+    assert np.isfinite(a).all() and a.shape == (n, 20) and np.array_equal(a, b)
+    perm = np.random.default_rng(2).permutation(n)
+    inp_p = {k: (v[perm] if k != "offset" else v) for k, v in inp.items()}
+    c = run(full_model, inp_p, dict(noise=draws["noise"][torch.from_numpy(perm)], perms=draws["perms"]))
+    assert np.array_equal(c, a[perm])
+    full_model.precision = "bf16"
+    d = run(full_model, inp, draws)
+    err, agree = report("robust 120k->%dk bf16 vs fp32 (HIP both)" % (n // 1000), d, a)
     assert np.isfinite(d).all() and err < 0.3 and agree > 0.9
 
 

@@ -225,6 +225,65 @@ def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
     assert err < 2e-4
 
 
+@pytest.mark.parametrize("name,C", [("room1500", 32), ("batch2", 64), ("lidar5000", 32), ("lidar8", 64), ("tiny64", 32),
+                                    ("rand16", 64)])
+def test_subm_conv3_weight_stationary_vs_oracle(ops, name, C):
+    """csrc/conv.hip (W resident in LDS, gathered rows straight into MFMA fragments, C = 32 / 64 bf16) against the
+    oracle's subm_conv3d on bf16-rounded operands, and against the gathered-A GEMM it replaces (same inputs; different
+    summation order only).  Row counts that are not a multiple of the 256 / 512-row block, rows with no neighbour but
+    themselves (rand16), all 27 offsets (corner offsets of the C = 64 kernel come from L2)."""
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    nbr = ops.nbr_table(zs, g0, b0, depth, 3, True)
+    g = torch.Generator().manual_seed(C + n)
+    x = _bf16_round(torch.randn(n, C, generator=g))
+    w = _bf16_round(torch.randn(C, 3, 3, 3, C, generator=g) / (27 * C) ** 0.5)
+    b = torch.randn(C, generator=g)
+    ref = OM.subm_conv3d(x, nbr.t().cpu().numpy().astype(np.int64), w, b)
+    xd, wd = dev(x, torch.bfloat16), dev(w.reshape(C, -1), torch.bfloat16)
+    assert ops.subm_conv3_ok(xd)
+    img = ops.subm_conv3_pack(wd)
+    out = torch.full((n, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.subm_conv3(xd, img, dev(b), nbr, out)
+    old = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(xd, wd, old, bias=dev(b), nbr=nbr, nbr_kmajor=True, kvol=27)
+    err = (out.float().cpu() - ref).abs().max().item()
+    err_old = (old.float().cpu() - ref).abs().max().item()
+    report(f"subm_conv3 {name} C={C}", max_err=err, gathered_gemm_err=err_old)
+    scale = 1 + ref.abs().max().item()
+    assert err < 0.01 * scale  # one bf16 rounding of the output (2^-9 relative)
+    assert torch.isfinite(out.float()).all()
+
+
+def test_subm_conv3_large_random_map(ops):
+    """120k-row scene map, both widths, and bias = None; compares with the gathered-A GEMM on the same bf16 operands
+    (fp32 accumulation in both: equal up to summation order, then one bf16 rounding)."""
+    from cdsegnet_amd import synth
+    sc = synth.room_scene(2, 120000)
+    grid = torch.as_tensor(sc["grid_coord"]).cuda()
+    batch = torch.zeros(len(grid), dtype=torch.int64, device="cuda")
+    depth = int(ops.grid_max(grid).item()).bit_length()
+    zs, perm0 = ops.sort_pairs(ops.encode(grid, batch, depth, "z"))
+    g0, b0 = ops.plan_gather_grid(grid, perm0, zs, depth)
+    nbr = ops.nbr_table(zs, g0, b0, depth, 3, True)
+    n = len(grid)
+    for C in (32, 64):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(n, C, generator=g).cuda().to(torch.bfloat16)
+        w = (torch.randn(C, 27 * C, generator=g) / (27 * C) ** 0.5).cuda().to(torch.bfloat16)
+        out = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
+        ops.subm_conv3(x, ops.subm_conv3_pack(w), None, nbr, out)
+        old = torch.empty(n, C, dtype=torch.float32, device="cuda")
+        ops.gemm(x, w, old, nbr=nbr, nbr_kmajor=True, kvol=27)
+        err = (out.float() - old).abs().max().item()
+        report(f"subm_conv3 120k C={C} vs gathered GEMM (fp32 out)", max_err=err)
+        assert err < 0.01 * (1 + old.abs().max().item())
+        out2 = torch.empty_like(out)
+        ops.subm_conv3(x, ops.subm_conv3_pack(w), None, nbr, out2)
+        assert torch.equal(out, out2)  # deterministic
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(1000, 32, 32), (4097, 64, 64), (130, 128, 128), (70, 16, 16), (515, 48, 48),
                                    # rows over several column tiles: finished by the last block of the row tile
