@@ -2,24 +2,29 @@
 """bench.py - CDSegNet single-step inference throughput on MI355X (points/s/node).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-attention
-fusion) over one synthetic ScanNet-shaped scene per GPU (BASELINE.json configs[1]: ~120k voxels,
-6-ch features, 20 classes, bf16), inputs already resident in HBM.  Scenes are independent units:
-each rank runs its own scenes, no data-path collective ("scaling": "weak").  One step = one batch of
---scenes-per-forward x --lanes (8 x 3 = 24) scenes through DefaultSegmentorV2.inference_many: every lane
-(HIP stream) gets one collated forward of 8 scenes (the reference's collate_fn batching), three forwards
-are in flight.  Every scene runs the full path; `value` counts all of them; `single_scene_latency_ms`
-reports the one-scene-at-a-time latency next to the throughput.  RCCL is used once to
-broadcast the weights from rank 0 and for the final timing / counter reductions.
+N > 1 with no torch.distributed environment: bench.py launches its own N ranks (re-executes itself under
+torch.distributed.run on 127.0.0.1, like the reference's self-spawning launcher, pointcept/engines/launch.py:35-135);
+under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = serialized window attention,
-HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle on the host cores).
+A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-attention fusion) over one batch of
+--scenes-per-forward x --lanes (8 x 3 = 24) DISTINCT synthetic ScanNet-shaped scenes per GPU (BASELINE.json configs[1]:
+~120k voxels each - sizes 103k..137k, mean 120k - 6-ch features, 20 classes, bf16), inputs already resident in HBM.
+Scenes are independent units: every rank runs its own scenes, no data-path collective ("scaling": "weak").  Every lane
+(HIP stream) gets one collated forward of 8 scenes (the reference's collate_fn batching), three forwards are in flight.
+`value` counts all points of all scenes; `single_scene_latency_ms` is the one-scene-at-a-time (bs = 1) latency.
+RCCL is used once to broadcast the weights from rank 0 and for the final timing / counter reductions.
+
+Prints ONE JSON line on rank 0.  `roofline` (window attention, the north-star kernel) and `roofline_conv` (the sparse
+convs, the largest share of kernel time) are timed with HIP events around every launch ON THE LAUNCH STREAM, in a pass
+right after the timed region that replays the timed configuration's own forward (the same 8 collated scenes) with
+nothing else on the GPU; `cpu_baseline` is the CPU oracle on the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,13 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from cdsegnet_amd import configs, ops, synth  # noqa: E402
-from cdsegnet_amd import dist as cdist  # noqa: E402
-from cdsegnet_amd.param_init import fill_state_dict  # noqa: E402
-from cdsegnet_amd.registry import build_model  # noqa: E402
-import cdsegnet_amd.models  # noqa: E402,F401
-
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+CPU_THREADS = 32  # fastest of {8, 16, 32, 64, 128} torch threads on the 2 x 64-core host (tools/cpu_sweep.py)
 
 
 def parse():
@@ -46,52 +47,129 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=120000)
+    ap.add_argument("--points", type=int, default=120000, help="mean voxels per scene")
     ap.add_argument("--dataset", default="scannet", choices=["scannet", "scannet200", "nuscenes"])
+    ap.add_argument("--robust", action="store_true",
+                    help="BASELINE config 5: every scene gets Gaussian coord noise sigma = 0.05 m + 50 %% random drop and is "
+                         "re-voxelised (~half the points, scattered voxels)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-baseline", dest="cpu_baseline", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
-    ap.add_argument("--cpu-points", type=int, default=24000)
+    ap.add_argument("--cpu-points", type=int, default=60000)
+    ap.add_argument("--cpu-threads", type=int, default=CPU_THREADS)
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the roofline pass after the timed region")
-    ap.add_argument("--time-in-region", action="store_true",
-                    help="also record HIP events around the attention launches INSIDE the timed region (costs ~5 %% "
-                         "throughput: the run is host-issue bound and every launch gets two hipEventCreate/Record)")
+    ap.add_argument("--no-agreement", action="store_true", help="skip the bf16-vs-fp32 agreement leg")
     ap.add_argument("--scenes-per-forward", type=int, default=8,
                     help="scenes collated into one forward (the reference's collate_fn batching); one step = "
                          "scenes-per-forward x lanes scenes (one batch per lane)")
     ap.add_argument("--lanes", type=int, default=3,
-                    help="independent scenes in flight per GPU (HIP streams); 1 = strictly one scene at a time")
+                    help="independent forwards in flight per GPU (HIP streams); 1 = strictly one forward at a time")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group plumbing only (no model, gloo when there is no GPU): what the CPU test runs")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, points, dataset):
-    """The CPU oracle (our PyTorch-CPU fp32 port of the reference path) on a bounded sample."""
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N without a torch.distributed environment: become the launcher of N ranks on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def make_scenes(args, rank, count):
+    """`count` distinct scenes of this rank: different seeds AND sizes (mean = --points), so ragged patches, LPT
+    sharding and the allocator see what a real scene list gives them."""
+    from cdsegnet_amd import synth
+    scenes = []
+    for i in range(count):
+        seed = 1000 * rank + i
+        if args.dataset == "nuscenes":
+            n = int(round(args.points * (1.0 + 0.25 * ((i + 0.5) / count - 0.5))))
+            sc = synth.lidar_scene(seed, n)
+        else:
+            n = int(round(args.points * (1.0 + 0.3 * ((i + 0.5) / count - 0.5))))  # 0.85 .. 1.15 x, mean 1.0
+            sc = synth.room_scene(seed, n)
+        if args.robust:
+            sc = synth.perturb_scene(sc, seed=seed, sigma=0.05, drop=0.5, voxel=0.05 if args.dataset == "nuscenes" else 0.02)
+        scenes.append(sc)
+    return scenes
+
+
+def cpu_baseline(cfg, sd, points, dataset, threads):
+    """The CPU oracle (our PyTorch-CPU fp32 restatement of the reference path) on ONE scene of the bench generator:
+    one warm-up, median of three, on `threads` torch threads (swept once: tools/cpu_sweep.py)."""
+    from cdsegnet_amd import synth
     from oracle import model as OM
     sc = synth.lidar_scene(100, points) if dataset == "nuscenes" else synth.room_scene(100, points)
     n = len(sc["coord"])
     inp = {k: sc[k] for k in ("coord", "grid_coord", "feat", "offset")}
     draws = OM.draw_rng(1, n, cfg["c_in_channels"])
-    threads = torch.get_num_threads()
-    t0 = time.time()
-    OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"])
-    dt = time.time() - t0
-    return dict(value=n / dt, unit="points/s", cores=threads, kind="port",
-                sample=f"1 scene x {n} points (same generator/model as the GPU run, fp32, PyTorch-CPU oracle), {dt:.1f} s")
+    keep = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        times = []
+        for i in range(4):
+            t0 = time.time()
+            OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"])
+            if i:
+                times.append(time.time() - t0)
+    finally:
+        torch.set_num_threads(keep)
+    med = float(np.median(times))
+    return dict(value=n / med, unit="points/s", cores=threads, kind="port",
+                sample=f"1 scene x {n} points (bench generator and model, fp32, PyTorch-CPU oracle), 1 warm-up + median of 3: "
+                       f"{med:.1f} s (runs {', '.join(f'{t:.1f}' for t in times)} s), {threads} of {os.cpu_count()} host threads")
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    have_gpu = torch.cuda.is_available()
     dist = None
     if world > 1:
         import torch.distributed as dist
+    if args.dry_run:
+        dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("nccl" if have_gpu else "gloo", **(dict(device_id=dev) if have_gpu else {}))
+            dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64, device=dev)
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ones.item()), "max_over_ranks": float(t.item()),
+                              "backend": "nccl" if have_gpu else "gloo"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    assert have_gpu, "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+
+    from cdsegnet_amd import configs, ops
+    from cdsegnet_amd import dist as cdist
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    import cdsegnet_amd.models  # noqa: F401
 
     cfg = configs.cdsegnet_config(args.dataset)
     model = build_model(cfg)
@@ -100,38 +178,39 @@ def main():
         sd = fill_state_dict(model.state_dict(), seed=0)  # random-init weights of the named architecture
         model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
-    if world > 1:  # weights: one RCCL broadcast from rank 0 (replaces the reference's DDP-ctor broadcast)
-        cdist.broadcast_model(model, src=0)
+    T = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    if world > 1:  # weights: one RCCL broadcast from rank 0 in the compute dtype (replaces the DDP-ctor broadcast)
+        cdist.broadcast_model(model, src=0, weight_dtype=T if T != torch.float32 else None)
     model.precision = args.precision
     model.noise_source = "device"  # noise-branch input drawn by the Philox kernel (no host RNG + PCIe in the step)
 
-    sc = synth.lidar_scene(rank, args.points) if args.dataset == "nuscenes" else synth.room_scene(rank, args.points)
-    n = len(sc["coord"])
-    inp = {k: torch.as_tensor(sc[k]).to(dev) for k in ("coord", "grid_coord", "feat", "offset")}
-    inp["offset_host"] = [int(v) for v in sc["offset"]]
+    scenes_per_step = args.scenes_per_forward * args.lanes
+    scenes = make_scenes(args, rank, scenes_per_step)
+    dicts = []
+    for sc in scenes:
+        d = {k: torch.as_tensor(sc[k]).to(dev) for k in ("coord", "grid_coord", "feat", "offset")}
+        d["offset_host"] = [int(v) for v in sc["offset"]]
+        dicts.append(d)
+    sizes = [len(sc["coord"]) for sc in scenes]
+    pts_per_step = int(sum(sizes))
     torch.manual_seed(54421566 + rank)
 
-    scenes_per_step = args.scenes_per_forward * args.lanes
-
     def run(k):
-        """k steps; one step = one batch of `scenes_per_step` independent scenes through inference_many: one collated
+        """k steps; one step = the batch of `scenes_per_step` distinct scenes through inference_many: one collated
         forward of --scenes-per-forward scenes per lane (no host sync between steps: the lanes keep streaming)."""
         out = None
         for _ in range(k):
-            out = model.inference_many([dict(inp) for _ in range(scenes_per_step)], lanes=args.lanes,
-                                       batch=args.scenes_per_forward)[-1]["seg_logits"]
+            out = model.inference_many([dict(d) for d in dicts], lanes=args.lanes, batch=args.scenes_per_forward)
         return out
 
     timer = not args.no_kernel_timer
+    out = None
     if args.warmup:
         out = run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if timer and args.time_in_region:  # HIP events around every attention launch, on the launch stream
-        ops.attention_prof_enable(True)
-    work0 = model.engine().attn_work
     t0 = time.perf_counter()
     out = run(args.steps)
     torch.cuda.synchronize()
@@ -139,44 +218,74 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    attn_ms, attn_launches = ops.attention_prof_summary() if (timer and args.time_in_region) else (0.0, 0)
-    attn_work = model.engine().attn_work - work0
-    ops.attention_prof_enable(False)
-    assert torch.isfinite(out).all()
-    # after the timed region: the attention launches with nothing else on the GPU (one scene at a time, no side stream).
-    # This is the kernel-quality figure (and what rocprofv3 sees: its kernel trace serialises the streams); inside the
-    # timed region up to --lanes scenes share the CUs, so a launch's wall time there is not a property of the kernel.
+    last = out[-1]["seg_logits"]
+    assert torch.isfinite(last).all()
+
+    # ---- kernel-level pass (rank 0): the SAME forward the timed region issues (first lane's 8 collated scenes), one
+    # forward at a time, HIP events around every attention / sparse-conv launch on the launch stream.  Inside the timed
+    # region three forwards share the CUs, so a launch's wall time there is not a property of the kernel; rocprofv3
+    # --kernel-trace serialises the streams the same way (profiles/).
     iso = None
+    eng = model.engine()
     if timer and rank == 0:
-        eng = model.engine()
+        from cdsegnet_amd.models import collate_device
         torch.cuda.synchronize()
         torch.cuda.empty_cache()  # the lanes' allocator pools would otherwise starve the default stream's
-        for _ in range(3):
-            model.inference(dict(inp), eval=False)
+        fwd = collate_device([dict(d) for d in dicts[:args.scenes_per_forward]])
         fork, eng.fork_stage = eng.fork_stage, None
+        reps = 3
+        try:
+            for _ in range(2):
+                model.inference(dict(fwd), eval=False)
+            torch.cuda.synchronize()
+            ops.attention_prof_enable(True)
+            a0, c0 = eng.attn_work, eng.conv_bytes
+            for _ in range(reps):
+                model.inference(dict(fwd), eval=False)
+            torch.cuda.synchronize()
+            ams, al = ops.prof_summary(ops.PROF_ATTENTION)
+            cms, cl = ops.prof_summary(ops.PROF_CONV)
+            iso = dict(reps=reps, attn_ms=ams, attn_launches=al, attn_work=eng.attn_work - a0, conv_ms=cms, conv_launches=cl,
+                       conv_bytes=eng.conv_bytes - c0,
+                       points=int(sum(sizes[:args.scenes_per_forward])))
+            ops.attention_prof_enable(False)
+        finally:
+            eng.fork_stage = fork
+        # bs = 1 latency (the reference tester's batch size, test.py:99), side-stream fork on
+        one = dict(dicts[0])
+        for _ in range(2):
+            model.inference(dict(one), eval=False)
         torch.cuda.synchronize()
-        ops.attention_prof_enable(True)
-        w1 = eng.attn_work
-        for _ in range(5):
-            model.inference(dict(inp), eval=False)
-        torch.cuda.synchronize()
-        ims, il = ops.attention_prof_summary()
-        iso = dict(ms=ims, launches=il, work=eng.attn_work - w1)
-        ops.attention_prof_enable(False)
-        eng.fork_stage = fork
         t1 = time.perf_counter()
         for _ in range(5):
-            model.inference(dict(inp), eval=False)
+            model.inference(dict(one), eval=False)
         torch.cuda.synchronize()
         iso["latency_ms"] = 1e3 * (time.perf_counter() - t1) / 5
+        iso["latency_points"] = sizes[0]
 
+    # ---- bf16 accuracy on a bench scene: same draws through the exact-fp32 HIP path (rank 0)
+    agreement = None
+    if rank == 0 and args.precision == "bf16" and not args.no_agreement:
+        d0 = dict(dicts[0])
+        gen = torch.Generator().manual_seed(54421566)
+        draws = dict(noise=torch.normal(0, 1, size=(sizes[0], cfg["c_in_channels"]), dtype=torch.float32, generator=gen),
+                     perms=[torch.randperm(4, generator=gen).tolist() for _ in range(8)])
+        model.noise_source = "torch_cpu"
+        a = model.inference(dict(d0), eval=False, draws=dict(draws))["seg_logits"].clone()
+        model.precision = "fp32"
+        b = model.inference(dict(d0), eval=False, draws=dict(draws))["seg_logits"]
+        agreement = dict(points=sizes[0], argmax_agreement=float((a.argmax(1) == b.argmax(1)).float().mean()),
+                         max_abs_logit_diff=float((a - b).abs().max()), mean_abs_logit=float(b.abs().mean()),
+                         reference="exact-fp32 HIP path (within 5e-6 of the reference's CPU logits, tests/)")
+        model.precision = args.precision
+        model.noise_source = "device"
 
-    # per-class intersection/union/target counters of the last step: the per-scene record the reference
+    # per-class intersection/union/target counters of the last scene: the per-scene record the reference
     # gathers over gloo (test.py:374) - here one RCCL all-reduce (random-init weights: the value is meaningless)
-    counts = cdist.confusion_counts(out.argmax(1), torch.as_tensor(sc["segment"]).to(dev), out.shape[1])
+    counts = cdist.confusion_counts(last.argmax(1), torch.as_tensor(scenes[-1]["segment"]).to(dev), last.shape[1])
     cdist.reduce_counts(counts)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    pts = torch.tensor([n * scenes_per_step], dtype=torch.int64, device=dev)
+    pts = torch.tensor([pts_per_step], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
@@ -184,6 +293,7 @@ def main():
     total_pts = int(pts.item())
 
     if rank == 0:
+        shape = {"scannet": "ScanNet", "scannet200": "ScanNet200", "nuscenes": "nuScenes"}[args.dataset]
         res = {
             "metric": "points/sec/node (ScanNet ~120k-pt scenes, 1-step)",
             "value": total_pts * args.steps / elapsed,
@@ -197,40 +307,51 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision if args.precision != "fp32" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.dataset}-shape {n}-point scene per GPU, CDSegNet 1-step inference "
-                                   f"(PT-v3m1 dual backbone, 101.4M params, random-init), {scenes_per_step} scenes/step/GPU",
-                       "points_per_scene": n, "precision": args.precision, "scenes_per_step_per_gpu": scenes_per_step,
-                       "scenes_per_forward": args.scenes_per_forward, "forwards_in_flight_per_gpu": args.lanes,
-                       "noise": "device Philox"},
+            "config": {"workload": f"{shape}-shape scenes{' after coord noise 0.05 m + 50 % drop + re-voxelisation' if args.robust else ''}"
+                                   f", CDSegNet 1-step inference (PT-v3m1 dual backbone, 101.4M params, random-init), "
+                                   f"{scenes_per_step} distinct scenes/step/GPU",
+                       "points_per_scene_mean": pts_per_step / scenes_per_step, "points_per_scene_min": min(sizes),
+                       "points_per_scene_max": max(sizes), "precision": args.precision,
+                       "scenes_per_step_per_gpu": scenes_per_step, "scenes_per_forward": args.scenes_per_forward,
+                       "forwards_in_flight_per_gpu": args.lanes, "noise": "device Philox"},
         }
-        if timer and iso and iso["ms"] > 0:
+        if iso and iso["attn_ms"] > 0:
             peak = PEAK_TFLOPS[args.precision]
-            achieved = iso["work"] / (iso["ms"] * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                               "frac": achieved / peak, "traffic": None,
-                               "kernel": "attn_bf16_kernel" if args.precision == "bf16" else "attn_f32_kernel",
-                               "launches_per_step": iso["launches"] / 5,
-                               "avg_launch_us": 1e3 * iso["ms"] / iso["launches"],
-                               "algorithmic_gflop_per_step": iso["work"] / 5 / 1e9,
-                               "measured": "HIP events around every launch, 5 scenes one at a time right after the timed "
-                                           "region (no other work on the GPU; rocprofv3 --kernel-trace serialises the "
-                                           "streams the same way, profiles/)",
-                               "note": "VALU/transcendental-issue bound at head dim 16 (DESIGN.md 5)"}
-            if attn_ms > 0:
-                ia = attn_work / (attn_ms * 1e-3) / 1e12
-                res["roofline"]["in_timed_region"] = {
-                    "achieved": ia, "frac": ia / peak, "avg_launch_us": 1e3 * attn_ms / attn_launches,
-                    "note": f"same launches while {args.lanes} scenes share the GPU (wall time of a launch, not kernel speed)"}
+            r = iso["reps"]
+            achieved = iso["attn_work"] / (iso["attn_ms"] * 1e-3) / 1e12
+            res["roofline"] = {
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "kernel": "attn_bf16_kernel" if args.precision == "bf16" else "attn_f32_kernel",
+                "launches_per_forward": iso["attn_launches"] / r, "avg_launch_us": 1e3 * iso["attn_ms"] / iso["attn_launches"],
+                "algorithmic_gflop_per_forward": iso["attn_work"] / r / 1e9, "kernel_ms_per_forward": iso["attn_ms"] / r,
+                "scenes_per_forward": args.scenes_per_forward, "points_per_forward": iso["points"],
+                "measured": f"HIP events around every launch on the launch stream; the timed configuration's own forward "
+                            f"({args.scenes_per_forward} collated scenes), {r} forwards one at a time right after the timed region",
+                "note": "head dim 16: 16 v_exp_f32 per 32x32 score tile bound the kernel at ~25 % of the MFMA peak (DESIGN.md 5)"}
+            if iso["conv_ms"] > 0:
+                gbs = iso["conv_bytes"] / (iso["conv_ms"] * 1e-3) / 1e9
+                res["roofline_conv"] = {
+                    "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                    "kernel": "conv_rg_kernel<32|64> + gemm_kernel<..., GATHER> (all k = 3 sparse convs of the forward)",
+                    "launches_per_forward": iso["conv_launches"] / r, "kernel_ms_per_forward": iso["conv_ms"] / r,
+                    "algorithmic_mb_per_forward": iso["conv_bytes"] / r / 1e6,
+                    "bytes": "features in + out, kernel map as stored (27 x int32 per point), weights once"}
             res["single_scene_latency_ms"] = iso["latency_ms"]
-            res["kernel_ms_per_step"] = {"attention": iso["ms"] / 5}
-            tpath = os.path.join(ROOT, "profiles", "r01_attention_traffic.json")
+            res["single_scene_points"] = iso["latency_points"]
+            tpath = os.path.join(ROOT, "profiles", "r02_attention_traffic.json")
             if args.precision == "bf16" and os.path.exists(tpath):
-                # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-                # WRITE_SIZE) on the stage-0-shaped launch; the live run cannot collect PMCs itself
+                # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) on
+                # the stage-0 launch of this forward: an OFFLINE measurement of this build, the live run cannot collect PMCs
                 with open(tpath) as f:
-                    res["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+                    tj = json.load(f)
+                res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = "profiles/r02_attention_traffic.json (offline rocprofv3 --pmc passes, stage-0 launch)"
+        if agreement:
+            res["bf16_agreement"] = agreement
+        m = cdist.metrics(counts)
+        res["eval_counters"] = {"mIoU_random_init": m["mIoU"], "points_counted": int(counts[2].sum())}
         if args.cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_points, args.dataset)
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_points, args.dataset, args.cpu_threads)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -4,35 +4,34 @@
 //      :246-296 SerializedAttention (flash_attn_varlen_qkvpacked_func :282-288, CPU branch :264-280)
 //      :988-1055 SerializedCrossAttention (flash_attn_varlen_kvpacked_func :1038-1047)
 //
-// One workgroup (4 waves) = one (patch, head) x one slice of its queries.
+// One workgroup (8 waves) = one (patch, head) x one slice of its queries.
 //  * the gather by serialized order is fused into the K/V staging loads and the Q fragment
 //    loads (row indices come from the slot plan, cdseg_pad_plan); the scatter by the inverse
 //    order and the dropping of the padding duplicates are fused into the store;
 //  * the whole K tile and V^T tile of the patch-head live in LDS for the lifetime of the block
-//    (bf16: 32 KB + 36 KB -> 2 blocks / CU; f32: 64 KB + 65 KB);
+//    (bf16: 32 KB + 34 KB -> 2 blocks / CU; f32: 64 KB + 65 KB);
 //  * scores are computed TRANSPOSED (S^T = K Q^T) so that a query's scores stay inside one lane
-//    pair: the row max / row sum need no cross-lane traffic in the key loop;
-//  * two passes over the keys (max, then exp + PV) instead of an online rescale: with d = 16
-//    the kernel is bound by the VALU/transcendental work per score, not by MFMA, and a second
-//    QK^T MFMA (32 cycles per 1024 scores) is cheaper than the rescale bookkeeping;
+//    pair: row statistics need no cross-lane traffic in the key loop;
+//  * bf16: ONE pass over the keys.  Softmax is shift invariant, so instead of the row max the kernel subtracts the
+//    Cauchy-Schwarz bound |q'_i| max_j |k_j| (one norm per query, one max over the keys while staging K): no max
+//    sweep, no second QK^T.  Scale * log2(e) is folded into Q', the shift rides in the MFMA's C operand, so a score
+//    costs ONE v_exp_f32.  Query tiles whose bound is too loose (> 2^60) are redone with the exact row max;
+//  * the kernel is bound by the VALU, not by the matrix pipe: 16 v_exp_f32 (quarter rate, ~8.7 cycles each with 4
+//    waves per SIMD) + 8 packs per 32x32 score tile against 3 MFMAs of 32 cycles - tools/ubench/pipes.hip: the
+//    transcendental unit shares the VALU issue (exp + fma times ADD), the matrix pipe overlaps both, and the
+//    instruction mix alone tops out at ~30 % of the bf16 MFMA peak;
 //  * bf16: v_mfma_f32_32x32x16_bf16 for both products; the MFMA k-slot <-> key assignment of
 //    the PV product is chosen so the exponentiated scores feed it straight from the
-//    accumulator registers (no permute), V^T is read to match; a row of ones appended to V^T
-//    makes the softmax denominator fall out of the same MFMA (row 16 of the result);
+//    accumulator registers (no permute); V^T is STORED in that key order, so a PV operand is one ds_read_b128;
+//    a row of ones appended to V^T makes the softmax denominator fall out of the same MFMA (row 16 of the result);
 //  * f32 (the 1e-3 parity mode): v_mfma_f32_16x16x4_f32 for both products, exact fp32.
 // LDS layouts are bank-conflict free for every fragment read (tools/lds_conflicts.py).
 #include <cstdlib>
-#include <mutex>
-#include <vector>
 
 #include "common.h"
+#include "prof.h"
 
 namespace {
-
-// optional HIP-event timing of every attention launch on its own stream (bench.py's roofline leg)
-bool g_prof_on = false;
-std::mutex g_prof_mu;  // launches may come from several host threads (one per lane)
-std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 
 struct AttnP {
   const void* q;
@@ -72,8 +71,12 @@ __device__ __forceinline__ bool decode_block(const AttnP& p, int& patch, int& he
   return patch < p.num_patches;
 }
 
-constexpr int VT_STRIDE_BF16 = 2056;  // bytes per V^T row (1024 bf16 + 8 B pad -> conflict-free b64 reads)
-constexpr int VT_ROWS_BF16 = 18;      // 16 head dims + ones row + zero row
+// V^T rows: 1024 bf16 + 16 B pad.  Row stride = 516 dwords = 4 mod 64 banks: the 16 rows a ds_read_b128 lane group
+// touches sit on 16 distinct 4-bank slots -> conflict free.  Inside every 32-key tile the keys are stored in the
+// order the PV MFMA's k-slots want them (vt_pos): a lane's 8 keys are ONE 16-byte read (was two ds_read2_b64 halves:
+// 36 -> 12 LDS cycles per tile; the tile loop was 77 % LDS-busy next to the VALU-bound softmax).
+constexpr int VT_STRIDE_BF16 = 2064;
+constexpr int VT_ROWS_BF16 = 17;      // 16 head dims + ones row (MFMA rows 17..31 are never read: their lanes load row 16)
 constexpr int KS_BYTES_BF16 = 1024 * 32;
 constexpr int SMEM_BF16 = KS_BYTES_BF16 + VT_ROWS_BF16 * VT_STRIDE_BF16;
 
@@ -101,6 +104,14 @@ __device__ __forceinline__ float tile_max(const f32x16_t& s, float m) {
   return fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), fmaxf(fmaxf(e, s[15]), m));
 }
 
+// position of key slot s inside its V^T row: within a 32-key tile the 4-key blocks go 0,2,1,3,4,6,5,7, so that the
+// k-slots of PV MFMA mf for lane half h (keys 16mf + 4h + {0..3} and 16mf + 8 + 4h + {0..3}: what the exponentiated
+// S^T accumulator registers hold, see pv_tile) are the 8 consecutive positions 16mf + 8h ..
+__device__ __forceinline__ int vt_pos(int s) {
+  const int b = (s >> 2) & 7;
+  return (s & ~31) | ((b & 4) | ((b & 1) << 1) | ((b >> 1) & 1)) << 2 | (s & 3);
+}
+
 // two fp32 -> packed bf16 by truncation: ONE v_perm_b32 (measured 2.8x cheaper than v_cvt_pk_bf16_f32 on
 // gfx950, tools/ubench/valu_rates.hip).  The softmax denominator is accumulated from the SAME truncated
 // values (row of ones in V^T), so the truncation bias cancels in the normalisation.
@@ -126,11 +137,8 @@ __device__ __forceinline__ void pv_tile(const f32x16_t& s, int kt, int h, int L,
     union { bf16x8_t v; uint32_t u[4]; } pf, vf;
 #pragma unroll
     for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2_trunc(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
-    // k-slots 8h+j (j<4) <-> keys kbase + 4h + j ; (j>=4) <-> keys kbase + 8 + 4h + (j-4)
-    const char* vp = vt_lane + (kt * 32 + 16 * mf) * 2;
-    const uint2 lo = *reinterpret_cast<const uint2*>(vp);
-    const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
-    vf.u[0] = lo.x; vf.u[1] = lo.y; vf.u[2] = hi.x; vf.u[3] = hi.y;
+    // k-slots 8h+j (j<4) <-> keys kbase + 4h + j ; (j>=4) <-> keys kbase + 8 + 4h + (j-4): stored contiguously (vt_pos)
+    vf.v = *reinterpret_cast<const bf16x8_t*>(vt_lane + (kt * 32 + 16 * mf) * 2);
     o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o, 0, 0, 0);
   }
 }
@@ -194,14 +202,13 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
     *reinterpret_cast<uint4*>(Ks + s1 * 32 + ((1 ^ sw) << 4)) = k1[1];
     const uint32_t a[8] = {v0[0].x, v0[0].y, v0[0].z, v0[0].w, v0[1].x, v0[1].y, v0[1].z, v0[1].w};
     const uint32_t b[8] = {v1[0].x, v1[0].y, v1[0].z, v1[0].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w};
+    const int vp = vt_pos(s0) * 2;  // s0 is even: s0 + 1 is the next position too
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      *reinterpret_cast<uint32_t*>(Vt + (2 * d) * VT_STRIDE_BF16 + s0 * 2) = (a[d] & 0xffffu) | (b[d] << 16);
-      *reinterpret_cast<uint32_t*>(Vt + (2 * d + 1) * VT_STRIDE_BF16 + s0 * 2) = (a[d] >> 16) | (b[d] & 0xffff0000u);
+      *reinterpret_cast<uint32_t*>(Vt + (2 * d) * VT_STRIDE_BF16 + vp) = (a[d] & 0xffffu) | (b[d] << 16);
+      *reinterpret_cast<uint32_t*>(Vt + (2 * d + 1) * VT_STRIDE_BF16 + vp) = (a[d] >> 16) | (b[d] & 0xffff0000u);
     }
-    *reinterpret_cast<uint32_t*>(Vt + 16 * VT_STRIDE_BF16 + s0 * 2) =
-        (s0 < L ? 0x3F80u : 0u) | (s1 < L ? 0x3F800000u : 0u);
-    *reinterpret_cast<uint32_t*>(Vt + 17 * VT_STRIDE_BF16 + s0 * 2) = 0u;
+    *reinterpret_cast<uint32_t*>(Vt + 16 * VT_STRIDE_BF16 + vp) = (s0 < L ? 0x3F80u : 0u) | (s1 < L ? 0x3F800000u : 0u);
   }
   kn2max = wave_max(kn2max);
   if (lane == 0) atomicMax(&s_kmax2, __float_as_uint(kn2max));  // non-negative floats order like their bit patterns
@@ -210,8 +217,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bf16_kernel(AttnP p) {
 
   const int ql = lane & 31;  // query (B operand column) / key or head-dim row (A operand row)
   const int h = lane >> 5;
-  const int vrow = ql < 17 ? ql : 17;
-  const char* vt_lane = Vt + vrow * VT_STRIDE_BF16 + h * 8;
+  const int vrow = ql < 16 ? ql : 16;  // rows 17..31 of O^T are never read: their lanes reload the ones row (broadcast)
+  const char* vt_lane = Vt + vrow * VT_STRIDE_BF16 + h * 16;
   const float c = p.scale_log2e;
   const int nqt = (L + 31) >> 5;
   const bool tail = (nkt << 5) != L;
@@ -463,46 +470,13 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
     attr_done = true;
   }
   if (dtype != CDSEG_BF16 && dtype != CDSEG_F32) return CDSEG_ERR_ARG;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (g_prof_on) {
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CDSEG_ERR_LAUNCH;
-    (void)hipEventRecord(e0, s);
-  }
+  CdsegProfToken tok;
+  const bool prof = cdseg_prof_begin(CDSEG_PROF_ATTENTION, s, &tok);
   if (dtype == CDSEG_BF16)
     hipLaunchKernelGGL(attn_bf16_kernel, grid, block, SMEM_BF16, s, p);
   else
     hipLaunchKernelGGL(attn_f32_kernel, grid, block, SMEM_F32, s, p);
-  if (g_prof_on) {
-    (void)hipEventRecord(e1, s);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_events.emplace_back(e0, e1);
-  }
+  if (prof) cdseg_prof_end(tok, s);
   CDSEG_CHECK_LAUNCH();
-  return CDSEG_OK;
-}
-
-// enable / disable event timing of the attention launches (drops earlier records)
-extern "C" int cdseg_prof_enable(int on) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (auto& ev : g_prof_events) {
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
-  g_prof_events.clear();
-  g_prof_on = on != 0;
-  return CDSEG_OK;
-}
-
-// after a device synchronisation: total milliseconds and number of attention launches recorded
-extern "C" int cdseg_prof_summary(double* total_ms, long* launches) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  double t = 0.0;
-  for (auto& ev : g_prof_events) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ev.first, ev.second) != hipSuccess) return CDSEG_ERR_LAUNCH;
-    t += ms;
-  }
-  if (total_ms) *total_ms = t;
-  if (launches) *launches = (long)g_prof_events.size();
   return CDSEG_OK;
 }

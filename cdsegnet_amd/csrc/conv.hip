@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -38,6 +39,8 @@ struct ConvP {
   int ldx, ldy;
   int row_shift;        // log2(ldx * 2): byte stride of a feature row (a power of two)
   int tiles;            // ceil(n / ROWS_PER_BLOCK)
+  int dbg;              // timing experiments only (CDSEG_CONV_DBG; results are WRONG when set): 1 = corner offsets
+                        // treated as dead, 2 = every neighbour replaced by the row itself (perfectly local gathers)
 };
 
 // offsets in LDS-residency priority order (C = 64 keeps the first 19 in LDS): centre, 6 faces, 12 edges, 8 corners
@@ -157,7 +160,9 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
 #pragma unroll
           for (int ks = 0; ks < K::KS; ++ks) {
             // -1 << row_shift wraps to the top of the 32-bit offset range: out of bounds -> zeros
-            const unsigned off = ((unsigned)idx[B][q][g] << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
+            unsigned src = (unsigned)idx[B][q][g];
+            if (p.dbg & 2) src = idx[B][q][g] >= 0 ? (unsigned)myrow[g] : src;
+            const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
             const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
             xb[B][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
           }
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
         for (int g = 0; g < K::RG; ++g) any |= idx[B][q][g] >= 0;
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) m |= 1u << q;
       }
-      return m;
+      return m;  // (dbg bit 1 is applied by the caller)
     };
     auto mfma_step = [&](int step, unsigned live, auto buf) {
       constexpr int B = decltype(buf)::value;
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
       for (int q = 0; q < G; ++q) {
         if (!((live >> q) & 1u)) continue;  // wave-uniform: nobody in these 32 rows has this offset
         const int slot = K::LDS_OFFSETS == 27 ? step * G + q : (int)c_slot_of_offset[step * G + q];
+        if ((p.dbg & 1) && c_slot_of_offset[step * G + q] >= 19) continue;
 #pragma unroll
         for (int ks = 0; ks < K::KS; ++ks)
 #pragma unroll
@@ -269,7 +275,10 @@ int launch_conv(const ConvP& p0, const void* wimg, hipStream_t s) {
   if (blocks_per_cu > 0) per_cu = blocks_per_cu;
   int grid = 256 * per_cu;
   if (grid > p.tiles) grid = (p.tiles + 7) / 8 * 8;  // every XCD keeps a block for its tile range
+  CdsegProfToken tok;
+  const bool prof = cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);
   hipLaunchKernelGGL((conv_rg_kernel<C>), dim3(grid), dim3(K::WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
+  if (prof) cdseg_prof_end(tok, s);
   if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
   return CDSEG_OK;
 }
@@ -298,6 +307,8 @@ extern "C" int cdseg_subm_conv3(const void* x, int ldx, const void* wimg, const 
   ConvP p;
   p.x = (const bf16_t*)x; p.bias = bias; p.nbr = nbr_kmajor; p.y = (bf16_t*)y;
   p.n = n; p.ldx = ldx; p.ldy = ldy; p.tiles = 0;
+  static const int dbg = []() { const char* e = getenv("CDSEG_CONV_DBG"); return e ? atoi(e) : 0; }();
+  p.dbg = dbg;
   p.row_shift = 0;
   while ((1 << p.row_shift) < ldx * 2) ++p.row_shift;
   if ((1 << p.row_shift) != ldx * 2) return CDSEG_ERR_UNSUPPORTED;  // feature rows with a power-of-two stride only

@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -740,7 +741,11 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   }
   const size_t wsb = p.ws ? a->ws_bytes : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (a->compute_dtype == CDSEG_BF16) return a->nbr ? launch<bf16_t, true>(p, wsb, s) : launch<bf16_t, false>(p, wsb, s);
-  if (a->compute_dtype == CDSEG_F32) return a->nbr ? launch<float, true>(p, wsb, s) : launch<float, false>(p, wsb, s);
-  return CDSEG_ERR_ARG;
+  CdsegProfToken tok;
+  const bool prof = a->nbr && a->kvol == 27 && cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);  // the k = 3 sparse convs
+  int rc = CDSEG_ERR_ARG;
+  if (a->compute_dtype == CDSEG_BF16) rc = a->nbr ? launch<bf16_t, true>(p, wsb, s) : launch<bf16_t, false>(p, wsb, s);
+  else if (a->compute_dtype == CDSEG_F32) rc = a->nbr ? launch<float, true>(p, wsb, s) : launch<float, false>(p, wsb, s);
+  if (prof) cdseg_prof_end(tok, s);
+  return rc;
 }

@@ -168,6 +168,9 @@ class Engine:
         self._work_lock = threading.Lock()
         self._tls = threading.local()  # per host thread: device-RNG cursor
         self.attn_work = 0.0  # algorithmic attention FLOPs issued so far (4 * 16 * H * sum_p L_p^2 per launch)
+        # algorithmic HBM bytes of the k = 3 sparse convs issued so far: features in + out, the kernel map as stored
+        # (27 x int32 per point), the weights once per launch
+        self.conv_bytes = 0.0
 
     # ------------------------------------------------------------------ weights
     def prepare(self, device):
@@ -451,10 +454,14 @@ class Engine:
 
     FUSE_LN_MAX_C = 512  # rows up to this width are finished by one GEMM block -> LayerNorm in the epilogue
 
+    def _count_conv(self, n, c, esz):
+        self.conv_bytes += 2.0 * n * c * esz + 27.0 * 4 * n + 27.0 * c * c * esz
+
     def _conv3(self, xc, pre, lv, y):
         """y = SubMConv3d_k3(xc) (ref: ptv3.py:356-362): the weight-stationary kernel on the wide bf16 stages, the
         gathered-A GEMM elsewhere."""
         w = self.w
+        self._count_conv(lv.n, xc.shape[1], xc.element_size())
         if (pre + ".wimg") in w and ops.subm_conv3_ok(xc):
             ops.subm_conv3(xc, w[pre + ".wimg"], w[pre + ".b"], lv.nbr(3, True), y)
         else:
@@ -510,6 +517,7 @@ class Engine:
             gidx, widx = lv.slots(st.curves[att.order_index], att.patch_size, att.enable_flash)
             _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
             self.attn_work += 64.0 * att.num_heads * sum_l2
+            self._count_conv(n, c, st.xc.element_size())
             desc = self.block_desc[pre]
             xc_out = st.x if self.T == torch.float32 else self._buf(n, c, self.T)
             sb = self._scratch_bytes.get((pre, n))

@@ -77,6 +77,16 @@ def attention_prof_summary():
     return ms.value, cnt.value
 
 
+PROF_ATTENTION, PROF_CONV = 0, 1
+
+
+def prof_summary(cls):
+    """(total_ms, launches) of one profiled kernel class since attention_prof_enable(True); after a device sync."""
+    ms, cnt = ctypes.c_double(0.0), ctypes.c_long(0)
+    check(_lib.load().cdseg_prof_summary_class(int(cls), ctypes.byref(ms), ctypes.byref(cnt)), "prof_summary_class")
+    return ms.value, cnt.value
+
+
 def set_timer(t):
     global TIMER
     TIMER = t

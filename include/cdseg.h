@@ -213,7 +213,11 @@ int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ld
 /* HIP-event timing of the attention launches on their own stream (bench.py's live roofline measurement):
  * enable(1) starts recording, summary() (after a device sync) returns the summed durations. */
 int cdseg_prof_enable(int on);
-int cdseg_prof_summary(double* total_ms, long* launches);
+int cdseg_prof_summary(double* total_ms, long* launches); /* class CDSEG_PROF_ATTENTION */
+/* per kernel class: 0 = window attention, 1 = k = 3 sparse convs (cdseg_subm_conv3 and cdseg_gemm with a 27-offset map) */
+#define CDSEG_PROF_ATTENTION 0
+#define CDSEG_PROF_CONV 1
+int cdseg_prof_summary_class(int cls, double* total_ms, long* launches);
 
 /* ------------------------------------------------------------------ pooling reduce
  * out[j] = act(max_{i in run j} y[i] * scale + shift), runs = seg_start (m+1).
