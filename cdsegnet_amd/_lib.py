@@ -90,6 +90,11 @@ SIGNATURES = {
     "cdseg_pad_plan_batch": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
                                      POINTER(c_long), c_int, c_void_p, c_void_p, c_void_p]),
     "cdseg_voxelize": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cdseg_voxelize_f64": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cdseg_center_shift": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "cdseg_tta_apply": (c_int, [c_void_p, c_long, POINTER(ctypes.c_double), ctypes.c_double, c_int, c_int, c_void_p, c_void_p]),
+    "cdseg_div_add": (c_int, [c_void_p, c_float, c_float, c_long, c_void_p, c_void_p]),
+    "cdseg_collect_feat": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
     "cdseg_max_run": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
     "cdseg_fragment_select": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "cdseg_softmax_vote": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),

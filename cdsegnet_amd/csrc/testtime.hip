@@ -8,11 +8,104 @@
 
 namespace {
 
-// grid = floor(double(coord) / grid_size)   (the reference divides a float32 array by a float64 scalar)
-__global__ void grid_floor_kernel(const float* __restrict__ coord, double grid_size, long n3,
-                                  int32_t* __restrict__ grid) {
+// grid = floor(double(coord) / grid_size)   (the reference divides a float32 - or, after a test-time rotation,
+// float64 - array by a float64 scalar)
+template <typename T>
+__global__ void grid_floor_kernel(const T* __restrict__ coord, double grid_size, long n3, int32_t* __restrict__ grid) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n3) grid[i] = (int32_t)floor((double)coord[i] / grid_size);
+}
+
+// ---- pre-model transforms of the test pipeline (ref: datasets/transform.py:113-117 NormalizeColor, :142-155 CenterShift,
+// :259-294 RandomRotateTargetAngle, :298-309 RandomScale, :313-328 RandomFlip; configs/scannet/CDSegNet.py:253-398)
+// per-axis min / max of an (n,3) array -> out6 = [min x y z, max x y z] as doubles (exact for both input types).
+// Doubles are compared through an order-preserving integer image so that one atomicMin / atomicMax pair suffices.
+__device__ __forceinline__ unsigned long long ord_u64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord_f64(unsigned long long u) {
+  return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+template <typename T>
+__global__ void minmax3_kernel(const T* __restrict__ xyz, long n, unsigned long long* __restrict__ acc6) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (; i < n; i += stride)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double v = (double)xyz[3 * i + a];
+      lo[a] = fmin(lo[a], v);
+      hi[a] = fmax(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[a] = fmin(lo[a], __shfl_xor(lo[a], o, 64));
+      hi[a] = fmax(hi[a], __shfl_xor(hi[a], o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&acc6[a], ord_u64(lo[a]));
+      atomicMax(&acc6[3 + a], ord_u64(hi[a]));
+    }
+  }
+}
+__global__ void minmax3_finish_kernel(const unsigned long long* __restrict__ acc6, double* __restrict__ out6) {
+  if (threadIdx.x < 6) out6[threadIdx.x] = ord_f64(acc6[threadIdx.x]);
+}
+// CenterShift: coord -= [(xmin + xmax) / 2, (ymin + ymax) / 2, apply_z ? zmin : 0], in the array's own precision
+template <typename T>
+__global__ void center_shift_kernel(const T* __restrict__ in, const double* __restrict__ mm6, int apply_z, long n,
+                                    T* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T sx = ((T)mm6[0] + (T)mm6[3]) / (T)2, sy = ((T)mm6[1] + (T)mm6[4]) / (T)2, sz = apply_z ? (T)mm6[2] : (T)0;
+  out[3 * i] = in[3 * i] - sx;
+  out[3 * i + 1] = in[3 * i + 1] - sy;
+  out[3 * i + 2] = in[3 * i + 2] - sz;
+}
+// one test-time augmentation as the reference applies it: rotate about the origin (float32 rows times a float64
+// matrix: the result IS float64), then scale; or flip x and y in place (stays float32).  R row-major.
+struct TtaP {
+  double r[9];
+  double scale;
+  int rotate, flip;
+};
+template <typename TO>
+__global__ void tta_kernel(const float* __restrict__ in, TtaP p, int apply_scale, long n, TO* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+  if (p.rotate) {
+    // np.dot(coord, rot_t.T): out_j = sum_k in_k R[j][k], accumulated left to right with fused multiply-adds
+    double o[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = fma((double)z, p.r[3 * j + 2], fma((double)y, p.r[3 * j + 1], (double)x * p.r[3 * j]));
+    if (apply_scale) { o[0] *= p.scale; o[1] *= p.scale; o[2] *= p.scale; }
+    out[3 * i] = (TO)o[0]; out[3 * i + 1] = (TO)o[1]; out[3 * i + 2] = (TO)o[2];
+  } else {
+    out[3 * i] = (TO)(p.flip ? -x : x);
+    out[3 * i + 1] = (TO)(p.flip ? -y : y);
+    out[3 * i + 2] = (TO)z;
+  }
+}
+// out = in / div + add in float32 (NormalizeColor: color / 127.5 - 1)
+__global__ void div_add_kernel(const float* __restrict__ in, float div, float add, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] / div + add;
+}
+// feat (n, ca + cb) float32 = cat([a.float(), b.float()], 1)  (Collect(feat_keys=...), transform.py:46-49); b may be f64
+template <typename TB>
+__global__ void collect_feat_kernel(const float* __restrict__ a, int ca, const TB* __restrict__ b, int cb, long n,
+                                    float* __restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = ca + cb;
+  if (t >= n * c) return;
+  const long i = t / c;
+  const int j = (int)(t - i * c);
+  out[t] = j < ca ? a[i * ca + j] : (float)b[i * cb + (j - ca)];
 }
 
 __global__ void min3_kernel(const int32_t* __restrict__ grid, long n, int32_t* __restrict__ out3) {
@@ -235,12 +328,86 @@ int cdseg_voxelize(const float* coord, double grid_size, long n, int32_t* grid, 
   if (n <= 0) return CDSEG_OK;
   if (!(grid_size > 0)) return CDSEG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(grid_floor_kernel, g1(3 * n), dim3(256), 0, s, coord, grid_size, 3 * n, grid);
+  hipLaunchKernelGGL(grid_floor_kernel<float>, g1(3 * n), dim3(256), 0, s, coord, grid_size, 3 * n, grid);
   if (hipMemsetAsync(min3_dev, 0x7f, 3 * sizeof(int32_t), s) != hipSuccess) return CDSEG_ERR_LAUNCH;
   long blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(min3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grid, n, min3_dev);
   hipLaunchKernelGGL(voxel_key_kernel, g1(n), dim3(256), 0, s, grid, min3_dev, n, key);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// the same for float64 coordinates (what GridSample sees after a test-time rotation / scale)
+int cdseg_voxelize_f64(const double* coord, double grid_size, long n, int32_t* grid, int64_t* key, int32_t* min3_dev,
+                       void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (!(grid_size > 0)) return CDSEG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(grid_floor_kernel<double>, g1(3 * n), dim3(256), 0, s, coord, grid_size, 3 * n, grid);
+  if (hipMemsetAsync(min3_dev, 0x7f, 3 * sizeof(int32_t), s) != hipSuccess) return CDSEG_ERR_LAUNCH;
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(min3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grid, n, min3_dev);
+  hipLaunchKernelGGL(voxel_key_kernel, g1(n), dim3(256), 0, s, grid, min3_dev, n, key);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// CenterShift (transform.py:142-155) on an (n,3) float32 / float64 array; ws: 6 x 8 bytes of scratch + 6 doubles
+int cdseg_center_shift(const void* xyz, int is_f64, long n, int apply_z, void* out, void* ws12, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (!xyz || !out || !ws12) return CDSEG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* acc = (unsigned long long*)ws12;
+  double* mm = (double*)ws12 + 6;
+  if (hipMemsetAsync(acc, 0xff, 3 * 8, s) != hipSuccess || hipMemsetAsync(acc + 3, 0, 3 * 8, s) != hipSuccess)
+    return CDSEG_ERR_LAUNCH;
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (is_f64) hipLaunchKernelGGL(minmax3_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double*)xyz, n, acc);
+  else hipLaunchKernelGGL(minmax3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)xyz, n, acc);
+  hipLaunchKernelGGL(minmax3_finish_kernel, dim3(1), dim3(64), 0, s, acc, mm);
+  if (is_f64)
+    hipLaunchKernelGGL(center_shift_kernel<double>, g1(n), dim3(256), 0, s, (const double*)xyz, mm, apply_z, n, (double*)out);
+  else
+    hipLaunchKernelGGL(center_shift_kernel<float>, g1(n), dim3(256), 0, s, (const float*)xyz, mm, apply_z, n, (float*)out);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// One test-time augmentation of an (n,3) float32 array (coordinates, or normals with apply_scale = 0):
+// rot9_host != NULL: out (float64) = (in R^T) [* scale]; else flip != 0: out (float32) = in with x, y negated.
+int cdseg_tta_apply(const float* in, long n, const double* rot9_host, double scale, int apply_scale, int flip, void* out,
+                    void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (!in || !out) return CDSEG_ERR_ARG;
+  TtaP p;
+  p.rotate = rot9_host != nullptr;
+  p.flip = flip;
+  p.scale = scale;
+  for (int i = 0; i < 9; ++i) p.r[i] = rot9_host ? rot9_host[i] : 0.0;
+  hipStream_t s = (hipStream_t)stream;
+  if (p.rotate) hipLaunchKernelGGL(tta_kernel<double>, g1(n), dim3(256), 0, s, in, p, apply_scale, n, (double*)out);
+  else hipLaunchKernelGGL(tta_kernel<float>, g1(n), dim3(256), 0, s, in, p, 0, n, (float*)out);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// out = in / div + add (float32): NormalizeColor is (color, 127.5, -1)
+int cdseg_div_add(const float* in, float div, float add, long n, float* out, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipLaunchKernelGGL(div_add_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, in, div, add, n, out);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// Collect(feat_keys=(a, b)): feat (n, ca + cb) float32 = cat([a, b.float()], 1)
+int cdseg_collect_feat(const float* a, int ca, const void* b, int b_is_f64, int cb, long n, float* out, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (b_is_f64) hipLaunchKernelGGL(collect_feat_kernel<double>, g1(n * (ca + cb)), dim3(256), 0, s, a, ca, (const double*)b, cb, n, out);
+  else hipLaunchKernelGGL(collect_feat_kernel<float>, g1(n * (ca + cb)), dim3(256), 0, s, a, ca, (const float*)b, cb, n, out);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

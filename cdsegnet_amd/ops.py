@@ -685,6 +685,73 @@ def voxelize(coord, grid_size):
     return grid, key, mn
 
 
+def voxelize_any(coord, grid_size):
+    """voxelize for float32 or float64 coordinates (GridSample after a test-time rotation sees float64)."""
+    if coord.dtype != torch.float64:
+        return voxelize(coord, grid_size)
+    _need_gpu(coord)
+    coord = coord.contiguous()
+    n = coord.shape[0]
+    grid = torch.empty((n, 3), dtype=torch.int32, device=coord.device)
+    key = torch.empty(n, dtype=torch.int64, device=coord.device)
+    mn = torch.empty(3, dtype=torch.int32, device=coord.device)
+    check(_lib.load().cdseg_voxelize_f64(_ptr(coord), float(grid_size), n, _ptr(grid), _ptr(key), _ptr(mn), _stream()),
+          "voxelize_f64")
+    return grid, key, mn
+
+
+def center_shift(coord, apply_z=True):
+    """CenterShift (ref: datasets/transform.py:142-155): coord - [(xmin+xmax)/2, (ymin+ymax)/2, zmin or 0], in coord's dtype."""
+    _need_gpu(coord)
+    assert coord.dtype in (torch.float32, torch.float64) and coord.dim() == 2 and coord.shape[1] == 3
+    coord = coord.contiguous()
+    out = torch.empty_like(coord)
+    ws = torch.empty(12, dtype=torch.float64, device=coord.device)
+    check(_lib.load().cdseg_center_shift(_ptr(coord), 1 if coord.dtype == torch.float64 else 0, coord.shape[0],
+                                         1 if apply_z else 0, _ptr(out), _ptr(ws), _stream()), "center_shift")
+    return out
+
+
+def tta_apply(xyz, rot=None, scale=None, flip=False):
+    """One test-time augmentation of an (n,3) float32 array (ref: transform.py:259-328).  rot (3x3 nested floats):
+    float64 result (xyz @ rot^T) [* scale]; else flip: float32 result with x, y negated; neither: xyz itself."""
+    _need_gpu(xyz)
+    xyz = xyz.float().contiguous()
+    n = xyz.shape[0]
+    if rot is None and not flip:
+        return xyz
+    if rot is not None:
+        r = (ctypes.c_double * 9)(*[float(v) for row in rot for v in row])
+        out = torch.empty((n, 3), dtype=torch.float64, device=xyz.device)
+        check(_lib.load().cdseg_tta_apply(_ptr(xyz), n, r, float(scale if scale is not None else 1.0),
+                                          1 if scale is not None else 0, 0, _ptr(out), _stream()), "tta_apply")
+        return out
+    out = torch.empty_like(xyz)
+    check(_lib.load().cdseg_tta_apply(_ptr(xyz), n, None, 1.0, 0, 1, _ptr(out), _stream()), "tta_apply")
+    return out
+
+
+def div_add(x, div, add):
+    """x / div + add in float32 (NormalizeColor = (color, 127.5, -1), ref: transform.py:113-117)."""
+    _need_gpu(x)
+    x = x.float().contiguous()
+    out = torch.empty_like(x)
+    check(_lib.load().cdseg_div_add(_ptr(x), float(div), float(add), x.numel(), _ptr(out), _stream()), "div_add")
+    return out
+
+
+def collect_feat(a, b):
+    """Collect(feat_keys=(a, b)): cat([a.float(), b.float()], 1) (ref: transform.py:46-49); b float32 or float64."""
+    _need_gpu(a, b)
+    a = a.float().contiguous()
+    b = b.contiguous()
+    n = a.shape[0]
+    out = torch.empty((n, a.shape[1] + b.shape[1]), dtype=torch.float32, device=a.device)
+    check(_lib.load().cdseg_collect_feat(_ptr(a), a.shape[1], _ptr(b), 1 if b.dtype == torch.float64 else 0, b.shape[1], n,
+                                         _ptr(out), _stream()), "collect_feat")
+    return out
+
+
 def max_run(seg_start, m):
     out = torch.empty(1, dtype=torch.int32, device=seg_start.device)
     check(_lib.load().cdseg_max_run(_ptr(seg_start), int(m), _ptr(out), _stream()), "max_run")

@@ -251,6 +251,18 @@ int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, 
 /* grid = floor(coord / grid_size) - min (int32), key = one int64 per voxel; min3_dev (3 x int32) receives the min */
 int cdseg_voxelize(const float* coord, double grid_size, long n, int32_t* grid, int64_t* key, int32_t* min3_dev,
                    void* stream);
+int cdseg_voxelize_f64(const double* coord, double grid_size, long n, int32_t* grid, int64_t* key, int32_t* min3_dev,
+                       void* stream); /* float64 coordinates: what GridSample sees after a test-time rotation */
+/* pre-model transforms of the test pipeline (ref: configs/scannet/CDSegNet.py:253-398, datasets/transform.py):
+ * CenterShift :142-155 on an (n,3) float32 / float64 array (ws12: 96 bytes of device scratch);
+ * one test-time augmentation :259-328 - rot9_host (row-major R) given: out FLOAT64 (n,3) = (in R^T) [* scale]
+ *   (RandomRotateTargetAngle about the origin, then RandomScale), else flip: out float32 = in with x and y negated;
+ * NormalizeColor :113-117 as out = in / div + add;  Collect(feat_keys=(a, b)) :46-49 as feat = cat([a, float(b)], 1). */
+int cdseg_center_shift(const void* xyz, int is_f64, long n, int apply_z, void* out, void* ws12, void* stream);
+int cdseg_tta_apply(const float* in, long n, const double* rot9_host, double scale, int apply_scale, int flip, void* out,
+                    void* stream);
+int cdseg_div_add(const float* in, float div, float add, long n, float* out, void* stream);
+int cdseg_collect_feat(const float* a, int ca, const void* b, int b_is_f64, int cb, long n, float* out, void* stream);
 /* largest run length of a seg_start array (m runs) = number of test fragments (count.max()) */
 int cdseg_max_run(const int32_t* seg_start, long m, int32_t* out_dev, void* stream);
 /* fragment `frag`: idx_part[v] = idx_sort[seg_start[v] + frag % count_v].  ref: transform.py:862-864 */

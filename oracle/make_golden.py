@@ -391,6 +391,61 @@ def gen_gridsample(ref):
         print("gridsample", tag, idx.shape)
 
 
+def gen_tta(ref):
+    """The reference's test pipeline up to the model: CenterShift, NormalizeColor, the 13 aug_transform lists of
+    configs/scannet/CDSegNet.py:278-398, GridSample(mode="test"), CenterShift(apply_z=False) + Collect per fragment
+    (datasets/defaults.py:98-132), run with the reference's own transform classes."""
+    import importlib.util
+    import runpy
+    spec = importlib.util.spec_from_file_location("_ref_transform", os.path.join(REF, "pointcept/datasets/transform.py"))
+    T = importlib.util.module_from_spec(spec)
+    sys.modules["_ref_transform"] = T
+    spec.loader.exec_module(T)
+    cfg = runpy.run_path(os.path.join(REF, "configs/scannet/CDSegNet.py"))["data"]["test"]
+    rng = np.random.default_rng(17)
+    n = 1400
+    coord = (rng.random((n, 3)) * np.array([3.0, 2.2, 1.6]) + np.array([1.0, -0.5, 0.2])).astype(np.float32)
+    coord[:40] = coord[40:80] + rng.normal(0, 0.004, (40, 3)).astype(np.float32)  # several points per voxel
+    color = rng.integers(0, 256, (n, 3)).astype(np.float32)
+    normal = rng.normal(size=(n, 3)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    gsize = 0.05
+    pre = T.Compose(cfg["transform"])
+    data = pre(dict(coord=coord.copy(), color=color.copy(), normal=normal.copy()))
+    vox = dict(cfg["test_cfg"]["voxelize"], grid_size=gsize)
+    voxelize = T.TRANSFORMS.build(vox)
+    post = T.Compose(cfg["test_cfg"]["post_transform"])
+    augs = [T.Compose(a) for a in cfg["test_cfg"]["aug_transform"]]
+    assert len(augs) == 13
+    from copy import deepcopy
+    fx = dict(coord=coord, color=color, normal=normal, grid_size=np.float64(gsize), coord0=data["coord"], color0=data["color"],
+              num_aug=np.int64(len(augs)))
+    for a, aug in enumerate(augs):
+        d = aug(deepcopy(data))
+        fx[f"aug{a}_coord"] = np.asarray(d["coord"])          # float64 after a rotation, float32 after the flip
+        fx[f"aug{a}_normal"] = np.asarray(d["normal"])
+        parts = voxelize(d)
+        grid_full = np.full((n, 3), -1, dtype=np.int64)
+        feat_full = np.zeros((n, 6), dtype=np.float32)
+        sizes = []
+        for k, part in enumerate(parts):
+            idx = np.asarray(part["index"])
+            grid_full[idx] = part["grid_coord"]
+            sizes.append(len(idx))
+            out = post(part)
+            feat_full[idx] = out["feat"].numpy()
+            if k == 0:
+                fx[f"aug{a}_frag0_index"] = idx.astype(np.int64)
+                fx[f"aug{a}_frag0_coord"] = out["coord"].numpy()
+                assert out["offset"].tolist() == [len(idx)] and out["feat"].dtype == torch.float32
+        assert (grid_full >= 0).all()
+        fx[f"aug{a}_grid"] = grid_full.astype(np.int32)
+        fx[f"aug{a}_feat"] = feat_full
+        fx[f"aug{a}_frag_sizes"] = np.array(sizes, dtype=np.int64)
+        print("tta aug", a, fx[f"aug{a}_coord"].dtype, "fragments", sizes)
+    save_fixture(os.path.join(OUT, "tta_pipeline.npz"), **fx)
+
+
 def gen_iou(ref):
     """intersection_and_union of the reference (utils/misc.py:38-50) on random label arrays with ignored rows."""
     import importlib.util
@@ -414,7 +469,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "iou"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "tta", "iou"]
     if "ser" in which:
         gen_serialization(ref)
     if "e2e" in which:
@@ -427,5 +482,7 @@ if __name__ == "__main__":
         gen_ptv3(ref)
     if "gs" in which:
         gen_gridsample(ref)
+    if "tta" in which:
+        gen_tta(ref)
     if "iou" in which:
         gen_iou(ref)

@@ -363,6 +363,34 @@ def voxelize(coord, grid_size):
     return g.int(), key, mn.int()
 
 
+def voxelize_any(coord, grid_size):
+    return voxelize(coord, grid_size)
+
+
+def center_shift(coord, apply_z=True):
+    mn, mx = coord.min(0).values, coord.max(0).values
+    z = mn[2] if apply_z else torch.zeros((), dtype=coord.dtype)
+    return coord - torch.stack([(mn[0] + mx[0]) / 2, (mn[1] + mx[1]) / 2, z])
+
+
+def tta_apply(xyz, rot=None, scale=None, flip=False):
+    xyz = xyz.float()
+    if rot is not None:
+        out = xyz.double() @ torch.tensor(rot, dtype=torch.float64).t()
+        return out * scale if scale is not None else out
+    if flip:
+        return xyz * torch.tensor([-1.0, -1.0, 1.0])
+    return xyz
+
+
+def div_add(x, div, add):
+    return x.float() / div + add
+
+
+def collect_feat(a, b):
+    return torch.cat([a.float(), b.float()], 1)
+
+
 def max_run(seg_start, m):
     s = seg_start[: m + 1].long()
     return (s[1:] - s[:-1]).max().int().reshape(1)

@@ -215,3 +215,30 @@ def test_evaluate_scene_host_logic(monkeypatch):
     c2 = ev.evaluate_scene(torch.as_tensor(logits), d2, k, ignore_index=-1, reduce=False).numpy()
     i, u, t = OT.intersection_and_union(logits.argmax(1), seg[keep], k, -1)
     assert np.array_equal(c2[0], i) and np.array_equal(c2[1], u) and np.array_equal(c2[2], t)
+
+
+def test_tta_pipeline_host_logic_vs_reference_fixture(monkeypatch):
+    """cdsegnet_amd.testtime.prepare_test_fragments (raw scan -> CenterShift / NormalizeColor -> 13 augmentations ->
+    GridSample fragments -> per-fragment CenterShift + Collect) on the emulated op layer against the reference fixture."""
+    from cdsegnet_amd import testtime as tt
+    monkeypatch.setattr(tt, "ops", emu_ops)
+    fx = load_fixture("tta_pipeline.npz")
+    n = len(fx["coord"])
+    idxs, dicts = tt.prepare_test_fragments(torch.as_tensor(fx["coord"]), torch.as_tensor(fx["color"]),
+                                            torch.as_tensor(fx["normal"]), float(fx["grid_size"]))
+    sizes = [int(v) for a in range(13) for v in fx[f"aug{a}_frag_sizes"]]
+    assert [d["feat"].shape[0] for d in dicts] == sizes
+    pos = 0
+    for a in range(13):
+        k = len(fx[f"aug{a}_frag_sizes"])
+        grid = np.full((n, 3), -1, dtype=np.int64)
+        feat = np.zeros((n, 6), dtype=np.float32)
+        for idx, d in zip(idxs[pos:pos + k], dicts[pos:pos + k]):
+            i = idx.numpy().astype(np.int64)
+            grid[i] = d["grid_coord"].numpy()
+            feat[i] = d["feat"].numpy()
+            assert d["feat"].dtype == torch.float32 and d["offset_host"] == [len(i)]
+        assert np.array_equal(grid, fx[f"aug{a}_grid"]), a
+        assert np.array_equal(feat, fx[f"aug{a}_feat"]), a
+        pos += k
+    assert pos == len(dicts)

@@ -412,6 +412,54 @@ def test_testtime_pipeline_vs_oracle():
     assert err < 1e-4 and agree > 0.999
 
 
+def test_testtime_pipeline_with_tta_vs_oracle():
+    """Raw scan -> labels with test-time augmentation (cdsegnet_amd.testtime.segment_scene_tta: CenterShift,
+    NormalizeColor, rotations / scale / flip, GridSample fragments, per-fragment inference, softmax vote) against the
+    CPU oracle pipeline (oracle/testtime.py, pinned to the reference's transform classes) + oracle model, same draws."""
+    from cdsegnet_amd import testtime as tt
+    from oracle import testtime as OT
+    cfg = configs.mini_config()
+    model = build_model(cfg)
+    sd = fill_state_dict(model.state_dict(), seed=2)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    model.precision = "fp32"
+    rng = np.random.default_rng(11)
+    n, gsize = 2500, 0.08
+    coord = (rng.random((n, 3)) * np.array([3.0, 2.0, 0.5]) + np.array([0.7, -1.0, 0.1])).astype(np.float32)
+    color = rng.integers(0, 256, (n, 3)).astype(np.float32)
+    normal = rng.normal(size=(n, 3)).astype(np.float32)
+    augs = [tt.SCANNET_TTA[1], tt.SCANNET_TTA[6], tt.SCANNET_TTA[12]]  # rot pi/2; rot pi + scale 0.95; flip
+    cd, cl, nr = (torch.as_tensor(v).cuda() for v in (coord, color, normal))
+    torch.manual_seed(5)
+    state = torch.get_rng_state()
+    labels, pred = tt.segment_scene_tta(model, cd, cl, nr, gsize, cfg["num_classes"], augs=augs)
+    # oracle: same fragments in the DEVICE's member order (stable sort by packed key vs the oracle's hash order), same draws
+    idxs, dicts = tt.prepare_test_fragments(cd, cl, nr, gsize, augs=augs)
+    ref = OT.prepare_test_fragments(coord, color, normal, gsize, augs=augs)
+    ref_frags = [f for r in ref for f in r["fragments"]]
+    assert len(ref_frags) == len(dicts)
+    torch.set_rng_state(state)
+    parts, lg = [], []
+    for idx, d, rf in zip(idxs, dicts, ref_frags):
+        p = idx.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(p), np.sort(rf["index"]))
+        m = len(p)
+        draws = dict(noise=torch.normal(0, 1, size=(m, cfg["c_in_channels"])),
+                     perms=[torch.randperm(4).numpy().copy() for _ in range(8)])
+        order = np.argsort(rf["index"], kind="stable")[np.argsort(np.argsort(p, kind="stable"), kind="stable")]
+        inp = dict(coord=rf["coord"][order].astype(np.float32), grid_coord=rf["grid_coord"][order], feat=rf["feat"][order],
+                   offset=np.array([m], dtype=np.int64))
+        assert np.array_equal(inp["grid_coord"], d["grid_coord"].cpu().numpy()) and np.array_equal(inp["feat"], d["feat"].cpu().numpy())
+        lg.append(OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"]).numpy())
+        parts.append(p)
+    ref_labels, ref_pred = OT.vote(n, cfg["num_classes"], parts, lg)
+    err = np.abs(pred.cpu().numpy() - ref_pred).max()
+    agree = (labels.cpu().numpy() == ref_labels).mean()
+    print(f"[testtime + TTA fp32] max_prob_err={err:.3e} label_agreement={agree:.5f} fragments={len(parts)}")
+    assert err < 1e-4 and agree > 0.999
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_inference_many_equals_scene_by_scene(precision):
     """Scenes in flight on several HIP streams (inference_many) give bit-identical logits to one inference call

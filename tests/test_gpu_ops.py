@@ -902,3 +902,47 @@ def test_cpe_head_fused_equals_linear_ln_qkv_sequence(ops, M, C, tb):
     qb = torch.empty(M, 3 * C, dtype=bf, device="cuda")
     ops.gemm(h, wq, qb, bias=bq)
     assert torch.equal(xa, xb) and torch.equal(qa, qb)
+
+
+def test_tta_pipeline_device_vs_reference_fixture(ops):
+    """SURVEY 8f row 1, complete: raw scan -> CenterShift / NormalizeColor -> the 13 test-time augmentations of
+    configs/scannet/CDSegNet.py:278-398 -> GridSample(mode="test") -> per-fragment CenterShift + Collect, all on the device
+    (csrc/testtime.hip), against the reference's own transform classes (tests/golden/tta_pipeline.npz): augmented
+    coordinates / normals bit-exact incl. their float64 / float32 dtype, per-point voxel coordinates exact, features exact."""
+    from cdsegnet_amd import testtime as tt
+    fx = load_fixture("tta_pipeline.npz")
+    n = len(fx["coord"])
+    coord, color, normal = dev(fx["coord"]), dev(fx["color"]), dev(fx["normal"])
+    ops.bind_stream()
+    c0 = ops.center_shift(coord, apply_z=True)
+    assert np.array_equal(c0.cpu().numpy(), fx["coord0"])
+    assert np.array_equal(ops.div_add(color, 127.5, -1.0).cpu().numpy(), fx["color0"])
+    for a, aug in enumerate(tt.SCANNET_TTA):
+        ca, na = tt.apply_aug(c0, normal, aug)
+        want_c, want_n = fx[f"aug{a}_coord"], fx[f"aug{a}_normal"]
+        assert str(ca.dtype).endswith(str(want_c.dtype)) and np.array_equal(ca.cpu().numpy(), want_c), a
+        assert np.array_equal(na.cpu().numpy(), want_n), a
+    ops.unbind_stream()
+    idxs, dicts = tt.prepare_test_fragments(coord, color, normal, float(fx["grid_size"]))
+    pos = 0
+    for a in range(13):
+        k = len(fx[f"aug{a}_frag_sizes"])
+        assert [d["feat"].shape[0] for d in dicts[pos:pos + k]] == fx[f"aug{a}_frag_sizes"].tolist()
+        grid = np.full((n, 3), -1, dtype=np.int64)
+        feat = np.zeros((n, 6), dtype=np.float32)
+        for idx, d in zip(idxs[pos:pos + k], dicts[pos:pos + k]):
+            i = idx.cpu().numpy().astype(np.int64)
+            grid[i] = d["grid_coord"].cpu().numpy()
+            feat[i] = d["feat"].cpu().numpy()
+        assert np.array_equal(grid, fx[f"aug{a}_grid"]), a
+        assert np.array_equal(feat, fx[f"aug{a}_feat"]), a
+        # per-fragment CenterShift(apply_z=False): compare on the reference's own fragment-0 member set
+        i0 = fx[f"aug{a}_frag0_index"]
+        ops.bind_stream()
+        sub = ops.gather_rows((tt.apply_aug(ops.center_shift(coord, True), normal, tt.SCANNET_TTA[a])[0]).contiguous(),
+                              dev(i0.astype(np.int32)))
+        got = ops.center_shift(sub, apply_z=False).cpu().numpy()
+        ops.unbind_stream()
+        assert np.array_equal(got.astype(np.float32) if fx[f"aug{a}_frag0_coord"].dtype == np.float32 else got,
+                              fx[f"aug{a}_frag0_coord"]), a
+        pos += k

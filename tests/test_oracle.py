@@ -245,3 +245,30 @@ def test_knn_oracle_vs_kdtree():
         same = (j + rs) == idx[qs:qe]
         assert same.mean() > 0.999  # float32 vs float64 near-ties only
         assert np.allclose(np.sqrt(d2[qs:qe]), d, atol=1e-5)
+
+
+def test_tta_pipeline_oracle_vs_reference():
+    """oracle/testtime.py's restatement of the pre-model transforms + the 13 test-time augmentations + GridSample +
+    per-fragment CenterShift / Collect against tests/golden/tta_pipeline.npz, produced by the reference's own transform
+    classes driven by configs/scannet/CDSegNet.py's test block (oracle/make_golden.py tta)."""
+    from oracle import testtime as TT
+    fx = load_fixture("tta_pipeline.npz")
+    assert len(TT.SCANNET_TTA) == int(fx["num_aug"]) == 13
+    coord0 = TT.center_shift(fx["coord"], apply_z=True)
+    assert coord0.dtype == np.float32 and np.array_equal(coord0, fx["coord0"])
+    assert np.array_equal(TT.normalize_color(fx["color"]), fx["color0"])
+    res = TT.prepare_test_fragments(fx["coord"], fx["color"], fx["normal"], float(fx["grid_size"]))
+    for a, r in enumerate(res):
+        assert r["coord"].dtype == fx[f"aug{a}_coord"].dtype  # float64 after a rotation, float32 after the flip
+        assert np.array_equal(r["coord"], fx[f"aug{a}_coord"]), a
+        assert np.array_equal(r["normal"], fx[f"aug{a}_normal"]), a
+        assert np.array_equal(r["grid"], fx[f"aug{a}_grid"]), a  # per-point voxel coordinates: exact
+        assert [len(f["index"]) for f in r["fragments"]] == fx[f"aug{a}_frag_sizes"].tolist()
+        feat = np.zeros((len(fx["coord"]), 6), dtype=np.float32)
+        for f in r["fragments"]:
+            feat[f["index"]] = f["feat"]
+        assert np.array_equal(feat, fx[f"aug{a}_feat"]), a
+        # fragment 0: same voxel set; the member chosen per voxel is platform dependent in the reference (unstable argsort)
+        f0 = r["fragments"][0]
+        g_ref = fx[f"aug{a}_grid"][fx[f"aug{a}_frag0_index"]]
+        assert sorted(map(tuple, f0["grid_coord"])) == sorted(map(tuple, g_ref))

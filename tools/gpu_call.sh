@@ -1,15 +1,11 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "attention or subm_conv3 or sparse_conv" 2>&1 | tail -15 ) > gpurun_out/r2b_tests.log 2>&1
-( timeout 200 python tools/bench_attention.py 120000 2 bf16; timeout 200 python tools/bench_attention.py 960000 2 bf16; timeout 200 python tools/bench_attention.py 446000 4 bf16 ) > gpurun_out/r2b_attn.txt 2>&1
-( for d in 0 1 2 3; do echo "DBG=$d"; CDSEG_CONV_DBG=$d CDSEG_BENCH_NEW_ONLY=1 timeout 200 python tools/bench_conv.py 1 8 | grep weight; CDSEG_CONV_DBG=$d CDSEG_BENCH_NEW_ONLY=1 timeout 200 python tools/bench_conv.py 0 8 | grep weight; done ) > gpurun_out/r2b_conv_dbg.txt 2>&1
-export CDSEG_BENCH_NEW_ONLY=1
-bash tools/pmc_r02.sh conv32 conv_rg_kernel python tools/bench_conv.py 0 8 10 > /dev/null 2>&1
-bash tools/pmc_r02.sh conv64 conv_rg_kernel python tools/bench_conv.py 1 8 10 > /dev/null 2>&1
-bash tools/pmc_r02.sh attn attn_bf16 python tools/bench_attention.py 960000 2 bf16 10 > /dev/null 2>&1
-unset CDSEG_BENCH_NEW_ONLY
-( rocprofv3 -L 2>/dev/null | grep -oE "\b(TCP|TA|TCC|SQ|TD)_[A-Z0-9_a-z]+" | sort -u | tr '\n' ' ' ) > gpurun_out/r2b_counters.txt 2>&1
-( timeout 600 python bench.py --steps 8 --warmup 3 --cpu-points 120000 --cpu-threads 16 ) > gpurun_out/r2b_bench.json 2> gpurun_out/r2b_bench.err
-cat gpurun_out/r2b_tests.log gpurun_out/r2b_attn.txt gpurun_out/r2b_conv_dbg.txt
-tail -3 gpurun_out/r2b_bench.err
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/r2c_tests.log 2>&1
+( timeout 120 tools/ubench/pipes | grep -E "exp_f16|legacy|16 perm|bpermute|16 exp  |16 fma" ) > gpurun_out/r2c_pipes.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_r2c -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-agreement --no-kernel-timer > gpurun_out/r2c_bench_under_rocprof.json 2> gpurun_out/r2c_prof.err )
+cd $GRAFT_REPO_ROOT
+DB=$(find /tmp/prof_r2c -name "*.db" | head -1)
+python tools/prof_summary.py $DB 6 > gpurun_out/r2c_kernel_stats.txt 2>&1
+tail -5 gpurun_out/r2c_tests.log; cat gpurun_out/r2c_pipes.txt; head -40 gpurun_out/r2c_kernel_stats.txt

@@ -94,6 +94,23 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters, flo
 #define FRA(i) asm volatile("v_fract_f32 %0, %1" : "=v"(e[i]) : "v"(x[i]))
       FRA(0); FRA(1); FRA(2); FRA(3); FRA(4); FRA(5); FRA(6); FRA(7); FRA(8); FRA(9); FRA(10); FRA(11); FRA(12); FRA(13); FRA(14); FRA(15);
     }
+    if (KIND == 15) {
+#define EXH(i) asm volatile("v_exp_f16 %0, %1" : "=v"(e[i]) : "v"(x[i]))
+      EXH(0); EXH(1); EXH(2); EXH(3); EXH(4); EXH(5); EXH(6); EXH(7); EXH(8); EXH(9); EXH(10); EXH(11); EXH(12); EXH(13); EXH(14); EXH(15);
+    }
+    if (KIND == 16) {
+#define EXL(i) asm volatile("v_exp_legacy_f32 %0, %1" : "=v"(e[i]) : "v"(x[i]))
+      EXL(0); EXL(1); EXL(2); EXL(3); EXL(4); EXL(5); EXL(6); EXL(7); EXL(8); EXL(9); EXL(10); EXL(11); EXL(12); EXL(13); EXL(14); EXL(15);
+    }
+    if (KIND == 17) {
+#define PERMX(i) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(e[i]) : "v"(x[i]), "v"(f[i]), "s"(0x07060302u))
+      PERMX(0); PERMX(1); PERMX(2); PERMX(3); PERMX(4); PERMX(5); PERMX(6); PERMX(7); PERMX(8); PERMX(9); PERMX(10); PERMX(11); PERMX(12); PERMX(13); PERMX(14); PERMX(15);
+    }
+    if (KIND == 18) {  // bpermute (LDS crossbar, no LDS memory): cost next to VALU work
+#define BPM(i) asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(e[i]) : "v"(p[(i) & 7]), "v"(x[i]))
+      BPM(0); BPM(1); BPM(2); BPM(3); BPM(4); BPM(5); BPM(6); BPM(7); BPM(8); BPM(9); BPM(10); BPM(11); BPM(12); BPM(13); BPM(14); BPM(15);
+      asm volatile("s_waitcnt lgkmcnt(0)");
+    }
     if (KIND == 14) {  // PV on 16x16x32 instead: 1 mfma32 (QK) + 4 mfma16 per tile
       f32x16_t& q = acc0;
       MFMA(q);
@@ -153,6 +170,10 @@ int main() {
   run<11>("16 ldexp");
   run<12>("16 cvt_pk_bf16");
   run<13>("16 fract");
+  run<15>("16 exp_f16");
+  run<16>("16 exp_legacy_f32");
+  run<17>("16 perm");
+  run<18>("16 ds_bpermute");
   run<4>("3 mfma32x32x16");
   run<14>("1 mfma32 + 4 mfma16x16x32");
   run<5>("3 mfma + 16 exp");
