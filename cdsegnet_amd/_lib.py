@@ -116,8 +116,6 @@ SIGNATURES = {
     "cdseg_subm_conv3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
-    "cdseg_stem_conv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
-                                c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "cdseg_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
                                 c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "cdseg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

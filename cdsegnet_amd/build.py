@@ -35,7 +35,7 @@ def build_library(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++20", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -132,56 +132,6 @@ __global__ void segment_mean_kernel(const float* __restrict__ x, int ldx, const 
   }
 }
 
-// ---------------------------------------------------------------- stem conv (k=5, Cin<=8)
-// 4 lanes per point, each lane owns Cout/4 output channels (<= 16).  Neighbour table is
-// k-major (kvol, n) so a wave's 16 points read consecutive int32.  Weights (kvol, Cin, Cout).
-template <int CPT, bool WLDS>
-__global__ void stem_conv_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ nbr,
-                                 const float* __restrict__ w, const float* __restrict__ scale,
-                                 const float* __restrict__ shift, long n, int cin, int cout, int kvol,
-                                 float* __restrict__ out, int ldo, void* __restrict__ out2, int out2_dtype, int ldo2) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const float* ws = w;  // weights too large for LDS: read through L1/L2 (wave-uniform addresses)
-  if (WLDS) {
-    float* wl = reinterpret_cast<float*>(smem_raw);
-    const int wsize = kvol * cin * cout;
-    for (int i = threadIdx.x; i < wsize; i += blockDim.x) wl[i] = w[i];
-    __syncthreads();
-    ws = wl;
-  }
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long p = t >> 2;
-  const int co0 = (int)(t & 3) * CPT;
-  if (p >= n) return;
-  float acc[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) acc[i] = 0.f;
-  for (int k = 0; k < kvol; ++k) {
-    const int j = nbr[(long)k * n + p];
-    if (j >= 0) {
-      const float* xr = x + (long)j * ldx;
-      const float* wk = ws + (long)k * cin * cout + co0;
-      for (int ci = 0; ci < cin; ++ci) {
-        const float xv = xr[ci];
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) acc[i] = fmaf(xv, wk[ci * cout + i], acc[i]);
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int co = co0 + i;
-    float v = acc[i];
-    if (scale) v = v * scale[co] + shift[co];
-    v = gelu_erf(v);
-    out[p * ldo + co] = v;
-    if (out2) {
-      if (out2_dtype == CDSEG_F32) ((float*)out2)[p * ldo2 + co] = v;
-      else ((bf16_t*)out2)[p * ldo2 + co] = f32_to_bf16(v);
-    }
-  }
-}
-
 // ---------------------------------------------------------------- GEMV (timestep MLP): one wave per output
 __global__ void gemv_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ x,
                             int n, int k, int act, float* __restrict__ y) {
@@ -328,41 +278,6 @@ int cdseg_segment_mean(const float* x, int ldx, const int32_t* seg_start, long m
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(segment_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      seg_start, m, c, out, ldo);
-  CDSEG_CHECK_LAUNCH();
-  return CDSEG_OK;
-}
-
-int cdseg_stem_conv(const float* x, int ldx, const int32_t* nbr, const float* w, const float* scale,
-                    const float* shift, long n, int cin, int cout, int kvol, float* out, int ldo, void* out2,
-                    int out2_dtype, int ldo2, void* stream) {
-  if (n <= 0) return CDSEG_OK;
-  if (cin <= 0 || cout <= 0 || (cout & 3) || cout > 64 || (scale && !shift)) return CDSEG_ERR_ARG;
-  size_t smem = (size_t)kvol * cin * cout * sizeof(float);
-  const bool wlds = smem <= 128 * 1024;
-  if (!wlds) smem = 0;
-  const int cpt = cout / 4;
-  const int bs = smem > 48 * 1024 ? 1024 : 256;
-  dim3 grid((unsigned)((n * 4 + bs - 1) / bs)), block(bs);
-  hipStream_t s = (hipStream_t)stream;
-#define STEM_LAUNCH(CPT)                                                                                          \
-  do {                                                                                                            \
-    if (wlds) {                                                                                                   \
-      if (smem > 64 * 1024 &&                                                                                     \
-          hipFuncSetAttribute((const void*)stem_conv_kernel<CPT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)smem) != hipSuccess)                                                           \
-        return CDSEG_ERR_LAUNCH;                                                                                  \
-      hipLaunchKernelGGL((stem_conv_kernel<CPT, true>), grid, block, smem, s, x, ldx, nbr, w, scale, shift, n, cin, \
-                         cout, kvol, out, ldo, out2, out2_dtype, ldo2);                                           \
-    } else {                                                                                                      \
-      hipLaunchKernelGGL((stem_conv_kernel<CPT, false>), grid, block, 0, s, x, ldx, nbr, w, scale, shift, n, cin,   \
-                         cout, kvol, out, ldo, out2, out2_dtype, ldo2);                                           \
-    }                                                                                                             \
-  } while (0)
-  if (cpt == 4) STEM_LAUNCH(4);
-  else if (cpt == 8) STEM_LAUNCH(8);
-  else if (cpt == 16) STEM_LAUNCH(16);
-  else return CDSEG_ERR_UNSUPPORTED;
-#undef STEM_LAUNCH
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

@@ -576,17 +576,6 @@ def subm_conv3(x, wimg, bias, nbr_kmajor, out):
     return out
 
 
-def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):
-    """SubMConv3d(k=5, bias=False) + folded BN + GELU.  w_packed (kvol, Cin, Cout) fp32."""
-    n, cin = x.shape
-    kvol, _, cout = w_packed.shape
-    check(_lib.load().cdseg_stem_conv(_ptr(x), x.stride(0), _ptr(nbr_kmajor), _ptr(w_packed), _ptr(scale), _ptr(shift),
-                                      n, cin, cout, kvol, _ptr(out), out.stride(0), _ptr(out2),
-                                      dt(out2) if out2 is not None else 0, out2.stride(0) if out2 is not None else 0,
-                                      _stream()), "stem_conv")
-    return out
-
-
 def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=None):
     m, c = x.shape
     check(_lib.load().cdseg_layernorm(_ptr(x), dt(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(res),

@@ -185,12 +185,6 @@ typedef struct cdseg_gemm_args {
 } cdseg_gemm_args;
 int cdseg_gemm(const cdseg_gemm_args* args_host, void* stream);
 
-/* stem: SubMConv3d(Cin -> Cout, k=5, bias=False) + eval BN + GELU on the VALU (Cin is 4..6).
- * ref: ptv3.py:633-663.  w is repacked (kvol, Cin, Cout) fp32. */
-int cdseg_stem_conv(const float* x, int ldx, const int32_t* nbr, const float* w, const float* scale,
-                    const float* shift, long n, int cin, int cout, int kvol, float* out, int ldo, void* out2,
-                    int out2_dtype, int ldo2, void* stream);
-
 /* ------------------------------------------------------------------ LayerNorm
  * out = [res +] LayerNorm(x) * gamma + beta [+ colbias]; optional second copy out2.
  * ref: nn.LayerNorm(eps 1e-5) at ptv3.py:365, 367, 381 and the CPE residual ptv3.py:401-404,

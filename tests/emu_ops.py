@@ -250,20 +250,6 @@ def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
     return x
 
 
-def stem_conv(x, nbr_kmajor, w_packed, scale, shift, out, out2=None):
-    kvol, cin, cout = w_packed.shape
-    v = torch.zeros(x.shape[0], cout)
-    for k in range(kvol):
-        j = nbr_kmajor[k].long()
-        m = j >= 0
-        v[m] += x[j[m]] @ w_packed[k]
-    v = F.gelu(v * scale + shift)
-    out.copy_(v)
-    if out2 is not None:
-        out2.copy_(v.to(out2.dtype))
-    return out
-
-
 def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=None):
     v = F.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps)
     if res is not None:

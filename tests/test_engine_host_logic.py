@@ -134,7 +134,9 @@ def test_testtime_pipeline_host_logic(emulated, monkeypatch):
 
     feat = torch.as_tensor(np.random.default_rng(1).random((len(coord), 3)).astype(np.float32))
     labels, pred = tt.segment_scene(FakeModel(), coord, feat, gsize, 4)
-    lg = [FakeModel().inference(dict(coord=coord[p], grid_coord=torch.as_tensor(grid[p]), feat=feat[p],
+    # post_transform of the reference's test_cfg: CenterShift(apply_z=False) on every fragment's own coordinates
+    lg = [FakeModel().inference(dict(coord=torch.as_tensor(OT.center_shift(fx["coord"][p], apply_z=False)),
+                                     grid_coord=torch.as_tensor(grid[p]), feat=feat[p],
                                      offset_host=[len(p)]))["seg_logits"].numpy() for p in parts]
     ref_labels, ref_pred = OT.vote(len(coord), 4, parts, lg)
     assert np.allclose(pred.numpy(), ref_pred, atol=1e-5)

@@ -400,25 +400,6 @@ def test_stem_as_gathered_gemm_vs_oracle(ops, dtype, name, cin, cout):
     assert err < 1e-4
 
 
-@pytest.mark.parametrize("name,cin,cout", [("room1500", 6, 32), ("lidar5000", 4, 16), ("batch2", 6, 64)])
-def test_stem_conv_vs_oracle(ops, name, cin, cout):
-    fx = load_fixture(f"serialization_{name}.npz")
-    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
-    n = len(p)
-    nbr_t = ops.nbr_table(zs, g0, b0, depth, 5, kmajor=True)
-    g = torch.Generator().manual_seed(cin * cout)
-    x = torch.randn(n, cin, generator=g)
-    w = torch.randn(cout, 5, 5, 5, cin, generator=g) / (125 * cin) ** 0.5
-    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
-    ref = F.gelu(OM.subm_conv3d(x, nbr_t.cpu().numpy().T.astype(np.int64), w, None) * sc + sh)
-    out = torch.empty(n, cout, dtype=torch.float32, device="cuda")
-    out2 = torch.empty(n, cout, dtype=torch.bfloat16, device="cuda")
-    wp = w.reshape(cout, 125, cin).permute(1, 2, 0).contiguous()
-    ops.stem_conv(dev(x), nbr_t, dev(wp), dev(sc), dev(sh), out, out2)
-    assert (out.cpu() - ref).abs().max().item() < 1e-4
-    assert (out2.float().cpu() - ref).abs().max().item() < 0.01 * (1 + ref.abs().max().item())
-
-
 # ------------------------------------------------------------------ LayerNorm / pooling reduce / small ops
 @pytest.mark.parametrize("C", [16, 32, 48, 64, 128, 256, 512, 2048])
 def test_layernorm(ops, C):

@@ -1,11 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/r2c_tests.log 2>&1
-( timeout 120 tools/ubench/pipes | grep -E "exp_f16|legacy|16 perm|bpermute|16 exp  |16 fma" ) > gpurun_out/r2c_pipes.txt 2>&1
-cd /tmp && export TMPDIR=/tmp
-( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_r2c -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-agreement --no-kernel-timer > gpurun_out/r2c_bench_under_rocprof.json 2> gpurun_out/r2c_prof.err )
-cd $GRAFT_REPO_ROOT
-DB=$(find /tmp/prof_r2c -name "*.db" | head -1)
-python tools/prof_summary.py $DB 6 > gpurun_out/r2c_kernel_stats.txt 2>&1
-tail -5 gpurun_out/r2c_tests.log; cat gpurun_out/r2c_pipes.txt; head -40 gpurun_out/r2c_kernel_stats.txt
+( timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "subm_conv3 or sparse_conv" 2>&1 | tail -15 ) > gpurun_out/r2d_tests.log 2>&1
+( export CDSEG_BENCH_NEW_ONLY=1; for a in "0 1" "0 4" "0 8" "1 4" "1 8"; do timeout 200 python tools/bench_conv.py $a | grep weight; done ) > gpurun_out/r2d_conv.txt 2>&1
+( timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-agreement ) > gpurun_out/r2d_bench.json 2> gpurun_out/r2d_bench.err
+cat gpurun_out/r2d_tests.log gpurun_out/r2d_conv.txt; tail -2 gpurun_out/r2d_bench.err
