@@ -114,6 +114,11 @@ SIGNATURES = {
     "cdseg_subm_conv3_wimg_bytes": (c_size_t, [c_int]),
     "cdseg_subm_conv3_pack": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "cdseg_subm_conv3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
+    "cdseg_child_info": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "cdseg_stem5_wimg_bytes": (c_size_t, []),
+    "cdseg_stem5_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cdseg_stem5": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long,
+                            c_int, c_void_p, c_void_p, c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
     "cdseg_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,

@@ -22,7 +22,6 @@
 // HBM traffic = features once + kernel map once + output once; W never leaves the CU after the first tile.
 #include <cstdlib>
 #include <type_traits>
-#include <utility>
 
 #include "common.h"
 #include "prof.h"
@@ -62,7 +61,7 @@ struct ConvCfg {
   static constexpr int LDS_BYTES = LDS_OFFSETS * OFF_BYTES;  // 55,296 / 155,648
   static constexpr int WAVES = C <= 32 ? 8 : 16;             // C = 32: 2 blocks / CU, C = 64: 1 -> 4 waves / SIMD
   static constexpr int RG = 2;                               // 16-row groups per wave
-  static constexpr int RING = C <= 32 ? 6 : 3;               // single-offset gather slots in flight (register budget 128)
+  static constexpr int G = C <= 32 ? 3 : 1;                  // offsets per pipeline group (register budget 128)
   static constexpr int ROWS_PER_WAVE = RG * 16;
   static constexpr int ROWS_PER_BLOCK = WAVES * ROWS_PER_WAVE;
 };
@@ -90,30 +89,13 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_pack_w_kernel(con
   img[u] = *reinterpret_cast<const uint4*>(w + (long)frag_channel<C>(ct, i) * (27 * C) + o * C + kc * 8);
 }
 
-// The 27 x 32 kernel-map entries of a wave's 32 rows live in 14 registers: idxr[g][k], lane (q = lane >> 4, j = lane & 15)
-// holds nbr[4k + q][row0 + 16g + j] (offset 27 = none).  One ds_bpermute hands the 16 entries of (offset o, row group g)
-// to the 64 MFMA lanes: source lane ((o & 3) << 4) + j of register idxr[g][o >> 2].  o is wave-uniform, the register
-// is picked by a scalar switch.
-__device__ __forceinline__ int idx_fetch(const int (&r)[7], int o, int jrow) {
-  const int addr = ((((o & 3) << 4) + jrow) << 2);
-  switch (o >> 2) {
-    case 0: return __builtin_amdgcn_ds_bpermute(addr, r[0]);
-    case 1: return __builtin_amdgcn_ds_bpermute(addr, r[1]);
-    case 2: return __builtin_amdgcn_ds_bpermute(addr, r[2]);
-    case 3: return __builtin_amdgcn_ds_bpermute(addr, r[3]);
-    case 4: return __builtin_amdgcn_ds_bpermute(addr, r[4]);
-    case 5: return __builtin_amdgcn_ds_bpermute(addr, r[5]);
-    default: return __builtin_amdgcn_ds_bpermute(addr, r[6]);
-  }
-}
-
 template <int C>
 __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p, const uint4* __restrict__ wimg) {
   using K = ConvCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (scalar tile loop / switch)
+  const int wave = tid >> 6;
   const int jrow = lane & 15;  // point within a 16-row group (B operand column)
   const int cgrp = lane >> 4;  // channel chunk of the k step (B operand k block) / channel group of the result
 
@@ -124,8 +106,7 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
   }
   __syncthreads();
 
-  // all gathers are BUFFER loads: an out-of-range offset returns zeros without touching memory and without a
-  // branch (a missing neighbour, index -1, wraps to an offset beyond the end of x)
+
   const __amdgpu_buffer_rsrc_t x_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.n * p.ldx * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t nbr_rsrc =
@@ -136,123 +117,118 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = (gridDim.x + 7 - xcd) >> 3;
   const int per = (p.tiles + 7) >> 3;
   const int t_end = min(p.tiles, (xcd + 1) * per);
-
-  // kernel-map registers of the CURRENT tile; the next tile's are requested as soon as the last entry has been handed
-  // out (their HBM latency - the map is streamed, it always misses the caches - hides behind the tail of this tile)
-  int idxr[K::RG][7];
-  auto request_idx = [&](int tile) {
+  for (int tile = xcd * per + bx; tile < t_end; tile += nbx) {
     const long row0 = (long)tile * K::ROWS_PER_BLOCK + wave * K::ROWS_PER_WAVE;
+    if (row0 >= p.n) continue;  // no barrier below: waves are independent
+    long myrow[K::RG];
+    bool rowok[K::RG];
+    unsigned idx_off[K::RG];
 #pragma unroll
     for (int g = 0; g < K::RG; ++g) {
-      long r = row0 + g * 16 + jrow;
-      if (r >= p.n) r = p.n - 1;  // rows past the end read the last row's map: computed, never stored
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int o = 4 * k + cgrp;
-        // offset 27 does not exist: out-of-range voffset -> 0, fixed up to -1 below
-        idxr[g][k] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, o < 27 ? (unsigned)(r * 4) : 0xfffffff0u,
-                                                          (o < 27 ? o : 0) * (int)(p.n * 4), 0);
-      }
+      myrow[g] = row0 + g * 16 + jrow;
+      rowok[g] = myrow[g] < p.n;
+      idx_off[g] = (unsigned)((rowok[g] ? myrow[g] : p.n - 1) * 4);
     }
-  };
-  int tile = xcd * per + bx;
-  if (tile < t_end) request_idx(tile);
-  for (; tile < t_end; tile += nbx) {
-    const long row0 = (long)tile * K::ROWS_PER_BLOCK + wave * K::ROWS_PER_WAVE;
-    const bool wave_has_rows = row0 < p.n;  // (no barrier below: waves are independent)
     f32x4_t acc[K::RG][K::CT];
 #pragma unroll
     for (int g = 0; g < K::RG; ++g)
 #pragma unroll
       for (int ct = 0; ct < K::CT; ++ct) acc[g][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // ---- which offsets does ANY of the wave's 32 rows have: 27-bit wave-uniform mask
-    unsigned live = 0;
-    if (cgrp == 3) {
+    // software pipeline over NS = 27 / G steps of G offsets, two buffer sets in ping-pong (static register names):
+    // while the MFMAs of step s run, the row loads of step s+1 and the index loads of step s+2 are in flight
+    constexpr int G = K::G, NS = 27 / G;
+    static_assert(NS * G == 27 && (NS & 1), "an odd number of steps: pairs + one tail step");
+    int idx[2][G][K::RG];
+    bf16x8_t xb[2][G][K::RG][K::KS];
+    // all gathers are BUFFER loads: an out-of-range offset returns zeros without touching memory and without a
+    // branch (a missing neighbour, index -1, wraps to an offset beyond the end of x)
+    auto load_idx = [&](int step, auto buf) {
+      constexpr int B = decltype(buf)::value;
 #pragma unroll
-      for (int g = 0; g < K::RG; ++g) idxr[g][6] = -1;  // "offset 27"
-    }
+      for (int q = 0; q < G; ++q)
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      bool any = false;
-#pragma unroll
-      for (int g = 0; g < K::RG; ++g) any |= idxr[g][k] >= 0;
-      const unsigned long long b = __builtin_amdgcn_ballot_w64(any);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if ((b >> (16 * q)) & 0xffffull) live |= 1u << (4 * k + q);
-    }
-    if (!wave_has_rows) live = 0;
-    if (p.dbg & 1) live &= ~0x5140145u & 0x7ffffffu;  // (timing experiment: corner offsets dropped)
-
-    // ---- ring of R single-offset slots: the row gathers of the next R-1 LIVE offsets are in flight behind the MFMAs
-    constexpr int R = K::RING;
-    bf16x8_t xb[R][K::RG][K::KS];
-    int slot_o[R];
-    auto pop = [&]() {  // next live offset or 27
-      const int o = live ? __builtin_ctz(live) : 27;
-      live &= live - 1;
-      return o;
+        for (int g = 0; g < K::RG; ++g)  // rows past the end read the last row's map: computed, never stored
+          idx[B][q][g] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, idx_off[g], (step * G + q) * (int)(p.n * 4), 0);
     };
-    auto issue = [&](int o, auto slot) {
-      constexpr int S = decltype(slot)::value;
-      slot_o[S] = o;
+    auto load_rows = [&](auto buf) {
+      constexpr int B = decltype(buf)::value;
 #pragma unroll
-      for (int g = 0; g < K::RG; ++g) {
-        unsigned src = (unsigned)idx_fetch(idxr[g], o, jrow);
-        if (p.dbg & 2) src = (int)src >= 0 ? (unsigned)(row0 + g * 16 + jrow) : src;
+      for (int q = 0; q < G; ++q)
 #pragma unroll
-        for (int ks = 0; ks < K::KS; ++ks) {
-          // -1 << row_shift wraps to the top of the 32-bit offset range: out of bounds -> zeros
-          const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
-          xb[S][g][ks] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
-        }
+        for (int g = 0; g < K::RG; ++g)
+#pragma unroll
+          for (int ks = 0; ks < K::KS; ++ks) {
+            // -1 << row_shift wraps to the top of the 32-bit offset range: out of bounds -> zeros
+            unsigned src = (unsigned)idx[B][q][g];
+            if (p.dbg & 2) src = idx[B][q][g] >= 0 ? (unsigned)myrow[g] : src;
+            const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
+            const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
+            xb[B][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
+          }
+    };
+    // which of the step's offsets does ANY of the wave's 32 rows have (wave-uniform bit mask)
+    auto live_mask = [&](auto buf) {
+      constexpr int B = decltype(buf)::value;
+      unsigned m = 0;
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < K::RG; ++g) any |= idx[B][q][g] >= 0;
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) m |= 1u << q;
+      }
+      return m;  // (dbg bit 1 is applied by the caller)
+    };
+    auto mfma_step = [&](int step, unsigned live, auto buf) {
+      constexpr int B = decltype(buf)::value;
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        if (!((live >> q) & 1u)) continue;  // wave-uniform: nobody in these 32 rows has this offset
+        const int slot = K::LDS_OFFSETS == 27 ? step * G + q : (int)c_slot_of_offset[step * G + q];
+        if ((p.dbg & 1) && c_slot_of_offset[step * G + q] >= 19) continue;
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < K::CT; ++ct) {
+            const int unit = ((slot * K::CT + ct) * K::KC + ks * 4 + cgrp) * 16 + jrow;
+            bf16x8_t wf;
+            if (K::LDS_OFFSETS == 27 || slot < K::LDS_OFFSETS)
+              wf = *reinterpret_cast<const bf16x8_t*>(smem + unit * 16);
+            else
+              wf = *reinterpret_cast<const bf16x8_t*>(wimg + unit);  // corner offset of the C = 64 kernel: L2
+#pragma unroll
+            for (int g = 0; g < K::RG; ++g)
+              acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[B][q][g][ks], acc[g][ct], 0, 0, 0);
+          }
       }
     };
-    auto compute = [&](auto slot) {
-      constexpr int S = decltype(slot)::value;
-      const int o = slot_o[S];
-      const int sl = K::LDS_OFFSETS == 27 ? o : (int)c_slot_of_offset[o];
-#pragma unroll
-      for (int ks = 0; ks < K::KS; ++ks)
-#pragma unroll
-        for (int ct = 0; ct < K::CT; ++ct) {
-          const int unit = ((sl * K::CT + ct) * K::KC + ks * 4 + cgrp) * 16 + jrow;
-          bf16x8_t wf;
-          if (K::LDS_OFFSETS == 27 || sl < K::LDS_OFFSETS)
-            wf = *reinterpret_cast<const bf16x8_t*>(smem + unit * 16);
-          else
-            wf = *reinterpret_cast<const bf16x8_t*>(wimg + unit);  // corner offset of the C = 64 kernel: L2
-#pragma unroll
-          for (int g = 0; g < K::RG; ++g)
-            acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[S][g][ks], acc[g][ct], 0, 0, 0);
-          if (K::CT > 2) asm volatile("" ::: "memory");  // C = 64: keep the 8 weight fragments from being loaded all at once
-        }
-    };
-    // prologue: R - 1 offsets in flight
-    [&]<int... I>(std::integer_sequence<int, I...>) {
-      (issue(pop(), std::integral_constant<int, I>{}), ...);
-    }(std::make_integer_sequence<int, R - 1>{});
-    bool done = false;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    load_idx(0, B0{});
+    load_idx(1, B1{});
+    load_rows(B0{});
 #pragma unroll 1
-    while (!done) {
-      [&]<int... I>(std::integer_sequence<int, I...>) {
-        ((done ? void() : [&] {
-           issue(pop(), std::integral_constant<int, (I + R - 1) % R>{});
-           if (slot_o[I] < 27) compute(std::integral_constant<int, I>{});
-           else done = true;  // offsets come out in order: the first empty slot ends the tile
-         }()), ...);
-      }(std::make_integer_sequence<int, R>{});
+    for (int step = 0; step + 1 < NS; step += 2) {
+      {
+        const unsigned live = live_mask(B0{});
+        load_rows(B1{});            // step + 1
+        load_idx(step + 2, B0{});   // step + 2 <= NS - 1 (its row addresses / live bits of `step` are consumed)
+        mfma_step(step, live, B0{});
+      }
+      {
+        const unsigned live = live_mask(B1{});
+        load_rows(B0{});            // step + 2
+        if (step + 3 < NS) load_idx(step + 3, B1{});
+        mfma_step(step + 1, live, B1{});
+      }
     }
-    // the map registers are free: request the next tile's
-    if (tile + nbx < t_end) request_idx(tile + nbx);
-
+    mfma_step(NS - 1, live_mask(B0{}), B0{});
     // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
 #pragma unroll
     for (int g = 0; g < K::RG; ++g) {
-      const long myrow = row0 + g * 16 + jrow;
-      if (myrow >= p.n) continue;
-      bf16_t* dst = p.y + myrow * p.ldy + cgrp * (C / 4);
+      if (!rowok[g]) continue;
+      bf16_t* dst = p.y + myrow[g] * p.ldy + cgrp * (C / 4);
 #pragma unroll
       for (int h = 0; h < K::CT / 2; ++h) {
         // the lane's channels cgrp * C/4 + 8h .. + 7 are consecutive: bias as two float4 (L1-resident)

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void row_finish_kernel(GemmP g) {
 // BM: rows per tile = 64 (4 waves) or 128 (8 waves); a wave always owns 32 rows x BN/2 columns.  The 128-row form
 // moves a third less A + W through L2 -> LDS per FLOP (the deep-stage linears are bound by that path, ~5 TB/s).
 template <typename CT, int BN, int NCH, bool GATHER, int BM = 64>
-__global__ __launch_bounds__(4 * BM, BM == 128 ? 4 : 1) void gemm_kernel(GemmP g) {
+__global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g) {
   constexpr int NT = 4 * BM;   // threads
   constexpr int TN = BN / 32;  // 16-wide column tiles per wave
   constexpr int RB = NCH * 16;
@@ -599,8 +599,12 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   // bound by (stage-0 conv of a 4-scene batch 196 -> 123 us, +2 % end to end).  The same tiles for the wide deep-stage
   // linears were neutral (-1 %) and are not instantiated.
   static const int conv_bm = env_int("CDSEG_CONV_BM", 128);
-  const bool tall = GATHER && NCH == 16 && conv_bm == 128 && p.M > 64 && !ln;
-  const int bm = tall ? 128 : 64;
+  const bool tall = GATHER && NCH == 16 && conv_bm >= 128 && p.M > 64 && !ln;
+  // deep stages (C >= 256: few rows, 3.5 - 14 MB of weights per conv): 256-row tiles, 16 waves - per K step the block
+  // moves 64 KB of A + 32 KB of W for 2048 MFMA cycles instead of 32 + 32 KB for 1024
+  static const int deep_bm = env_int("CDSEG_CONV_DEEP_BM", 256);
+  const bool deep = tall && sizeof(CT) == 2 && deep_bm == 256 && p.N >= 256 && p.M >= 512;
+  const int bm = deep ? 256 : (tall ? 128 : 64);
   const int gm = (int)((p.M + bm - 1) / bm);
   // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
   const int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
@@ -644,8 +648,22 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   else nblk = (unsigned)gm * (unsigned)slices;
   const dim3 grid(nblk);
   bool launched = false;
+  if constexpr (GATHER && NCH == 16 && sizeof(CT) == 2) {
+    if (deep) {
+      launched = true;
+      constexpr int smem = gemm_smem_bytes<CT, 128, 16, 256>();  // 97 KB: 1 block / CU, 4 waves / SIMD
+      static bool attr_done256 = false;
+      if (!attr_done256) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<CT, 128, 16, GATHER, 256>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+          return CDSEG_ERR_LAUNCH;
+        attr_done256 = true;
+      }
+      hipLaunchKernelGGL((gemm_kernel<CT, 128, 16, GATHER, 256>), grid, dim3(1024), smem, s, p);
+    }
+  }
   if constexpr (GATHER && NCH == 16) {
-    if (tall) {
+    if (tall && !launched) {
       launched = true;
       if (bn == 32) {
         hipLaunchKernelGGL((gemm_kernel<CT, 32, 16, GATHER, 128>), grid, dim3(512), 0, s, p);

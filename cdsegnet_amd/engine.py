@@ -90,6 +90,13 @@ class Level:
             return ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
         return _shared(self._nbr, (ksize, kmajor), build)
 
+    def child_info(self):
+        """Per parent cell of this level's points: first child row + octant occupancy (the stem kernel's traversal)."""
+        def build():
+            par, (_, seg) = self.parent
+            return ops.child_info(self.code4[0], seg, par.n)
+        return _shared(self._nbr, "child_info", build)
+
     def pad_host(self, patch_size, enable_flash):
         """Host side of the padding plan (ref: ptv3.py:188-250): K, offs, offs_pad, patch_start (int32 arrays)."""
         counts = np.diff(np.asarray(self.offs_host, dtype=np.int64))
@@ -229,6 +236,8 @@ class Engine:
             wp[:, :, :cin] = cw.reshape(cout, -1, cin).float().cpu()
             w[pre + ".w"] = wp.reshape(cout, -1).to(device=device, dtype=T).contiguous()
             w[pre + ".cpad"] = cpad
+            if cw.shape[1] == 5 and cpad == 8 and hasattr(ops, "stem5_pack") and ops.stem5_ok(cout, T):
+                w[pre + ".wimg"] = ops.stem5_pack(w[pre + ".w"])  # LDS image of the map-free stem kernel (csrc/stem.hip)
             bn(mod.stem.norm, pre + ".bn")
 
         def pool(mod, pre):
@@ -568,8 +577,14 @@ class Engine:
         a = ops.gather_pad_cast(feat, perm, w[pre + ".cpad"], self.T)
         x = self._buf(lv.n, cout, torch.float32)
         xc = x if self.T == torch.float32 else self._buf(lv.n, cout, self.T)
-        ops.gemm(a, w[pre + ".w"], x, scale=w[pre + ".bn.scale"], shift=w[pre + ".bn.shift"], act=ops.ACT_GELU,
-                 nbr=lv.nbr(5, True), nbr_kmajor=True, kvol=125, out2=None if xc is x else xc)
+        if (pre + ".wimg") in w and lv.parent is not None and lv.n < (1 << 24):
+            # bf16 stems: neighbours enumerated through the parent level, no 125-offset kernel map (csrc/stem.hip)
+            par, (cluster, seg) = lv.parent
+            ops.stem5(a, w[pre + ".wimg"], w[pre + ".bn.scale"], w[pre + ".bn.shift"], lv.grid, cluster, par.nbr(3, True),
+                      lv.child_info(), lv.depth, x, None if xc is x else xc)
+        else:
+            ops.gemm(a, w[pre + ".w"], x, scale=w[pre + ".bn.scale"], shift=w[pre + ".bn.shift"], act=ops.ACT_GELU,
+                     nbr=lv.nbr(5, True), nbr_kmajor=True, kvol=125, out2=None if xc is x else xc)
         return State(lv, x, xc, curves)
 
     def run_pooling(self, plan, st, pre, cum_to, perm):

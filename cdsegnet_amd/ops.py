@@ -552,6 +552,37 @@ def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start
     check(_lib.load().cdseg_block_forward(desc[1], ref, _stream()), "block_forward")
 
 
+def stem5_ok(cout, dtype):
+    """The map-free stem kernel (csrc/stem.hip) covers the shipped stems: 32 output channels, bf16."""
+    return os.environ.get("CDSEG_STEM5", "1") != "0" and cout == 32 and dtype == torch.bfloat16
+
+
+def child_info(zcode_sorted, seg_start, m):
+    """Per parent cell: (first child row << 8) | octant occupancy (children of a cell are contiguous in z-order)."""
+    _need_gpu(zcode_sorted, seg_start)
+    info = torch.empty(int(m), dtype=torch.int64, device=zcode_sorted.device)
+    check(_lib.load().cdseg_child_info(_ptr(zcode_sorted), _ptr(seg_start), int(m), _ptr(info), _stream()), "child_info")
+    return info
+
+
+def stem5_pack(w):
+    """(32, 125 * 8) bf16 stem weight -> LDS image of the stem kernel (built once per weight)."""
+    _need_gpu(w)
+    assert w.dtype == torch.bfloat16 and tuple(w.shape) == (32, 1000)
+    img = torch.empty(_lib.load().cdseg_stem5_wimg_bytes(), dtype=torch.uint8, device=w.device)
+    check(_lib.load().cdseg_stem5_pack(_ptr(w), _ptr(img), _stream()), "stem5_pack")
+    return img
+
+
+def stem5(x8, wimg, scale, shift, grid, cluster, parent_nbr3, cinfo, depth, out, out2=None):
+    """out (n, 32) fp32 [, out2 bf16] = GELU(BN(SubMConv3d_k5(x8))) without a 125-offset kernel map (ref: ptv3.py:633-663)."""
+    _need_gpu(x8, wimg, grid, cluster, parent_nbr3, cinfo, out)
+    n, m = x8.shape[0], cinfo.numel()
+    check(_lib.load().cdseg_stem5(_ptr(x8), _ptr(wimg), _ptr(scale), _ptr(shift), _ptr(grid), _ptr(cluster),
+                                  _ptr(parent_nbr3), _ptr(cinfo), n, m, int(depth), _ptr(out), _ptr(out2), _stream()), "stem5")
+    return out
+
+
 def subm_conv3_ok(x):
     """The weight-stationary register-gather conv (csrc/conv.hip) covers the wide bf16 stages: C = 32 / 64."""
     on = os.environ.get("CDSEG_CONV_RG", "1") != "0"

@@ -316,6 +316,20 @@ int cdseg_subm_conv3_pack(const void* w, int channels, void* wimg, void* stream)
 int cdseg_subm_conv3(const void* x, int ldx, const void* wimg, const float* bias, const int32_t* nbr_kmajor, long n,
                      int channels, void* y, int ldy, void* stream);
 
+/* ------------------------------------------------------------------ stem (k = 5) without a materialised kernel map
+ * ref: ptv3.py:633-663 (Embedding: SubMConv3d(c_in -> 32, k = 5, bias = False) + BatchNorm1d(eps 1e-3) + GELU).
+ * The <= 125 neighbours of a point are enumerated through the next coarser level (27 parent cells x <= 8 children);
+ * bf16 operands, fp32 accumulation (csrc/stem.hip).  x8 (n, 8) bf16 rows in physical order (channels zero-padded),
+ * wimg = cdseg_stem5_pack image of the (32, 125 * 8) bf16 weight, scale / shift = folded BatchNorm, grid (n, 3),
+ * cluster (n) parent of every point, parent_nbr3 (27, m) offset-major 3x3x3 map of the parent level,
+ * child_info (m) from cdseg_child_info(fine z-codes, children runs).  out (n, 32) fp32, out2 (n, 32) bf16 or NULL. */
+int cdseg_child_info(const int64_t* zcode_sorted, const int32_t* seg_start, long m, int64_t* info, void* stream);
+size_t cdseg_stem5_wimg_bytes(void);
+int cdseg_stem5_pack(const void* w, void* wimg, void* stream);
+int cdseg_stem5(const void* x8, const void* wimg, const float* scale, const float* shift, const int32_t* grid,
+                const int32_t* cluster, const int32_t* parent_nbr3, const int64_t* child_info, long n, long m, int depth,
+                float* out, void* out2, void* stream);
+
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
  * block itself, carving its temporaries from the caller's scratch buffer: sparse-conv CPE, then for bf16 with

@@ -199,6 +199,53 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     return out
 
 
+def stem5_ok(cout, dtype):
+    return cout == 32 and dtype == torch.bfloat16
+
+
+def child_info(zs, seg, m):
+    zs, seg = zs.long(), seg.long()
+    info = torch.zeros(int(m), dtype=torch.int64)
+    for p in range(int(m)):
+        occ = 0
+        for j in range(int(seg[p]), int(seg[p + 1])):
+            occ |= 1 << int(zs[j] & 7)
+        info[p] = (int(seg[p]) << 8) | occ
+    return info
+
+
+def stem5_pack(w):
+    return w
+
+
+def stem5(x8, wimg, scale, shift, grid, cluster, parent_nbr3, cinfo, depth, out, out2=None):
+    """Emulation through the explicit 5x5x5 map (what the device kernel avoids building)."""
+    g = grid.long()
+    key = {tuple(v): i for i, v in enumerate(g.tolist())}  # one batch element per call in the CPU tests, or disjoint grids
+    n = g.shape[0]
+    nbr = torch.full((n, 125), -1, dtype=torch.int64)
+    # batches: neighbours must share the batch element; recover it from the parent chain (cluster -> same parent map)
+    first = (cinfo >> 8)
+    par_of = cluster.long()
+    pn = parent_nbr3.long()
+    for i in range(n):
+        for cell in range(27):
+            q = int(pn[cell, par_of[i]])
+            if q < 0:
+                continue
+            s, occ = int(first[q]), int(cinfo[q] & 255)
+            rank = 0
+            for octv in range(8):
+                if not (occ >> octv) & 1:
+                    continue
+                j = s + rank
+                rank += 1
+                d = g[j] - g[i]
+                if int(d.abs().max()) <= 2:
+                    nbr[i, int((d[0] + 2) * 25 + (d[1] + 2) * 5 + (d[2] + 2))] = j
+    return gemm(x8, wimg, out, scale=scale, shift=shift, act=ACT_GELU, nbr=nbr, kvol=125, out2=out2)
+
+
 def subm_conv3_ok(x):
     return x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (32, 64)
 

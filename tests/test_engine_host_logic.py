@@ -244,3 +244,35 @@ def test_tta_pipeline_host_logic_vs_reference_fixture(monkeypatch):
         assert np.array_equal(feat, fx[f"aug{a}_feat"]), a
         pos += k
     assert pos == len(dicts)
+
+
+def test_engine_stem5_branch_wiring(emulated):
+    """bf16 full-width model on the emulated op layer: the map-free stem branch (child_info, cluster / parent-map wiring
+    in Engine.run_embedding) gives what the gathered-GEMM stem gives (both emulated; same bf16 operands)."""
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    cfg = configs.cdsegnet_config("scannet")
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=3))
+    model.eval()
+    model.precision = "bf16"
+    sc = synth.collate([synth.room_scene(5, 700), synth.room_scene(6, 500)])
+    inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")}
+    draws = dict(noise=torch.randn(len(sc["coord"]), 6), perms=[np.arange(4) for _ in range(8)])
+    eng = model.engine()
+    calls = []
+    real = emu_ops.stem5
+    emu_ops.stem5 = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        a = model.inference(dict(inp), eval=False, draws=dict(draws))["seg_logits"].clone()
+    finally:
+        emu_ops.stem5 = real
+    assert len(calls) == 2  # both branches' stems went through the new path
+    keep = emu_ops.stem5_ok
+    emu_ops.stem5_ok = lambda cout, dtype: False
+    try:
+        model._drop_engine()
+        b = model.inference(dict(inp), eval=False, draws=dict(draws))["seg_logits"]
+    finally:
+        emu_ops.stem5_ok = keep
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-3

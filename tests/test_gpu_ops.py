@@ -205,7 +205,8 @@ def test_gemm_epilogue_bn_gather_add_scatter(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("name,C", [("room1500", 32), ("batch2", 64), ("lidar5000", 16), ("room1500", 128)])
+@pytest.mark.parametrize("name,C", [("room1500", 32), ("batch2", 64), ("lidar5000", 16), ("room1500", 128),
+                                    ("room1500", 256), ("lidar8", 512)])  # C >= 256: the 256-row deep-stage tiles
 def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
     fx = load_fixture(f"serialization_{name}.npz")
     zs, perm0, g0, b0, depth, p = _physical(ops, fx)
@@ -398,6 +399,43 @@ def test_stem_as_gathered_gemm_vs_oracle(ops, dtype, name, cin, cout):
     err = (out.cpu() - ref).abs().max().item()
     report(f"stem gemm {dtype} {name}", max_err=err)
     assert err < 1e-4
+
+
+@pytest.mark.parametrize("name,cin", [("room1500", 6), ("lidar5000", 4), ("batch2", 6), ("lidar8", 4), ("rand16", 6), ("tiny64", 6)])
+def test_stem5_map_free_vs_oracle(ops, name, cin):
+    """csrc/stem.hip: the k = 5 stem WITHOUT a 125-offset kernel map (neighbours enumerated through the parent level's
+    3x3x3 map + per-parent octant masks), bf16 operands / fp32 accumulation, folded BN + GELU, against (a) the oracle's
+    subm_conv3d on the explicit 5x5x5 map with the same bf16-rounded operands and (b) the gathered-A GEMM path it
+    replaces.  Batches of 2 / 3 / 8 clouds: neighbours never cross batch elements (the parent map is per element)."""
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    cluster, seg, cnt = ops.pool_level(zs, 3)
+    m = int(cnt.item())
+    code4 = ops.encode4(g0, b0, depth)
+    g1, b1, c41 = ops.pool_gather(seg, m, n, 1, g0, b0, code4)
+    pn3 = ops.nbr_table(c41[0].contiguous(), g1, b1, depth - 1, 3, True)
+    cinfo = ops.child_info(zs, seg, m)
+    nbr5 = ops.nbr_table(zs, g0, b0, depth, 5)
+    g = torch.Generator().manual_seed(cin + n)
+    x = _bf16_round(torch.randn(n, cin, generator=g))  # caller order
+    w = _bf16_round(torch.randn(32, 5, 5, 5, cin, generator=g) / (125 * cin) ** 0.5)
+    sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    xp = x[torch.from_numpy(p)]
+    ref = F.gelu(OM.subm_conv3d(xp, nbr5.cpu().numpy().astype(np.int64), w, None) * sc + sh)
+    a = ops.gather_pad_cast(dev(x), perm0, 8, torch.bfloat16)
+    wp = torch.zeros(32, 125, 8)
+    wp[:, :, :cin] = w.reshape(32, 125, cin)
+    wd = dev(wp.reshape(32, -1), torch.bfloat16)
+    out = torch.full((n, 32), float("nan"), dtype=torch.float32, device="cuda")
+    out2 = torch.empty(n, 32, dtype=torch.bfloat16, device="cuda")
+    ops.stem5(a, ops.stem5_pack(wd), dev(sc), dev(sh), g0, cluster, pn3, cinfo, depth, out, out2)
+    old = torch.empty(n, 32, dtype=torch.float32, device="cuda")
+    ops.gemm(a, wd, old, scale=dev(sc), shift=dev(sh), act=ops.ACT_GELU, nbr=nbr5, kvol=125)
+    err = (out.cpu() - ref).abs().max().item()
+    report(f"stem5 {name}", max_err=err, vs_gathered_gemm=(out - old).abs().max().item())
+    assert err < 1e-4
+    assert (out2.float() - out).abs().max().item() < 0.02 * (1 + out.abs().max().item())
 
 
 # ------------------------------------------------------------------ LayerNorm / pooling reduce / small ops
