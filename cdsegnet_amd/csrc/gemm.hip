@@ -305,6 +305,72 @@ __global__ __launch_bounds__(256) void row_finish_kernel(GemmP g) {
   finish_row<2>(g, m, true, lane, 64, groups, 0, v);
 }
 
+// ---- accumulators -> LDS C tile -> fused epilogue, 64 rows at a time (shared by both main loops).
+// Wave (wm, wn) owns rows wm * 32 .. + 32, columns wn * BN/2 .. of the BM x BN tile; smem is free for reuse.
+template <int BN, int BM>
+__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[2][BN / 32], char* smem, int tid, int lane,
+                                              int wm, int wn, long m0, int n0, int zs) {
+  constexpr int NT = 4 * BM;
+  constexpr int TN = BN / 32;
+  constexpr int CLD = BN + 4;
+  const int fr = lane & 15, fg = lane >> 4;
+  // ---- accumulators -> LDS C tile -> epilogue, 64 rows at a time.  MFMA C layout: col = lane & 15,
+  // row = (lane >> 4) * 4 + r
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+  for (int hh = 0; hh < BM / 64; ++hh) {
+    if (hh) __syncthreads();  // the previous 64 rows have left the C tile
+    int zcol = 0;  // opaque zero in the column index: keeps the per-column epilogue vectors from being hoisted out of
+    if constexpr (BM > 64) asm volatile("v_mov_b32 %0, 0" : "=v"(zcol));  // the loop (and into 100+ extra VGPRs)
+    if ((wm >> 1) == hh) {
+      const int rbase = (wm & 1) * 32;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Cs[(rbase + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    const long mb = m0 + 64 * hh;
+    constexpr int GPR = BN / 4;  // float4 groups per row
+    if (g.fix) {
+      // raw partial tile -> workspace; a second launch sums the splits and runs the (row) epilogue
+      for (int item = tid; item < 64 * GPR; item += NT) {
+        const int row = item / GPR, cg = item % GPR;
+        const long m = mb + row;
+        const int n = n0 + 4 * cg;
+        if (m >= g.M || n >= g.N) continue;
+        *reinterpret_cast<float4*>(g.ws + ((long)zs * g.M + m) * g.N + n) =
+            *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
+      }
+    } else if (BM == 64 && (g.ln_pre_g || g.ln_post_g)) {
+      // fused LayerNorm (64-row launches only): the block holds complete rows; 4 lanes own one row, values stay
+      // in registers
+      constexpr int MAXG = BN / 16;
+      const int row = (tid >> 2) & 63, part = tid & 3;
+      const long m = mb + row;
+      const int ng = g.N >> 2;
+      float4 v[MAXG];
+#pragma unroll
+      for (int i = 0; i < MAXG; ++i)
+        v[i] = (part + 4 * i < ng) ? *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * (part + 4 * i))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      finish_row<MAXG>(g, m, m < g.M, part, 4, ng, 0, v);
+    } else {
+      // epilogue on row-contiguous groups of 4 columns
+      for (int item = tid; item < 64 * GPR; item += NT) {
+        const int row = item / GPR, cg = item % GPR;
+        const long m = mb + row;
+        const int n = n0 + 4 * cg + zcol;
+        if (m >= g.M || n >= g.N) continue;
+        epilogue4(g, m, n, *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg));
+      }
+    }
+  }
+}
+
 // CT: compute/storage type of A and W.  BN: tile width.  NCH: 16-byte chunks per LDS row.
 // BM: rows per tile = 64 (4 waves) or 128 (8 waves); a wave always owns 32 rows x BN/2 columns.  The 128-row form
 // moves a third less A + W through L2 -> LDS per FLOP (the deep-stage linears are bound by that path, ~5 TB/s).
@@ -516,61 +582,216 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
     __syncthreads();
   }
 
-  // ---- accumulators -> LDS C tile -> epilogue, 64 rows at a time.  MFMA C layout: col = lane & 15,
-  // row = (lane >> 4) * 4 + r
-  float* Cs = reinterpret_cast<float*>(smem);
+  tile_epilogue<BN, BM>(g, acc, smem, tid, lane, wm, wn, m0, n0, zs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 main loop on LDS-DMA (global_load_lds_dwordx4): BM x 128 tile, K steps of 64, TWO LDS stages, ONE barrier per
+// step.  The register-staged loop above waits for its global loads, writes them to LDS and barriers twice per step: on
+// the deep stages (C >= 128: few rows, long reductions, a dependent index -> row chain per step of the sparse convs)
+// that left the matrix pipe at ~10 %.  Here the tile of step k+1 is in flight - straight into LDS, no staging
+// registers - while the MFMAs of step k run:
+//     wait (own DMA of step k landed) -> barrier -> issue DMA of step k+1 -> ds_read + MFMA of step k
+//   * the barrier both publishes every wave's DMA of step k and certifies that all waves are done READING the other
+//     stage (which the DMA issued right after it overwrites);
+//   * an LDS-DMA instruction writes 64 lanes x 16 B linearly; the XOR swizzle that keeps the fragment reads conflict
+//     free is applied to the per-lane SOURCE address instead (lane (row, slot) fetches chunk slot ^ ((row >> 1) & 7));
+//   * sparse convs: the tile's kernel-map entries (BM rows x live offsets) sit in LDS, a missing neighbour reads a
+//     zero page - the index lookups are LDS reads one step ahead, not global loads in the dependency chain;
+//   * the DMA is issued from inline asm (M0 = LDS base in the same statement) and waited for with counted s_waitcnt:
+//     hipcc drains vmcnt(0) around compiler-visible LDS-DMA, and no other VMEM instruction lives in the loop.
+__device__ uint4 g_zero_page[8];  // 128 zero bytes: the source of a missing neighbour's row chunk
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int BM>
+struct DmaCfg {
+  static constexpr int WAVES = BM / 16, NT = WAVES * 64, BN = 128, BK = 64;
+  static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+  static constexpr int A_PW = (BM / 8) / WAVES, W_PW = (BN / 8) / WAVES;  // DMA instructions per wave and step (2, 16 / WAVES)
+  static constexpr int STAGES = 2 * (A_BYTES + W_BYTES);
+  static constexpr int ITAB = BM * 27 * 4;
+  static constexpr int LDS = STAGES + ITAB + 1024;
+};
+
+template <int BM, bool GATHER>
+__global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
+  using D = DmaCfg<BM>;
+  constexpr int BN = 128, TN = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tail = smem + D::STAGES + D::ITAB;
+  int* live = reinterpret_cast<int*>(tail);  // [0] = count, [1..] = live offsets
+  unsigned long long* smask = reinterpret_cast<unsigned long long*>(tail + 640);
+  int* itab = reinterpret_cast<int*>(smem + D::STAGES);  // [row][live slot]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, sl;
+  {
+    const int bid = blockIdx.x, slices = g.gn * g.splits;
+    if (g.xmode == 1) {
+      const int j = bid >> 3;
+      mt = j % g.gm;
+      sl = (bid & 7) + 8 * (j / g.gm);
+      if (sl >= slices) return;
+    } else if (g.xmode == 2) {
+      const int j = bid >> 3, chunk = (g.gm + 7) >> 3;
+      mt = (bid & 7) * chunk + j / slices;
+      sl = j % slices;
+      if (j / slices >= chunk || mt >= g.gm) return;
+    } else {
+      mt = bid % g.gm;
+      sl = bid / g.gm;
+    }
+  }
+  const int nt = sl % g.gn, zs = sl / g.gn;
+  const long m0 = (long)mt * BM;
+  const int n0 = nt * BN;
+  const long Kw = (long)g.kvol * g.K;
+
+  int nlive = 1;
+  if (GATHER) {
+    if (tid < 2) smask[tid] = 0ull;
+    __syncthreads();
+    for (int r = tid >> 2; r < BM; r += D::NT / 4) {
+      const long m = m0 + r;
+      if (m < g.M) {
+        unsigned long long lo = 0ull;
+        for (int o = tid & 3; o < g.kvol; o += 4)
+          if (g.nbr[m * g.nbr_sm + (long)o * g.nbr_so] >= 0) lo |= 1ull << o;
+        if (lo) atomicOr(&smask[0], lo);
+      }
+    }
+    __syncthreads();
+    if (tid < g.kvol) {
+      const unsigned long long mk = smask[0];
+      if ((mk >> tid) & 1ull) live[1 + __popcll(mk & ((1ull << tid) - 1ull))] = tid;
+      if (tid == 0) live[0] = __popcll(mk);
+    }
+    __syncthreads();
+    nlive = __builtin_amdgcn_readfirstlane(live[0]);
+    for (int e = tid; e < BM * nlive; e += D::NT) {
+      const int r = e / nlive, jl = e - r * nlive;
+      const long m = m0 + r;
+      itab[r * 27 + jl] = m < g.M ? g.nbr[m * g.nbr_sm + (long)live[1 + jl] * g.nbr_so] : -1;
+    }
+    __syncthreads();
+  }
+  const int KV = nlive * g.K;
+  const int nkc = KV / D::BK;  // K % 64 == 0 (launch condition)
+  const int kshift = g.kshift;
+  const int kc0 = (int)(((long)nkc * zs) / g.splits);
+  const int kc1 = (int)(((long)nkc * (zs + 1)) / g.splits);
+
+  // ---- per-lane DMA geometry (fixed for the whole tile)
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16_t* a_src[D::A_PW];   // plain: row base pointers
+  int a_row[D::A_PW];             // gather: tile row (index into itab)
+  int a_chunk[D::A_PW];
+  const bf16_t* w_src[D::W_PW];
+  int w_chunk[D::W_PW];
+#pragma unroll
+  for (int i = 0; i < D::A_PW; ++i) {
+    const int r = (wave * D::A_PW + i) * 8 + lrow;
+    a_row[i] = r;
+    a_chunk[i] = slot ^ ((r >> 1) & 7);
+    long m = m0 + r;
+    if (m >= g.M) m = g.M - 1;  // rows past the end: computed, never stored
+    a_src[i] = (const bf16_t*)g.A + m * g.lda + a_chunk[i] * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < D::W_PW; ++i) {
+    const int r = (wave * D::W_PW + i) * 8 + lrow;
+    w_chunk[i] = slot ^ ((r >> 1) & 7);
+    int n = n0 + r;
+    if (n >= g.N) n = g.N - 1;
+    w_src[i] = (const bf16_t*)g.W + (long)n * Kw + w_chunk[i] * 8;
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto a_stage = [&](int st) { return lds_base + st * D::A_BYTES; };
+  auto w_stage = [&](int st) { return lds_base + 2 * D::A_BYTES + st * D::W_BYTES; };
+
+  // gather indices of the step to be issued next (LDS reads, one step ahead of their DMA)
+  int idx_n[D::A_PW];
+  auto fetch_idx = [&](int kc) {
+    if (GATHER) {
+      const int jl = (kc * D::BK) >> kshift;
+#pragma unroll
+      for (int i = 0; i < D::A_PW; ++i) idx_n[i] = itab[a_row[i] * 27 + jl];
+    }
+  };
+  auto issue = [&](int kc, int st) {
+    const int kv = kc * D::BK;
+    int cc = kv, wcol = kv;
+    if (GATHER) {
+      const int jl = kv >> kshift;
+      cc = kv - (jl << kshift);
+      wcol = live[1 + jl] * g.K + cc;
+    }
+#pragma unroll
+    for (int i = 0; i < D::A_PW; ++i) {
+      const void* src;
+      if (GATHER) {
+        const int sidx = idx_n[i];
+        src = sidx >= 0 ? (const void*)((const bf16_t*)g.A + (long)sidx * g.lda + cc + a_chunk[i] * 8)
+                        : (const void*)((const char*)g_zero_page + slot * 16);
+      } else {
+        src = a_src[i] + cc;
+      }
+      dma16(src, a_stage(st) + (wave * D::A_PW + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < D::W_PW; ++i) dma16(w_src[i] + wcol, w_stage(st) + (wave * D::W_PW + i) * 1024);
+  };
+
+  f32x4_t acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+
+  if (kc0 < kc1) {
+    fetch_idx(kc0);
+    issue(kc0, 0);
+    if (kc0 + 1 < kc1) fetch_idx(kc0 + 1);
+  }
 #pragma unroll 1
-  for (int hh = 0; hh < BM / 64; ++hh) {
-    if (hh) __syncthreads();  // the previous 64 rows have left the C tile
-    int zcol = 0;  // opaque zero in the column index: keeps the per-column epilogue vectors from being hoisted out of
-    if constexpr (BM > 64) asm volatile("v_mov_b32 %0, 0" : "=v"(zcol));  // the loop (and into 100+ extra VGPRs)
-    if ((wm >> 1) == hh) {
-      const int rbase = (wm & 1) * 32;
+  for (int kc = kc0; kc < kc1; ++kc) {
+    const int st = (kc - kc0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of step kc (the only VMEM in flight) has landed
+    __builtin_amdgcn_s_barrier();                     // ... everybody's has, and nobody still reads the other stage
+    if (kc + 1 < kc1) {
+      issue(kc + 1, st ^ 1);
+      if (kc + 2 < kc1) fetch_idx(kc + 2);
+    }
+    const char* As = smem + st * D::A_BYTES;
+    const char* Bs = smem + 2 * D::A_BYTES + st * D::W_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t a[2], b[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off<8>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<8>(wn * 64 + j * 16 + fr, 4 * kk + fg));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            Cs[(rbase + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
-    }
-    __syncthreads();
-    const long mb = m0 + 64 * hh;
-    constexpr int GPR = BN / 4;  // float4 groups per row
-    if (g.fix) {
-      // raw partial tile -> workspace; a second launch sums the splits and runs the (row) epilogue
-      for (int item = tid; item < 64 * GPR; item += NT) {
-        const int row = item / GPR, cg = item % GPR;
-        const long m = mb + row;
-        const int n = n0 + 4 * cg;
-        if (m >= g.M || n >= g.N) continue;
-        *reinterpret_cast<float4*>(g.ws + ((long)zs * g.M + m) * g.N + n) =
-            *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
-      }
-    } else if (BM == 64 && (g.ln_pre_g || g.ln_post_g)) {
-      // fused LayerNorm (64-row launches only): the block holds complete rows; 4 lanes own one row, values stay
-      // in registers
-      constexpr int MAXG = BN / 16;
-      const int row = (tid >> 2) & 63, part = tid & 3;
-      const long m = mb + row;
-      const int ng = g.N >> 2;
-      float4 v[MAXG];
-#pragma unroll
-      for (int i = 0; i < MAXG; ++i)
-        v[i] = (part + 4 * i < ng) ? *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * (part + 4 * i))
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      finish_row<MAXG>(g, m, m < g.M, part, 4, ng, 0, v);
-    } else {
-      // epilogue on row-contiguous groups of 4 columns
-      for (int item = tid; item < 64 * GPR; item += NT) {
-        const int row = item / GPR, cg = item % GPR;
-        const long m = mb + row;
-        const int n = n0 + 4 * cg + zcol;
-        if (m >= g.M || n >= g.N) continue;
-        epilogue4(g, m, n, *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg));
-      }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
+  __syncthreads();  // all fragment reads done: the stages become the C tile
+  tile_epilogue<BN, BM>(g, acc, smem, tid, lane, wm, wn, m0, n0, zs);
 }
 
 template <typename CT, int BN, int NCH, int BM>
@@ -604,7 +825,18 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   // moves 64 KB of A + 32 KB of W for 2048 MFMA cycles instead of 32 + 32 KB for 1024
   static const int deep_bm = env_int("CDSEG_CONV_DEEP_BM", 256);
   const bool deep = tall && sizeof(CT) == 2 && deep_bm == 256 && p.N >= 256 && p.M >= 512;
-  const int bm = deep ? 256 : (tall ? 128 : 64);
+  int bm = deep ? 256 : (tall ? 128 : 64);
+  // LDS-DMA main loop (bf16, K % 64 == 0, N > 64): 128-row tiles for plain linears too (CDSEG_GEMM_DMA_BM overrides)
+  int dma_use_bm = -1;
+  if constexpr (NCH == 16 && sizeof(CT) == 2) {
+    static const int dma_on0 = env_int("CDSEG_GEMM_DMA", 1);
+    static const int dma_bm0 = env_int("CDSEG_GEMM_DMA_BM", 0);
+    if (dma_on0 && p.N > 64 && (p.K % 64) == 0 && (!GATHER || (p.kshift >= 6 && p.kvol <= 27)) && p.M >= 128) {
+      int want = dma_bm0 ? dma_bm0 : ((GATHER || p.M >= 16384) ? 128 : 64);
+      if (ln && p.N <= 128) want = -1;  // complete rows in one block: the fused-LayerNorm epilogue lives in the 64-row loop
+      if (want > 0) bm = dma_use_bm = want;
+    }
+  }
   const int gm = (int)((p.M + bm - 1) / bm);
   // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
   const int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
@@ -648,8 +880,47 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   else nblk = (unsigned)gm * (unsigned)slices;
   const dim3 grid(nblk);
   bool launched = false;
+  // bf16, K a multiple of 64, wide outputs: the LDS-DMA pipelined main loop
+  if constexpr (NCH == 16 && sizeof(CT) == 2) {
+    static const int dma_on = env_int("CDSEG_GEMM_DMA", 1);
+    static const int dma_bm = env_int("CDSEG_GEMM_DMA_BM", 0);
+    const bool fused_ln_here = ln && gn == 1 && splits == 1;  // complete rows in one 64-row block: stays on the old loop
+    if (dma_on && bn == 128 && (p.K % 64) == 0 && (!GATHER || (p.kshift >= 6 && p.kvol <= 27)) && !fused_ln_here &&
+        p.M >= 128 && dma_use_bm == bm) {
+      launched = true;
+      (void)dma_bm;
+      if (bm == 256) {
+        static bool a256 = false;
+        if (!a256) {
+          if (hipFuncSetAttribute((const void*)gemm_dma_kernel<256, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  DmaCfg<256>::LDS) != hipSuccess)
+            return CDSEG_ERR_LAUNCH;
+          a256 = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<256, GATHER>), grid, dim3(1024), DmaCfg<256>::LDS, s, p);
+      } else if (bm == 128) {
+        static bool a128 = false;
+        if (!a128) {
+          if (hipFuncSetAttribute((const void*)gemm_dma_kernel<128, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  DmaCfg<128>::LDS) != hipSuccess)
+            return CDSEG_ERR_LAUNCH;
+          a128 = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<128, GATHER>), grid, dim3(512), DmaCfg<128>::LDS, s, p);
+      } else {
+        static bool a64 = false;
+        if (!a64) {
+          if (hipFuncSetAttribute((const void*)gemm_dma_kernel<64, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  DmaCfg<64>::LDS) != hipSuccess)
+            return CDSEG_ERR_LAUNCH;
+          a64 = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<64, GATHER>), grid, dim3(256), DmaCfg<64>::LDS, s, p);
+      }
+    }
+  }
   if constexpr (GATHER && NCH == 16 && sizeof(CT) == 2) {
-    if (deep) {
+    if (deep && !launched) {
       launched = true;
       constexpr int smem = gemm_smem_bytes<CT, 128, 16, 256>();  // 97 KB: 1 block / CU, 4 waves / SIMD
       static bool attr_done256 = false;

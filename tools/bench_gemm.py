@@ -31,12 +31,14 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--conv", action="store_true", help="include sparse-conv shapes (builds a 120k scene plan)")
     ap.add_argument("--kmajor", action="store_true", help="offset-major neighbour tables")
+    ap.add_argument("--scenes", type=int, default=1, help="stage sizes of a batch of this many 120k-point scenes")
     args = ap.parse_args()
     dev = torch.device("cuda")
     bf = torch.bfloat16
     rows = []
     # (name, M, N, K, ln)
-    stages = [(120000, 32), (55818, 64), (14293, 128), (3364, 256), (778, 512)]
+    stages = [(120000 * args.scenes, 32), (55818 * args.scenes, 64), (14293 * args.scenes, 128), (3364 * args.scenes, 256),
+              (778 * args.scenes, 512)]
     shapes = []
     for n, c in stages:
         shapes += [(f"cpe-lin+LN n={n}", n, c, c, True), (f"qkv n={n}", n, 3 * c, c, False),
