@@ -46,6 +46,7 @@ class BlockDesc(Structure):
         ("qkv_w", c_void_p), ("qkv_b", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p),
         ("norm2_g", c_void_p), ("norm2_b", c_void_p), ("fc1_w", c_void_p), ("fc1_b", c_void_p),
         ("fc2_w", c_void_p), ("fc2_b", c_void_p), ("cpe_conv_wimg", c_void_p),
+        ("head_img", c_void_p), ("tail_img", c_void_p),
     ]
 
 
@@ -119,6 +120,12 @@ SIGNATURES = {
     "cdseg_stem5_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
     "cdseg_stem5": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long,
                             c_int, c_void_p, c_void_p, c_void_p]),
+    "cdseg_block_rr_img_bytes": (c_size_t, [c_int, c_int]),
+    "cdseg_block_rr_pack": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cdseg_cpe_head_rr": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "cdseg_attn_tail_rr": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
     "cdseg_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,

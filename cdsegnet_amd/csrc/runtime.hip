@@ -98,7 +98,14 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
   }
   static const bool fused_head = []() { const char* e = getenv("CDSEG_FUSED_HEAD"); return !(e && e[0] == '0'); }();
   const bool head = fused_head && T == CDSEG_BF16 && (C == 32 || C == 64);
-  if (head) {
+  if (head && d->head_img) {
+    // wide stages: weights resident in LDS, activations in registers (blockrr.hip)
+    if ((rc = cdseg_cpe_head_rr(L.y, C, d->head_img, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
+                                (const float*)d->cpe_ln_b, (float*)io->x, C, (const float*)io->tbias,
+                                (const float*)d->norm1_g, (const float*)d->norm1_b, d->ln_eps, (const float*)d->qkv_b, L.qkv,
+                                3 * C, n, C, stream)) != CDSEG_OK)
+      return rc;
+  } else if (head) {
     // big stages: cpe linear + LN + residual (+ t bias) + LN1 + qkv in one launch (mlp.hip); h never leaves the CU
     if ((rc = cdseg_cpe_head_fused(L.y, C, d->cpe_lin_w, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
                                    (const float*)d->cpe_ln_b, (float*)io->x, C, (const float*)io->tbias,
@@ -145,8 +152,12 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
     return !(e && e[0] == '0') && !(m && m[0] == '0');
   }();
   if (fused_tail && T == CDSEG_BF16 && (C == 32 || C == 64) && d->hidden == 4 * C) {
-    // big stages: proj + residual + LN2 + MLP in one launch (mlp.hip); h and the hidden activation never leave the CU
+    // big stages: proj + residual + LN2 + MLP in one launch; h and the hidden activation never leave the CU
     void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
+    if (d->tail_img)  // weights resident in LDS, activations in registers (blockrr.hip)
+      return cdseg_attn_tail_rr(L.o, C, d->tail_img, (const float*)d->proj_b, (const float*)d->norm2_g,
+                                (const float*)d->norm2_b, d->ln_eps, (const float*)d->fc1_b, (const float*)d->fc2_b,
+                                (float*)io->x, C, xc, C, n, C, stream);
     return cdseg_attn_tail_fused(L.o, C, d->proj_w, (const float*)d->proj_b, (const float*)d->norm2_g,
                                  (const float*)d->norm2_b, d->ln_eps, d->fc1_w, (const float*)d->fc1_b, d->fc2_w,
                                  (const float*)d->fc2_b, (float*)io->x, C, xc, C, n, C, T, stream);

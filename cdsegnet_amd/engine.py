@@ -323,6 +323,11 @@ class Engine:
                 w["x.feat_zero"] = torch.zeros(c, dtype=torch.float32, device=device)
         self.w = w
         # native Block executor: one descriptor per Block (weights never move after prepare)
+        # wide bf16 stages: fragment images of the Block's head / tail weights (register-resident kernels, blockrr.hip)
+        for mod, pre in self._blocks_to_describe:
+            if hasattr(ops, "block_rr_pack") and ops.block_rr_ok(mod.channels, T) and w[pre + ".fc1.w"].shape[0] == 4 * mod.channels:
+                w[pre + ".head_img"], w[pre + ".tail_img"] = ops.block_rr_pack(
+                    mod.channels, w[pre + ".cpe1.w"], w[pre + ".qkv.w"], w[pre + ".proj.w"], w[pre + ".fc1.w"], w[pre + ".fc2.w"])
         self.native_blocks = hasattr(ops, "block_forward") and self.use_native_blocks
         if self.native_blocks:
             for mod, pre in self._blocks_to_describe:
@@ -334,6 +339,8 @@ class Engine:
                          fc1_b=w[pre + ".fc1.b"], fc2_w=w[pre + ".fc2.w"], fc2_b=w[pre + ".fc2.b"])
                 if hasattr(ops, "subm_conv3_pack") and ops.subm_conv3_ok(torch.empty((1, mod.channels), dtype=T, device="meta")):
                     t["cpe_conv_wimg"] = w[pre + ".cpe0.wimg"]
+                if (pre + ".head_img") in w:
+                    t["head_img"], t["tail_img"] = w[pre + ".head_img"], w[pre + ".tail_img"]
                 self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
                                                            mod.attn.scale, 1e-5, t)
         self._scratch = {}
@@ -542,8 +549,12 @@ class Engine:
         if ops.cpe_head_fused_ok(st.xc):  # big stages: cpe linear + LN + residual + LN1 + qkv in one launch
             y = self._buf(n, c, self.T)
             self._conv3(st.xc, pre + ".cpe0", lv, y)
-            ops.cpe_head_fused(y, w[pre + ".cpe1.w"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
-                               tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.w"], w[pre + ".qkv.b"], qkv)
+            if (pre + ".head_img") in w:
+                ops.cpe_head_rr(y, w[pre + ".head_img"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
+                                tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.b"], qkv)
+            else:
+                ops.cpe_head_fused(y, w[pre + ".cpe1.w"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
+                                   tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.w"], w[pre + ".qkv.b"], qkv)
         else:
             h = self._cpe(st, pre + ".cpe", st.xc, tbias, next_norm=pre + ".norm1")
             ops.gemm(h, w[pre + ".qkv.w"], qkv, bias=w[pre + ".qkv.b"])
@@ -558,8 +569,12 @@ class Engine:
         hid = w[pre + ".fc1.w"].shape[0]
         if ops.attn_tail_fused_ok(o, hid):  # big stages: proj + LN2 + MLP in one launch
             st.xc = self._buf(n, c, self.T)
-            ops.attn_tail_fused(o, w[pre + ".proj.w"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
-                                w[pre + ".fc1.w"], w[pre + ".fc1.b"], w[pre + ".fc2.w"], w[pre + ".fc2.b"], st.x, st.xc)
+            if (pre + ".tail_img") in w:
+                ops.attn_tail_rr(o, w[pre + ".tail_img"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
+                                 w[pre + ".fc1.b"], w[pre + ".fc2.b"], st.x, st.xc)
+            else:
+                ops.attn_tail_fused(o, w[pre + ".proj.w"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
+                                    w[pre + ".fc1.w"], w[pre + ".fc1.b"], w[pre + ".fc2.w"], w[pre + ".fc2.b"], st.x, st.xc)
             return
         if c <= self.FUSE_LN_MAX_C:
             h2 = self._buf(n, c, self.T)

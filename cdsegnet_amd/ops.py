@@ -519,6 +519,38 @@ def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5)
     return x
 
 
+def block_rr_ok(channels, dtype):
+    """Register-resident Block head / tail kernels (csrc/blockrr.hip): bf16, C = 32 / 64."""
+    return os.environ.get("CDSEG_BLOCK_RR", "1") != "0" and dtype == torch.bfloat16 and channels in (32, 64)
+
+
+def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
+    """Fragment images of a Block's head (cpe linear, qkv) and tail (proj, fc1, fc2) weights -> (head_img, tail_img)."""
+    _need_gpu(wl, wqkv, wp, w1, w2)
+    lib = _lib.load()
+    dev = wl.device
+    head = torch.empty(lib.cdseg_block_rr_img_bytes(channels, 0), dtype=torch.uint8, device=dev)
+    tail = torch.empty(lib.cdseg_block_rr_img_bytes(channels, 1), dtype=torch.uint8, device=dev)
+    check(lib.cdseg_block_rr_pack(int(channels), _ptr(wl), _ptr(wqkv), _ptr(head), _ptr(wp), _ptr(w1), _ptr(w2), _ptr(tail),
+                                  _stream()), "block_rr_pack")
+    return head, tail
+
+
+def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5):
+    check(_lib.load().cdseg_cpe_head_rr(_ptr(y), y.stride(0), _ptr(head_img), _ptr(bl), _ptr(lnp[0]), _ptr(lnp[1]), _ptr(x),
+                                        x.stride(0), _ptr(colbias), _ptr(ln1[0]), _ptr(ln1[1]), float(eps), _ptr(bqkv),
+                                        _ptr(qkv), qkv.stride(0), y.shape[0], y.shape[1], _stream()), "cpe_head_rr")
+    return qkv
+
+
+def attn_tail_rr(o, tail_img, bp, ln_g, ln_b, b1, b2, x, xc=None, eps=1e-5):
+    check(_lib.load().cdseg_attn_tail_rr(_ptr(o), o.stride(0), _ptr(tail_img), _ptr(bp), _ptr(ln_g), _ptr(ln_b), float(eps),
+                                         _ptr(b1), _ptr(b2), _ptr(x), x.stride(0), _ptr(xc),
+                                         xc.stride(0) if xc is not None else 0, o.shape[0], o.shape[1], _stream()),
+          "attn_tail_rr")
+    return x
+
+
 def _dp(t):
     return None if t is None else t.data_ptr()
 

@@ -330,6 +330,22 @@ int cdseg_stem5(const void* x8, const void* wimg, const float* scale, const floa
                 const int32_t* cluster, const int32_t* parent_nbr3, const int64_t* child_info, long n, long m, int depth,
                 float* out, void* out2, void* stream);
 
+/* ------------------------------------------------------------------ Block head / tail, register-resident (C = 32 / 64, bf16)
+ * Same contracts as cdseg_cpe_head_fused / cdseg_attn_tail_fused, different machine mapping (csrc/blockrr.hip): all
+ * weights of the kernel resident in LDS as MFMA fragments, a wave owns 32 points, activations never leave registers.
+ * Images: cdseg_block_rr_img_bytes(C, 0 = head | 1 = tail); cdseg_block_rr_pack builds them once per Block from the
+ * bf16 row-major weights (head: cpe linear (C,C), qkv (3C,C); tail: proj (C,C), fc1 (4C,C), fc2 (C,4C)); either image
+ * pointer may be NULL. */
+size_t cdseg_block_rr_img_bytes(int channels, int which);
+int cdseg_block_rr_pack(int channels, const void* wl, const void* wqkv, void* head_img, const void* wp, const void* w1,
+                        const void* w2, void* tail_img, void* stream);
+int cdseg_cpe_head_rr(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b,
+                      float* x, int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps,
+                      const float* bqkv, void* qkv, int ldqkv, long n, int channels, void* stream);
+int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b,
+                       float eps, const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n,
+                       int channels, void* stream);
+
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
  * block itself, carving its temporaries from the caller's scratch buffer: sparse-conv CPE, then for bf16 with
@@ -363,6 +379,8 @@ typedef struct cdseg_block_desc {
   const void* fc2_w;       /* (C, hidden) T */
   const float* fc2_b;
   const void* cpe_conv_wimg; /* cdseg_subm_conv3_pack image of cpe_conv_w, or NULL: the conv runs on cdseg_gemm */
+  const void* head_img;      /* cdseg_block_rr_pack images, or NULL: cdseg_cpe_head_fused / cdseg_attn_tail_fused */
+  const void* tail_img;
 } cdseg_block_desc;
 
 typedef struct cdseg_block_io {

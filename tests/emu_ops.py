@@ -258,6 +258,22 @@ def subm_conv3(x, wimg, bias, nbr_kmajor, out):
     return gemm(x, wimg, out, bias=bias, nbr=nbr_kmajor, nbr_kmajor=True, kvol=27)
 
 
+def block_rr_ok(channels, dtype):
+    return dtype == torch.bfloat16 and channels in (32, 64)
+
+
+def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
+    return (wl, wqkv), (wp, w1, w2)  # the emulation multiplies by the plain weights
+
+
+def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5):
+    return cpe_head_fused(y, head_img[0], bl, lnp, x, colbias, ln1, head_img[1], bqkv, qkv, eps)
+
+
+def attn_tail_rr(o, tail_img, bp, ln_g, ln_b, b1, b2, x, xc=None, eps=1e-5):
+    return attn_tail_fused(o, tail_img[0], bp, ln_g, ln_b, tail_img[1], b1, tail_img[2], b2, x, xc, eps)
+
+
 def cpe_head_fused_ok(y):
     return y.dtype == torch.bfloat16 and y.shape[1] in (32, 64)
 

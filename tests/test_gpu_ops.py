@@ -923,6 +923,57 @@ def test_cpe_head_fused_equals_linear_ln_qkv_sequence(ops, M, C, tb):
     assert torch.equal(xa, xb) and torch.equal(qa, qb)
 
 
+@pytest.mark.parametrize("M,C,tb", [(1000, 32, True), (4097, 64, False), (64, 64, True), (31, 32, False), (120000, 32, False),
+                                    (120001, 64, True)])
+def test_block_rr_head_and_tail_vs_fused_kernels(ops, M, C, tb):
+    """csrc/blockrr.hip (weights resident in LDS, activations in registers, transposed MFMA products, permuted channel
+    ownership) against the 64-row-tile fused kernels they replace and against plain torch with the same bf16 rounding
+    points (ptv3.py:401-427).  Same products and rounding points; the fp32 summation order inside a dot product differs,
+    so the comparison is within a few fp32 ulps of the row norm, plus isolated bf16 boundary flips."""
+    g = torch.Generator().manual_seed(M * 7 + C)
+    bf = torch.bfloat16
+    rnd = lambda *sh, s=1.0: _bf16_round(torch.randn(*sh, generator=g) * s)  # noqa: E731
+    y, o = dev(rnd(M, C), bf), dev(rnd(M, C), bf)
+    wl, wq, wp = dev(rnd(C, C, s=C ** -0.5), bf), dev(rnd(3 * C, C, s=C ** -0.5), bf), dev(rnd(C, C, s=C ** -0.5), bf)
+    w1, w2 = dev(rnd(4 * C, C, s=C ** -0.5), bf), dev(rnd(C, 4 * C, s=(4 * C) ** -0.5), bf)
+    vec = lambda n_: dev(torch.randn(n_, generator=g))  # noqa: E731
+    bl, bq, bp, b1, b2 = vec(C), vec(3 * C), vec(C), vec(4 * C), vec(C)
+    g1, be1, g2, be2, g3, be3 = vec(C), vec(C), vec(C), vec(C), vec(C), vec(C)
+    cb = vec(C) if tb else None
+    x0 = torch.randn(M, C, generator=g)
+    assert ops.block_rr_ok(C, bf)
+    himg, timg = ops.block_rr_pack(C, wl, wq, wp, w1, w2)
+    # ---- head
+    xa, qa = dev(x0), torch.full((M, 3 * C), float("nan"), dtype=bf, device="cuda")
+    ops.cpe_head_rr(y, himg, bl, (g1, be1), xa, cb, (g2, be2), bq, qa)
+    xb, qb = dev(x0), torch.empty(M, 3 * C, dtype=bf, device="cuda")
+    ops.cpe_head_fused(y, wl, bl, (g1, be1), xb, cb, (g2, be2), wq, bq, qb)
+    dx = (xa - xb).abs().max().item()
+    dq = (qa.float() - qb.float()).abs()
+    report(f"head rr M={M} C={C}", x_max_diff=dx, qkv_max_diff=dq.max().item(), qkv_mean_diff=dq.mean().item())
+    assert dx < 2e-5 and dq.max().item() < 0.07 and dq.mean().item() < 2e-4  # x fp32; qkv: bf16 boundary flips only
+    t = (y.float().cpu() @ wl.float().cpu().t() + bl.cpu())
+    xr = x0 + F.layer_norm(t, (C,), g1.cpu(), be1.cpu(), 1e-5) + (cb.cpu() if tb else 0)
+    hr = _bf16_round(F.layer_norm(xr, (C,), g2.cpu(), be2.cpu(), 1e-5))
+    qr = hr @ wq.float().cpu().t() + bq.cpu()
+    assert (xa.cpu() - xr).abs().max().item() < 1e-4
+    assert (qa.float().cpu() - qr).abs().max().item() < 0.08
+    # ---- tail
+    xa, xca = dev(x0), torch.full((M, C), float("nan"), dtype=bf, device="cuda")
+    ops.attn_tail_rr(o, timg, bp, g3, be3, b1, b2, xa, xca)
+    xb, xcb = dev(x0), torch.empty(M, C, dtype=bf, device="cuda")
+    ops.attn_tail_fused(o, wp, bp, g3, be3, w1, b1, w2, b2, xb, xcb)
+    d = (xa - xb).abs()
+    report(f"tail rr M={M} C={C}", max_diff=d.max().item(), mean_diff=d.mean().item())
+    assert d.max().item() < 2e-2 and d.mean().item() < 5e-5  # isolated hidden values on a bf16 rounding boundary
+    assert torch.equal(xca, xa.to(bf))
+    xr = x0 + (o.float().cpu() @ wp.float().cpu().t() + bp.cpu())
+    hr = _bf16_round(F.layer_norm(xr, (C,), g3.cpu(), be3.cpu(), 1e-5))
+    u = _bf16_round(F.gelu(hr @ w1.float().cpu().t() + b1.cpu()))
+    ref = xr + u @ w2.float().cpu().t() + b2.cpu()
+    assert (xa.cpu() - ref).abs().max().item() < 3e-2
+
+
 def test_tta_pipeline_device_vs_reference_fixture(ops):
     """SURVEY 8f row 1, complete: raw scan -> CenterShift / NormalizeColor -> the 13 test-time augmentations of
     configs/scannet/CDSegNet.py:278-398 -> GridSample(mode="test") -> per-fragment CenterShift + Collect, all on the device
