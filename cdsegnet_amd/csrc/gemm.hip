@@ -832,7 +832,9 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     static const int dma_on0 = env_int("CDSEG_GEMM_DMA", 1);
     static const int dma_bm0 = env_int("CDSEG_GEMM_DMA_BM", 0);
     if (dma_on0 && p.N > 64 && (p.K % 64) == 0 && (!GATHER || (p.kshift >= 6 && p.kvol <= 27)) && p.M >= 128) {
-      int want = dma_bm0 ? dma_bm0 : ((GATHER || p.M >= 16384) ? 128 : 64);
+      // measured (tools/bench_gemm.py --scenes 8): 128-row tiles win for the sparse convs, for long row counts and for the
+      // wide deep-stage linears (qkv / fc1 at C = 512: 34.9 / 39.0 us vs 48.9 / 50.3 with 64-row tiles)
+      int want = dma_bm0 ? dma_bm0 : ((GATHER || p.M >= 16384 || (p.N >= 1024 && p.M >= 2048)) ? 128 : 64);
       if (ln && p.N <= 128) want = -1;  // complete rows in one block: the fused-LayerNorm epilogue lives in the 64-row loop
       if (want > 0) bm = dma_use_bm = want;
     }

@@ -326,8 +326,10 @@ class Engine:
         # wide bf16 stages: fragment images of the Block's head / tail weights (register-resident kernels, blockrr.hip)
         for mod, pre in self._blocks_to_describe:
             if hasattr(ops, "block_rr_pack") and ops.block_rr_ok(mod.channels, T) and w[pre + ".fc1.w"].shape[0] == 4 * mod.channels:
-                w[pre + ".head_img"], w[pre + ".tail_img"] = ops.block_rr_pack(
+                himg, w[pre + ".tail_img"] = ops.block_rr_pack(
                     mod.channels, w[pre + ".cpe1.w"], w[pre + ".qkv.w"], w[pre + ".proj.w"], w[pre + ".fc1.w"], w[pre + ".fc2.w"])
+                if ops.block_rr_head_on():  # measured slower than the 64-row-tile fused head (memory bound either way)
+                    w[pre + ".head_img"] = himg
         self.native_blocks = hasattr(ops, "block_forward") and self.use_native_blocks
         if self.native_blocks:
             for mod, pre in self._blocks_to_describe:
@@ -339,8 +341,10 @@ class Engine:
                          fc1_b=w[pre + ".fc1.b"], fc2_w=w[pre + ".fc2.w"], fc2_b=w[pre + ".fc2.b"])
                 if hasattr(ops, "subm_conv3_pack") and ops.subm_conv3_ok(torch.empty((1, mod.channels), dtype=T, device="meta")):
                     t["cpe_conv_wimg"] = w[pre + ".cpe0.wimg"]
+                if (pre + ".tail_img") in w:
+                    t["tail_img"] = w[pre + ".tail_img"]
                 if (pre + ".head_img") in w:
-                    t["head_img"], t["tail_img"] = w[pre + ".head_img"], w[pre + ".tail_img"]
+                    t["head_img"] = w[pre + ".head_img"]
                 self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
                                                            mod.attn.scale, 1e-5, t)
         self._scratch = {}

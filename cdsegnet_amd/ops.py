@@ -524,6 +524,12 @@ def block_rr_ok(channels, dtype):
     return os.environ.get("CDSEG_BLOCK_RR", "1") != "0" and dtype == torch.bfloat16 and channels in (32, 64)
 
 
+def block_rr_head_on():
+    """The register-resident HEAD is off by default: the 64-row-tile fused head already streams at ~4.3 TB/s and measured
+    5-10 % faster (tools/bench_block.py); the register-resident TAIL is 1.4-1.65x faster than its predecessor."""
+    return os.environ.get("CDSEG_BLOCK_RR_HEAD", "0") == "1"
+
+
 def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
     """Fragment images of a Block's head (cpe linear, qkv) and tail (proj, fc1, fc2) weights -> (head_img, tail_img)."""
     _need_gpu(wl, wqkv, wp, w1, w2)

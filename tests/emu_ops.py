@@ -262,6 +262,10 @@ def block_rr_ok(channels, dtype):
     return dtype == torch.bfloat16 and channels in (32, 64)
 
 
+def block_rr_head_on():
+    return False
+
+
 def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
     return (wl, wqkv), (wp, w1, w2)  # the emulation multiplies by the plain weights
 

@@ -1,9 +1,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "block_rr or fused or native" 2>&1 | tail -12 ) > gpurun_out/r2h_tests.log 2>&1
-( timeout 300 python tools/bench_block.py 8 ) > gpurun_out/r2h_block.txt 2>&1
-( CDSEG_GEMM_DMA_BM=128 timeout 300 python tools/bench_gemm.py --scenes 8 | grep -E "n=6224|n=26912|sum" ) > gpurun_out/r2h_gemm128.txt 2>&1
-( timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -x -q 2>&1 | tail -8 ) > gpurun_out/r2h_e2e.log 2>&1
-( timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline ) > gpurun_out/r2h_bench.json 2> gpurun_out/r2h_bench.err
-cat gpurun_out/r2h_tests.log gpurun_out/r2h_block.txt gpurun_out/r2h_gemm128.txt gpurun_out/r2h_e2e.log; tail -3 gpurun_out/r2h_bench.err; cut -c1-260 gpurun_out/r2h_bench.json
+( timeout 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-agreement ) > gpurun_out/r2i_bench.json 2> gpurun_out/r2i_bench.err
+cd /tmp && export TMPDIR=/tmp
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_r2i -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-agreement --no-kernel-timer > gpurun_out/r2i_bench_under_rocprof.json 2> gpurun_out/r2i_prof.err )
+cd $GRAFT_REPO_ROOT
+DB=$(find /tmp/prof_r2i -name "*.db" | head -1)
+python tools/prof_summary.py $DB 6 > gpurun_out/r2i_kernel_stats.txt 2>&1
+cut -c1-200 gpurun_out/r2i_bench.json; head -45 gpurun_out/r2i_kernel_stats.txt
