@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-CPU_THREADS = 32  # fastest of {8, 16, 32, 64, 128} torch threads on the 2 x 64-core host (tools/cpu_sweep.py)
+CPU_THREADS = 16  # fastest of {8, 16, 32, 64, 128} torch threads on the GPU box host (tools/cpu_sweep.py, profiles/r02_cpu_sweep.txt)
 
 
 def parse():
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-baseline", dest="cpu_baseline", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
-    ap.add_argument("--cpu-points", type=int, default=60000)
+    ap.add_argument("--cpu-points", type=int, default=120000)
     ap.add_argument("--cpu-threads", type=int, default=CPU_THREADS)
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the roofline pass after the timed region")
     ap.add_argument("--no-agreement", action="store_true", help="skip the bf16-vs-fp32 agreement leg")
@@ -239,14 +239,14 @@ def main():
                 model.inference(dict(fwd), eval=False)
             torch.cuda.synchronize()
             ops.attention_prof_enable(True)
-            a0, c0 = eng.attn_work, eng.conv_bytes
+            a0, c0, ab0 = eng.attn_work, eng.conv_bytes, eng.attn_bytes
             for _ in range(reps):
                 model.inference(dict(fwd), eval=False)
             torch.cuda.synchronize()
             ams, al = ops.prof_summary(ops.PROF_ATTENTION)
             cms, cl = ops.prof_summary(ops.PROF_CONV)
             iso = dict(reps=reps, attn_ms=ams, attn_launches=al, attn_work=eng.attn_work - a0, conv_ms=cms, conv_launches=cl,
-                       conv_bytes=eng.conv_bytes - c0,
+                       conv_bytes=eng.conv_bytes - c0, attn_bytes=eng.attn_bytes - ab0,
                        points=int(sum(sizes[:args.scenes_per_forward])))
             ops.attention_prof_enable(False)
         finally:
@@ -324,15 +324,16 @@ def main():
                 "kernel": "attn_bf16_kernel" if args.precision == "bf16" else "attn_f32_kernel",
                 "launches_per_forward": iso["attn_launches"] / r, "avg_launch_us": 1e3 * iso["attn_ms"] / iso["attn_launches"],
                 "algorithmic_gflop_per_forward": iso["attn_work"] / r / 1e9, "kernel_ms_per_forward": iso["attn_ms"] / r,
+                "algorithmic_bytes_per_launch": iso["attn_bytes"] / max(1, iso["attn_launches"]),
                 "scenes_per_forward": args.scenes_per_forward, "points_per_forward": iso["points"],
                 "measured": f"HIP events around every launch on the launch stream; the timed configuration's own forward "
                             f"({args.scenes_per_forward} collated scenes), {r} forwards one at a time right after the timed region",
-                "note": "head dim 16: 16 v_exp_f32 per 32x32 score tile bound the kernel at ~25 % of the MFMA peak (DESIGN.md 5)"}
+                "note": "head dim 16: the 16 v_exp_f32 + 8 v_perm per 32x32 score tile do not overlap with each other (measured, tools/ubench/pipes.hip) and bound the kernel at ~30 % of the MFMA peak (DESIGN.md 4.2)"}
             if iso["conv_ms"] > 0:
                 gbs = iso["conv_bytes"] / (iso["conv_ms"] * 1e-3) / 1e9
                 res["roofline_conv"] = {
                     "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                    "kernel": "conv_rg_kernel<32|64> + gemm_kernel<..., GATHER> (all k = 3 sparse convs of the forward)",
+                    "kernel": "conv_rg_kernel<32|64> + gemm_dma_kernel<128, GATHER> (all k = 3 sparse convs of the forward; the C >= 128 ones are MFMA-side bound)",
                     "launches_per_forward": iso["conv_launches"] / r, "kernel_ms_per_forward": iso["conv_ms"] / r,
                     "algorithmic_mb_per_forward": iso["conv_bytes"] / r / 1e6,
                     "bytes": "features in + out, kernel map as stored (27 x int32 per point), weights once"}
@@ -340,12 +341,13 @@ def main():
             res["single_scene_points"] = iso["latency_points"]
             tpath = os.path.join(ROOT, "profiles", "r02_attention_traffic.json")
             if args.precision == "bf16" and os.path.exists(tpath):
-                # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) on
-                # the stage-0 launch of this forward: an OFFLINE measurement of this build, the live run cannot collect PMCs
+                # HBM bytes per launch (mean over every attention launch of this bench's forwards) from separate rocprofv3
+                # --pmc passes, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE: tools/pmc_bench_traffic.sh, an OFFLINE
+                # measurement of this build - the live run cannot collect PMCs
                 with open(tpath) as f:
                     tj = json.load(f)
                 res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                res["roofline"]["traffic_source"] = "profiles/r02_attention_traffic.json (offline rocprofv3 --pmc passes, stage-0 launch)"
+                res["roofline"]["traffic_source"] = "profiles/r02_attention_traffic.json (offline rocprofv3 --pmc passes over bench.py's own forwards)"
         if agreement:
             res["bf16_agreement"] = agreement
         m = cdist.metrics(counts)

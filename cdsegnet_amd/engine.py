@@ -178,6 +178,7 @@ class Engine:
         # algorithmic HBM bytes of the k = 3 sparse convs issued so far: features in + out, the kernel map as stored
         # (27 x int32 per point), the weights once per launch
         self.conv_bytes = 0.0
+        self.attn_bytes = 0.0  # algorithmic attention bytes: q, k, v read once + o written once per launch
 
     # ------------------------------------------------------------------ weights
     def prepare(self, device):
@@ -537,6 +538,7 @@ class Engine:
             gidx, widx = lv.slots(st.curves[att.order_index], att.patch_size, att.enable_flash)
             _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
             self.attn_work += 64.0 * att.num_heads * sum_l2
+            self.attn_bytes += 4.0 * n * c * st.xc.element_size()
             self._count_conv(n, c, st.xc.element_size())
             desc = self.block_desc[pre]
             xc_out = st.x if self.T == torch.float32 else self._buf(n, c, self.T)
@@ -566,7 +568,7 @@ class Engine:
         curve = st.curves[att.order_index]
         gidx, widx = lv.slots(curve, att.patch_size, att.enable_flash)
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
-        self._add_work(64.0 * att.num_heads * sum_l2)
+        self._add_work(64.0 * att.num_heads * sum_l2, 4.0 * n * c * qkv.element_size())
         o = self._buf(n, c, self.T)
         ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
                       att.scale, o, work=64.0 * att.num_heads * sum_l2)
@@ -691,7 +693,7 @@ class Engine:
         q_gidx, widx = lv.slots(nst.curves[att.order_index], K, att.enable_flash)
         kv_gidx, _ = lv.slots(cst.curves[att.order_index], K, att.enable_flash)
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(K, att.enable_flash)
-        self._add_work(64.0 * att.num_heads * sum_l2)
+        self._add_work(64.0 * att.num_heads * sum_l2, 4.0 * n * cq * q.element_size())
         o = self._buf(n, cq, self.T)
         ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o,
                       work=64.0 * att.num_heads * sum_l2)
@@ -734,9 +736,10 @@ class Engine:
         d["rng_base"] = self.reserve_rng()
         return d
 
-    def _add_work(self, flops):
+    def _add_work(self, flops, nbytes=0.0):
         with self._work_lock:
             self.attn_work += flops
+            self.attn_bytes += nbytes
 
     RNG_RESERVE = 8  # device-RNG streams one single-step inference may consume
 

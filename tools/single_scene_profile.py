@@ -1,0 +1,27 @@
+"""One 120k-point scene at a time (batch 1), 30 inferences: wall per inference.  Run under
+`rocprofv3 --kernel-trace --stats` and divide the kernel total by 30 to see how much of the wall time is GPU work
+(the bs = 1 latency is kernel time, not host time).  usage: python tools/single_scene_profile.py"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.getcwd())
+from cdsegnet_amd import configs, synth
+from cdsegnet_amd.param_init import fill_state_dict
+from cdsegnet_amd.registry import build_model
+import cdsegnet_amd.models  # noqa: F401
+cfg = configs.cdsegnet_config("scannet")
+model = build_model(cfg)
+model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+model = model.cuda().eval()
+model.precision, model.noise_source = "bf16", "device"
+sc = synth.room_scene(0, 120000)
+inp = {k: torch.as_tensor(sc[k]).cuda() for k in ("coord", "grid_coord", "feat", "offset")}
+inp["offset_host"] = [int(v) for v in sc["offset"]]
+for _ in range(10):
+    model.inference(dict(inp), eval=False)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(20):
+    model.inference(dict(inp), eval=False)
+torch.cuda.synchronize()
+print(f"single scene, {len(sc['coord'])} points: {1e3 * (time.perf_counter() - t) / 20:.2f} ms wall per inference "
+      f"(30 inferences in this process incl. 10 warm-up)", flush=True)
