@@ -346,7 +346,7 @@ def main():
                 # measurement of this build - the live run cannot collect PMCs
                 with open(tpath) as f:
                     tj = json.load(f)
-                res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = "profiles/r02_attention_traffic.json (offline rocprofv3 --pmc passes over bench.py's own forwards)"
         if agreement:
             res["bf16_agreement"] = agreement

@@ -61,7 +61,8 @@ struct ConvCfg {
   static constexpr int LDS_BYTES = LDS_OFFSETS * OFF_BYTES;  // 55,296 / 155,648
   static constexpr int WAVES = C <= 32 ? 8 : 16;             // C = 32: 2 blocks / CU, C = 64: 1 -> 4 waves / SIMD
   static constexpr int RG = 2;                               // 16-row groups per wave
-  static constexpr int G = C <= 32 ? 3 : 1;                  // offsets per pipeline group (register budget 128)
+  static constexpr int G = C <= 32 ? 3 : 1;                  // offsets per step of the DEPTH = 1 pipeline (register budget 128)
+  static constexpr int DEPTH = C <= 32 ? 4 : 2;              // row-load steps in flight (see conv_rg_kernel)
   static constexpr int ROWS_PER_WAVE = RG * 16;
   static constexpr int ROWS_PER_BLOCK = WAVES * ROWS_PER_WAVE;
 };
@@ -89,8 +90,24 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_pack_w_kernel(con
   img[u] = *reinterpret_cast<const uint4*>(w + (long)frag_channel<C>(ct, i) * (27 * C) + o * C + kc * 8);
 }
 
-template <int C>
-__global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p, const uint4* __restrict__ wimg) {
+// the same table as a compile-time constant (the unrolled pipeline resolves LDS-vs-L2 residency per step statically)
+struct SlotTab {
+  static constexpr int8_t v[27] = {19, 7, 20, 8, 1, 9, 21, 10, 22, 11, 2, 12, 3, 0, 4, 13, 5, 14, 23, 15, 24, 16, 6, 17, 25, 18, 26};
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// DEPTH = row-load steps in flight behind the MFMAs.  1: rolled ping-pong loop (one memory round trip per step).
+// >= 2: the 27 / G steps fully unrolled with static buffer names; the index loads run 2 * DEPTH + 1 steps ahead so
+// that (loads return in order) waiting for an index never drains the row loads issued after it.
+template <int C, int DEPTH, int G>
+__global__ __launch_bounds__(ConvCfg<C>::WAVES * 64, 4) void conv_rg_kernel(ConvP p, const uint4* __restrict__ wimg) {
   using K = ConvCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -137,10 +154,13 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
 
     // software pipeline over NS = 27 / G steps of G offsets, two buffer sets in ping-pong (static register names):
     // while the MFMAs of step s run, the row loads of step s+1 and the index loads of step s+2 are in flight
-    constexpr int G = K::G, NS = 27 / G;
+    constexpr int NS = 27 / G;
     static_assert(NS * G == 27 && (NS & 1), "an odd number of steps: pairs + one tail step");
-    int idx[2][G][K::RG];
-    bf16x8_t xb[2][G][K::RG][K::KS];
+    constexpr int NX = DEPTH + 1;                       // row buffers: DEPTH in flight + the one being consumed
+    constexpr int ID = DEPTH == 1 ? 2 : 2 * DEPTH + 1;  // index prefetch distance (steps)
+    constexpr int NI = DEPTH == 1 ? 2 : ID + 1;         // index buffers
+    int idx[NI][G][K::RG];
+    bf16x8_t xb[NX][G][K::RG][K::KS];
     // all gathers are BUFFER loads: an out-of-range offset returns zeros without touching memory and without a
     // branch (a missing neighbour, index -1, wraps to an offset beyond the end of x)
     auto load_idx = [&](int step, auto buf) {
@@ -151,8 +171,8 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
         for (int g = 0; g < K::RG; ++g)  // rows past the end read the last row's map: computed, never stored
           idx[B][q][g] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, idx_off[g], (step * G + q) * (int)(p.n * 4), 0);
     };
-    auto load_rows = [&](auto buf) {
-      constexpr int B = decltype(buf)::value;
+    auto load_rows = [&](auto ibuf, auto xbuf) {
+      constexpr int B = decltype(ibuf)::value, X = decltype(xbuf)::value;
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
             if (p.dbg & 2) src = idx[B][q][g] >= 0 ? (unsigned)myrow[g] : src;
             const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
             const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
-            xb[B][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
+            xb[X][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
           }
     };
     // which of the step's offsets does ANY of the wave's 32 rows have (wave-uniform bit mask)
@@ -203,27 +223,73 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p
           }
       }
     };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    load_idx(0, B0{});
-    load_idx(1, B1{});
-    load_rows(B0{});
+    // the same with the step known at compile time: slot, residency and every fragment address are immediates.  The
+    // lane's base offset is made opaque per tile, otherwise the 27 * KS * CT loop-invariant fragment addresses are
+    // hoisted out of the tile loop and spilled
+    int lane_unit = cgrp * 16 + jrow;
+    asm volatile("" : "+v"(lane_unit));
+    auto mfma_step_static = [&](auto stepc, unsigned live, auto buf) {
+      constexpr int B = decltype(buf)::value, step = decltype(stepc)::value;
+      static_for<0, G>([&](auto Q) {
+        constexpr int q = Q.value;
+        constexpr int slot = K::LDS_OFFSETS == 27 ? step * G + q : (int)SlotTab::v[step * G + q];
+        if (((live >> q) & 1u) && !((p.dbg & 1) && SlotTab::v[step * G + q] >= 19)) {
+#pragma unroll
+          for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < K::CT; ++ct) {
+              const int unit = ((slot * K::CT + ct) * K::KC + ks * 4) * 16 + lane_unit;
+              bf16x8_t wf;
+              if constexpr (slot < K::LDS_OFFSETS)
+                wf = *reinterpret_cast<const bf16x8_t*>(smem + unit * 16);
+              else
+                wf = *reinterpret_cast<const bf16x8_t*>(wimg + unit);  // corner offset of the C = 64 kernel: L2
+#pragma unroll
+              for (int g = 0; g < K::RG; ++g)
+                acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[B][q][g][ks], acc[g][ct], 0, 0, 0);
+            }
+        }
+      });
+    };
+    if constexpr (DEPTH == 1) {
+      // software pipeline over NS steps of G offsets, two buffer sets in ping-pong (static register names): while the
+      // MFMAs of step s run, the row loads of step s+1 and the index loads of step s+2 are in flight
+      using B0 = std::integral_constant<int, 0>;
+      using B1 = std::integral_constant<int, 1>;
+      load_idx(0, B0{});
+      load_idx(1, B1{});
+      load_rows(B0{}, B0{});
 #pragma unroll 1
-    for (int step = 0; step + 1 < NS; step += 2) {
-      {
-        const unsigned live = live_mask(B0{});
-        load_rows(B1{});            // step + 1
-        load_idx(step + 2, B0{});   // step + 2 <= NS - 1 (its row addresses / live bits of `step` are consumed)
-        mfma_step(step, live, B0{});
+      for (int step = 0; step + 1 < NS; step += 2) {
+        {
+          const unsigned live = live_mask(B0{});
+          load_rows(B1{}, B1{});      // step + 1
+          load_idx(step + 2, B0{});   // step + 2 <= NS - 1 (its row addresses / live bits of `step` are consumed)
+          mfma_step(step, live, B0{});
+        }
+        {
+          const unsigned live = live_mask(B1{});
+          load_rows(B0{}, B0{});      // step + 2
+          if (step + 3 < NS) load_idx(step + 3, B1{});
+          mfma_step(step + 1, live, B1{});
+        }
       }
-      {
-        const unsigned live = live_mask(B1{});
-        load_rows(B0{});            // step + 2
-        if (step + 3 < NS) load_idx(step + 3, B1{});
-        mfma_step(step + 1, live, B1{});
-      }
+      mfma_step(NS - 1, live_mask(B0{}), B0{});
+    } else {
+      static_for<0, (ID < NS ? ID : NS)>([&](auto S) { load_idx(S.value, std::integral_constant<int, S.value % NI>{}); });
+      static_for<0, DEPTH>([&](auto S) {
+        load_rows(std::integral_constant<int, S.value % NI>{}, std::integral_constant<int, S.value % NX>{});
+      });
+      static_for<0, NS>([&](auto S) {
+        constexpr int s = S.value;
+        const unsigned live = live_mask(std::integral_constant<int, s % NI>{});
+        if constexpr (s + DEPTH < NS)
+          load_rows(std::integral_constant<int, (s + DEPTH) % NI>{}, std::integral_constant<int, (s + DEPTH) % NX>{});
+        if constexpr (s + ID < NS) load_idx(s + ID, std::integral_constant<int, (s + ID) % NI>{});
+        mfma_step_static(S, live, std::integral_constant<int, s % NX>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
-    mfma_step(NS - 1, live_mask(B0{}), B0{});
     // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
 #pragma unroll
     for (int g = 0; g < K::RG; ++g) {
@@ -257,30 +323,41 @@ int launch_pack(const bf16_t* w, void* wimg, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? CDSEG_OK : CDSEG_ERR_LAUNCH;
 }
 
+template <int C, int DEPTH, int G>
+int launch_conv_depth(const ConvP& p, int grid, const void* wimg, hipStream_t s) {
+  using K = ConvCfg<C>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)conv_rg_kernel<C, DEPTH, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            K::LDS_BYTES) != hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  CdsegProfToken tok;
+  const bool prof = cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);
+  hipLaunchKernelGGL((conv_rg_kernel<C, DEPTH, G>), dim3(grid), dim3(K::WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
+  if (prof) cdseg_prof_end(tok, s);
+  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
+  return CDSEG_OK;
+}
+
 template <int C>
 int launch_conv(const ConvP& p0, const void* wimg, hipStream_t s) {
   using K = ConvCfg<C>;
   ConvP p = p0;
   p.tiles = (int)((p.n + K::ROWS_PER_BLOCK - 1) / K::ROWS_PER_BLOCK);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)conv_rg_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) !=
-        hipSuccess)
-      return CDSEG_ERR_LAUNCH;
-    attr_done = true;
-  }
   // persistent blocks: as many as are co-resident (LDS: 2 per CU at C = 32, 1 at C = 64), never more than tiles
   static const int blocks_per_cu = []() { const char* e = getenv("CDSEG_CONV_RG_BLOCKS"); return e ? atoi(e) : 0; }();
+  static const int depth = []() { const char* e = getenv("CDSEG_CONV_DEPTH"); return e ? atoi(e) : K::DEPTH; }();
   int per_cu = K::LDS_BYTES > 80 * 1024 ? 1 : 2;
   if (blocks_per_cu > 0) per_cu = blocks_per_cu;
   int grid = 256 * per_cu;
   if (grid > p.tiles) grid = (p.tiles + 7) / 8 * 8;  // every XCD keeps a block for its tile range
-  CdsegProfToken tok;
-  const bool prof = cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);
-  hipLaunchKernelGGL((conv_rg_kernel<C>), dim3(grid), dim3(K::WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
-  if (prof) cdseg_prof_end(tok, s);
-  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
-  return CDSEG_OK;
+  // deep pipelines run one offset per step (more, smaller steps in flight for the same registers)
+  if (depth <= 1) return launch_conv_depth<C, 1, K::G>(p, grid, wimg, s);
+  if (depth == 2) return launch_conv_depth<C, 2, 1>(p, grid, wimg, s);
+  if (depth == 3) return launch_conv_depth<C, 3, 1>(p, grid, wimg, s);
+  return launch_conv_depth<C, 4, 1>(p, grid, wimg, s);
 }
 
 }  // namespace

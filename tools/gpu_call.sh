@@ -1,20 +1,14 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 1500 python -m pytest tests -m gpu -x -q ) > gpurun_out/r2j_tests.log 2>&1
-tail -3 gpurun_out/r2j_tests.log
-( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/r2j_smoke.log 2>&1; tail -2 gpurun_out/r2j_smoke.log
-bash tools/pmc_bench_traffic.sh $GRAFT_REPO_ROOT/gpurun_out/r02_attention_traffic.json > gpurun_out/r2j_pmc.log 2>&1
-tail -14 gpurun_out/r2j_pmc.log
-mkdir -p profiles; cp gpurun_out/r02_attention_traffic.json profiles/r02_attention_traffic.json
-( timeout 600 python bench.py ) > gpurun_out/r2j_bench.json 2> gpurun_out/r2j_bench.err
-cat gpurun_out/r2j_bench.json
-cd /tmp && export TMPDIR=/tmp
-( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_r2j -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-agreement --no-kernel-timer > gpurun_out/r2j_bench_under_rocprof.json 2> gpurun_out/r2j_prof.err )
-( cd $GRAFT_REPO_ROOT && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_r2j1 -o run -- python tools/single_scene_profile.py > gpurun_out/r2j_single.txt 2> gpurun_out/r2j_single.err )
-cd $GRAFT_REPO_ROOT
-DB=$(find /tmp/prof_r2j -name "*.db" | head -1)
-python tools/prof_summary.py $DB 6 > gpurun_out/r2j_kernel_stats.txt 2>&1
-DB=$(find /tmp/prof_r2j1 -name "*.db" | head -1)
-python tools/prof_summary.py $DB 30 > gpurun_out/r2j_single_kernel_stats.txt 2>&1
-cat gpurun_out/r2j_single.txt; head -3 gpurun_out/r2j_single_kernel_stats.txt
+for d in 1 2 3 4; do
+  CDSEG_CONV_DEPTH=$d CDSEG_BENCH_NEW_ONLY=1 timeout 120 python tools/bench_conv.py 0 8 2>&1 | grep "conv level" | sed "s/^/depth=$d /" >> gpurun_out/r2k_convdepth.txt
+  CDSEG_CONV_DEPTH=$d CDSEG_BENCH_NEW_ONLY=1 timeout 120 python tools/bench_conv.py 1 8 2>&1 | grep "conv level" | sed "s/^/depth=$d /" >> gpurun_out/r2k_convdepth.txt
+done
+cat gpurun_out/r2k_convdepth.txt | cut -c1-200
+( timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "conv" ) > gpurun_out/r2k_tests.log 2>&1; tail -3 gpurun_out/r2k_tests.log
+bash tools/pmc_bench_traffic.sh $GRAFT_REPO_ROOT/gpurun_out/r02_attention_traffic.json > gpurun_out/r2k_pmc.log 2>&1
+tail -14 gpurun_out/r2k_pmc.log
+cp gpurun_out/r02_attention_traffic.json profiles/r02_attention_traffic.json
+( timeout 600 python bench.py ) > gpurun_out/r2k_bench.json 2> gpurun_out/r2k_bench.err
+cat gpurun_out/r2k_bench.json; tail -3 gpurun_out/r2k_bench.err

@@ -10,7 +10,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   tail -2 /tmp/pmcb_$ctr.log | cut -c1-300
 done
 python3 - "$out" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, sys, collections  # noqa: E401
 out = sys.argv[1]
 tot = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -19,7 +19,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != ctr:
                 continue
-            k = r["Kernel_Name"].split("(")[0].split(" ")[-1]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].strip()
             acc[k] += float(r["Counter_Value"]); cnt[k] += 1
     tot[ctr] = (acc, cnt)
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0` "
