@@ -20,6 +20,14 @@
 //     store(s) per lane, 16 complete rows = 1 KB contiguous per store instruction - no LDS transpose;
 //   * offsets no point of the wave's 32 rows has (z-ordered points: 15-20 of 27) skip their MFMAs (wave-uniform).
 // HBM traffic = features once + kernel map once + output once; W never leaves the CU after the first tile.
+//
+// Two kernels share that layout.  conv_rg_kernel walks all 27 offsets per 32-row wave tile in a software pipeline
+// (index -> row -> MFMA, two buffer sets): every step pays one dependent index -> row memory round trip, and every
+// offset costs its index and row load instructions whether or not any row has it.  conv_ll_kernel (the default) loads
+// the wave's 27 x 32 map block once, coalesced, builds the list of offsets that are present and visits only those,
+// taking a lane's row index from registers (ds_bpermute): no dependent round trip, 3x fewer vector-memory
+// instructions on surface data (C = 32, 8 collated scenes: 80 -> 62 us; C = 64 single scene: 51 -> 30 us, 8 scenes
+// 151 -> 158 us: there the gathers are bound by L2 round trips x outstanding misses per CU, not by issue).
 #include <cstdlib>
 #include <type_traits>
 
@@ -61,8 +69,7 @@ struct ConvCfg {
   static constexpr int LDS_BYTES = LDS_OFFSETS * OFF_BYTES;  // 55,296 / 155,648
   static constexpr int WAVES = C <= 32 ? 8 : 16;             // C = 32: 2 blocks / CU, C = 64: 1 -> 4 waves / SIMD
   static constexpr int RG = 2;                               // 16-row groups per wave
-  static constexpr int G = C <= 32 ? 3 : 1;                  // offsets per step of the DEPTH = 1 pipeline (register budget 128)
-  static constexpr int DEPTH = C <= 32 ? 4 : 2;              // row-load steps in flight (see conv_rg_kernel)
+  static constexpr int G = C <= 32 ? 3 : 1;                  // offsets per pipeline group (register budget 128)
   static constexpr int ROWS_PER_WAVE = RG * 16;
   static constexpr int ROWS_PER_BLOCK = WAVES * ROWS_PER_WAVE;
 };
@@ -90,24 +97,8 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_pack_w_kernel(con
   img[u] = *reinterpret_cast<const uint4*>(w + (long)frag_channel<C>(ct, i) * (27 * C) + o * C + kc * 8);
 }
 
-// the same table as a compile-time constant (the unrolled pipeline resolves LDS-vs-L2 residency per step statically)
-struct SlotTab {
-  static constexpr int8_t v[27] = {19, 7, 20, 8, 1, 9, 21, 10, 22, 11, 2, 12, 3, 0, 4, 13, 5, 14, 23, 15, 24, 16, 6, 17, 25, 18, 26};
-};
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-// DEPTH = row-load steps in flight behind the MFMAs.  1: rolled ping-pong loop (one memory round trip per step).
-// >= 2: the 27 / G steps fully unrolled with static buffer names; the index loads run 2 * DEPTH + 1 steps ahead so
-// that (loads return in order) waiting for an index never drains the row loads issued after it.
-template <int C, int DEPTH, int G>
-__global__ __launch_bounds__(ConvCfg<C>::WAVES * 64, 4) void conv_rg_kernel(ConvP p, const uint4* __restrict__ wimg) {
+template <int C>
+__global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p, const uint4* __restrict__ wimg) {
   using K = ConvCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -154,13 +145,10 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64, 4) void conv_rg_kernel(Conv
 
     // software pipeline over NS = 27 / G steps of G offsets, two buffer sets in ping-pong (static register names):
     // while the MFMAs of step s run, the row loads of step s+1 and the index loads of step s+2 are in flight
-    constexpr int NS = 27 / G;
+    constexpr int G = K::G, NS = 27 / G;
     static_assert(NS * G == 27 && (NS & 1), "an odd number of steps: pairs + one tail step");
-    constexpr int NX = DEPTH + 1;                       // row buffers: DEPTH in flight + the one being consumed
-    constexpr int ID = DEPTH == 1 ? 2 : 2 * DEPTH + 1;  // index prefetch distance (steps)
-    constexpr int NI = DEPTH == 1 ? 2 : ID + 1;         // index buffers
-    int idx[NI][G][K::RG];
-    bf16x8_t xb[NX][G][K::RG][K::KS];
+    int idx[2][G][K::RG];
+    bf16x8_t xb[2][G][K::RG][K::KS];
     // all gathers are BUFFER loads: an out-of-range offset returns zeros without touching memory and without a
     // branch (a missing neighbour, index -1, wraps to an offset beyond the end of x)
     auto load_idx = [&](int step, auto buf) {
@@ -171,8 +159,8 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64, 4) void conv_rg_kernel(Conv
         for (int g = 0; g < K::RG; ++g)  // rows past the end read the last row's map: computed, never stored
           idx[B][q][g] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, idx_off[g], (step * G + q) * (int)(p.n * 4), 0);
     };
-    auto load_rows = [&](auto ibuf, auto xbuf) {
-      constexpr int B = decltype(ibuf)::value, X = decltype(xbuf)::value;
+    auto load_rows = [&](auto buf) {
+      constexpr int B = decltype(buf)::value;
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
@@ -184,7 +172,7 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64, 4) void conv_rg_kernel(Conv
             if (p.dbg & 2) src = idx[B][q][g] >= 0 ? (unsigned)myrow[g] : src;
             const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
             const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
-            xb[X][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
+            xb[B][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
           }
     };
     // which of the step's offsets does ANY of the wave's 32 rows have (wave-uniform bit mask)
@@ -223,73 +211,27 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64, 4) void conv_rg_kernel(Conv
           }
       }
     };
-    // the same with the step known at compile time: slot, residency and every fragment address are immediates.  The
-    // lane's base offset is made opaque per tile, otherwise the 27 * KS * CT loop-invariant fragment addresses are
-    // hoisted out of the tile loop and spilled
-    int lane_unit = cgrp * 16 + jrow;
-    asm volatile("" : "+v"(lane_unit));
-    auto mfma_step_static = [&](auto stepc, unsigned live, auto buf) {
-      constexpr int B = decltype(buf)::value, step = decltype(stepc)::value;
-      static_for<0, G>([&](auto Q) {
-        constexpr int q = Q.value;
-        constexpr int slot = K::LDS_OFFSETS == 27 ? step * G + q : (int)SlotTab::v[step * G + q];
-        if (((live >> q) & 1u) && !((p.dbg & 1) && SlotTab::v[step * G + q] >= 19)) {
-#pragma unroll
-          for (int ks = 0; ks < K::KS; ++ks)
-#pragma unroll
-            for (int ct = 0; ct < K::CT; ++ct) {
-              const int unit = ((slot * K::CT + ct) * K::KC + ks * 4) * 16 + lane_unit;
-              bf16x8_t wf;
-              if constexpr (slot < K::LDS_OFFSETS)
-                wf = *reinterpret_cast<const bf16x8_t*>(smem + unit * 16);
-              else
-                wf = *reinterpret_cast<const bf16x8_t*>(wimg + unit);  // corner offset of the C = 64 kernel: L2
-#pragma unroll
-              for (int g = 0; g < K::RG; ++g)
-                acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[B][q][g][ks], acc[g][ct], 0, 0, 0);
-            }
-        }
-      });
-    };
-    if constexpr (DEPTH == 1) {
-      // software pipeline over NS steps of G offsets, two buffer sets in ping-pong (static register names): while the
-      // MFMAs of step s run, the row loads of step s+1 and the index loads of step s+2 are in flight
-      using B0 = std::integral_constant<int, 0>;
-      using B1 = std::integral_constant<int, 1>;
-      load_idx(0, B0{});
-      load_idx(1, B1{});
-      load_rows(B0{}, B0{});
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    load_idx(0, B0{});
+    load_idx(1, B1{});
+    load_rows(B0{});
 #pragma unroll 1
-      for (int step = 0; step + 1 < NS; step += 2) {
-        {
-          const unsigned live = live_mask(B0{});
-          load_rows(B1{}, B1{});      // step + 1
-          load_idx(step + 2, B0{});   // step + 2 <= NS - 1 (its row addresses / live bits of `step` are consumed)
-          mfma_step(step, live, B0{});
-        }
-        {
-          const unsigned live = live_mask(B1{});
-          load_rows(B0{}, B0{});      // step + 2
-          if (step + 3 < NS) load_idx(step + 3, B1{});
-          mfma_step(step + 1, live, B1{});
-        }
+    for (int step = 0; step + 1 < NS; step += 2) {
+      {
+        const unsigned live = live_mask(B0{});
+        load_rows(B1{});            // step + 1
+        load_idx(step + 2, B0{});   // step + 2 <= NS - 1 (its row addresses / live bits of `step` are consumed)
+        mfma_step(step, live, B0{});
       }
-      mfma_step(NS - 1, live_mask(B0{}), B0{});
-    } else {
-      static_for<0, (ID < NS ? ID : NS)>([&](auto S) { load_idx(S.value, std::integral_constant<int, S.value % NI>{}); });
-      static_for<0, DEPTH>([&](auto S) {
-        load_rows(std::integral_constant<int, S.value % NI>{}, std::integral_constant<int, S.value % NX>{});
-      });
-      static_for<0, NS>([&](auto S) {
-        constexpr int s = S.value;
-        const unsigned live = live_mask(std::integral_constant<int, s % NI>{});
-        if constexpr (s + DEPTH < NS)
-          load_rows(std::integral_constant<int, (s + DEPTH) % NI>{}, std::integral_constant<int, (s + DEPTH) % NX>{});
-        if constexpr (s + ID < NS) load_idx(s + ID, std::integral_constant<int, (s + ID) % NI>{});
-        mfma_step_static(S, live, std::integral_constant<int, s % NX>{});
-        __builtin_amdgcn_sched_barrier(0);
-      });
+      {
+        const unsigned live = live_mask(B1{});
+        load_rows(B0{});            // step + 2
+        if (step + 3 < NS) load_idx(step + 3, B1{});
+        mfma_step(step + 1, live, B1{});
+      }
     }
+    mfma_step(NS - 1, live_mask(B0{}), B0{});
     // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
 #pragma unroll
     for (int g = 0; g < K::RG; ++g) {
@@ -314,6 +256,195 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64, 4) void conv_rg_kernel(Conv
   }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+// Live-list variant.  Per wave and 32-row tile:
+//   phase 1  the 27 x 32 block of the kernel map is loaded ONCE, coalesced and without duplicates (lane l holds
+//            offsets 2t + (l >> 5) of row l & 31 in register t: 14 loads instead of 54), and a ballot per register
+//            gives the set of offsets any of the 32 rows has;
+//   phase 2  only those offsets are visited (z-ordered surface points: 5-14 of 27): a lane fetches its row index
+//            from the register block (ds_bpermute, register picked by the wave-uniform offset), issues the row
+//            loads - no index -> row memory round trip - and the MFMAs of the offset two places back in the list
+//            run meanwhile (three row buffers in rotation).  The list is padded with offset 27 (index -1, loads
+//            return zeros without touching memory) so that every step issues the same number of loads.
+// Texture-address work per tile drops from 27 * (2 + 2 KS) to 14 + live * 2 KS wave instructions.
+template <int C, int WAVES, int NB, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const uint4* __restrict__ wimg) {
+  using K = ConvCfg<C>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int jrow = lane & 15;
+  const int cgrp = lane >> 4;
+  {
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int u = tid; u < K::LDS_BYTES / 16; u += WAVES * 64) dst[u] = wimg[u];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.n * p.ldx * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t nbr_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.nbr, 0, (int)(p.n * 27 * 4), 0x00020000);
+  const int prow = lane & 31, phalf = lane >> 5;
+  const int plane_bytes = (int)(p.n * 4);
+
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = (gridDim.x + 7 - xcd) >> 3;
+  const int per = (p.tiles + 7) >> 3;
+  const int t_end = min(p.tiles, (xcd + 1) * per);
+  for (int tile = xcd * per + bx; tile < t_end; tile += nbx) {
+    const long row0 = (long)tile * (WAVES * K::ROWS_PER_WAVE) + wave * K::ROWS_PER_WAVE;
+    if (row0 >= p.n) continue;  // no barrier below: waves are independent
+    // ---- phase 1: the wave's block of the kernel map
+    i32x16_t I;
+    {
+      long pr = row0 + prow;
+      if (pr >= p.n) pr = p.n - 1;  // rows past the end read the last row's map: computed, never stored
+      const unsigned voff = (unsigned)(pr * 4) + (phalf ? (unsigned)plane_bytes : 0u);
+#pragma unroll
+      for (int t = 0; t < 14; ++t) I[t] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, voff, 2 * t * plane_bytes, 0);
+      if (phalf) I[13] = -1;  // "offset 27": the padding entry of the live list
+      I[14] = -1;
+      I[15] = -1;
+    }
+    unsigned live = 0;
+#pragma unroll
+    for (int t = 0; t < 14; ++t) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(I[t] >= 0);
+      if ((unsigned)m != 0u) live |= 1u << (2 * t);
+      if ((unsigned)(m >> 32) != 0u) live |= 1u << (2 * t + 1);
+    }
+    if (p.dbg & 1) live &= ~0x5140145u;  // corner offsets
+    f32x4_t acc[K::RG][K::CT];
+#pragma unroll
+    for (int g = 0; g < K::RG; ++g)
+#pragma unroll
+      for (int ct = 0; ct < K::CT; ++ct) acc[g][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t xb[NB][K::RG][K::KS];
+    auto pop = [&]() {
+      int o = 27;
+      if (live) {
+        o = __builtin_ctz(live);
+        live &= live - 1;
+      }
+      return o;
+    };
+    auto issue = [&](int o, auto buf) {
+      constexpr int B = decltype(buf)::value;
+      const int v = I[__builtin_amdgcn_readfirstlane(o >> 1)];
+#pragma unroll
+      for (int g = 0; g < K::RG; ++g) {
+        const int srcl = ((o & 1) << 5) + 16 * g + jrow;
+        const int id = __builtin_amdgcn_ds_bpermute(srcl << 2, v);
+        const unsigned src = (unsigned)id;  // -1 << row_shift wraps beyond the end of x: zeros, no memory access
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks) {
+          const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
+          xb[B][g][ks] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+        }
+      }
+    };
+    int lane_unit = cgrp * 16 + jrow;
+    asm volatile("" : "+v"(lane_unit));  // opaque per tile: keeps the fragment address arithmetic inside the tile loop
+    auto consume = [&](int o, auto buf) {
+      constexpr int B = decltype(buf)::value;
+      if (o >= 27) return;
+      const int slot = K::LDS_OFFSETS == 27 ? o : (int)c_slot_of_offset[o];
+      if (K::LDS_OFFSETS == 27 || slot < K::LDS_OFFSETS) {
+        const char* base = smem + slot * K::OFF_BYTES + lane_unit * 16;
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < K::CT; ++ct) {
+            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 256);
+#pragma unroll
+            for (int g = 0; g < K::RG; ++g)
+              acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[B][g][ks], acc[g][ct], 0, 0, 0);
+          }
+      } else {  // corner offset of the C = 64 kernel: fragments from L2, two at a time
+        const uint4* base = wimg + slot * (K::OFF_BYTES / 16) + lane_unit;
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < K::CT; ct += 2) {
+            const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 16);
+            const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(base + ((ct + 1) * K::KC + ks * 4) * 16);
+#pragma unroll
+            for (int g = 0; g < K::RG; ++g) {
+              acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xb[B][g][ks], acc[g][ct], 0, 0, 0);
+              acc[g][ct + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xb[B][g][ks], acc[g][ct + 1], 0, 0, 0);
+            }
+          }
+      }
+    };
+    int o[NB];
+    static_for<0, NB - 1>([&](auto J) {
+      o[J.value] = pop();
+      issue(o[J.value], J);
+    });
+#pragma unroll 1
+    do {  // NB list entries per trip, no exits in between: at most NB - 1 padding steps per tile
+      static_for<0, NB>([&](auto J) {
+        constexpr int j = J.value, nb = (j + NB - 1) % NB;
+        o[nb] = pop();
+        issue(o[nb], std::integral_constant<int, nb>{});
+        consume(o[j], J);
+      });
+    } while (o[0] < 27);
+    // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
+#pragma unroll
+    for (int g = 0; g < K::RG; ++g) {
+      const long myrow = row0 + g * 16 + jrow;
+      if (myrow >= p.n) continue;
+      bf16_t* dst = p.y + myrow * p.ldy + cgrp * (C / 4);
+#pragma unroll
+      for (int h = 0; h < K::CT / 2; ++h) {
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (p.bias) {
+          b0 = *reinterpret_cast<const float4*>(p.bias + cgrp * (C / 4) + 8 * h);
+          b1 = *reinterpret_cast<const float4*>(p.bias + cgrp * (C / 4) + 8 * h + 4);
+        }
+        uint4 u;
+        u.x = pack_bf16x2(acc[g][2 * h][0] + b0.x, acc[g][2 * h][1] + b0.y);
+        u.y = pack_bf16x2(acc[g][2 * h][2] + b0.z, acc[g][2 * h][3] + b0.w);
+        u.z = pack_bf16x2(acc[g][2 * h + 1][0] + b1.x, acc[g][2 * h + 1][1] + b1.y);
+        u.w = pack_bf16x2(acc[g][2 * h + 1][2] + b1.z, acc[g][2 * h + 1][3] + b1.w);
+        *reinterpret_cast<uint4*>(dst + 8 * h) = u;
+      }
+    }
+  }
+}
+
+template <int C, int WAVES, int NB, int OCC>
+int launch_conv_ll(const ConvP& p0, int per_cu, const void* wimg, hipStream_t s) {
+  using K = ConvCfg<C>;
+  ConvP p = p0;
+  p.tiles = (int)((p.n + WAVES * K::ROWS_PER_WAVE - 1) / (WAVES * K::ROWS_PER_WAVE));
+  int grid = 256 * per_cu;
+  if (grid > p.tiles) grid = (p.tiles + 7) / 8 * 8;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)conv_ll_kernel<C, WAVES, NB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            K::LDS_BYTES) != hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  CdsegProfToken tok;
+  const bool prof = cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);
+  hipLaunchKernelGGL((conv_ll_kernel<C, WAVES, NB, OCC>), dim3(grid), dim3(WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
+  if (prof) cdseg_prof_end(tok, s);
+  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
+  return CDSEG_OK;
+}
+
 template <int C>
 int launch_pack(const bf16_t* w, void* wimg, hipStream_t s) {
   using K = ConvCfg<C>;
@@ -323,41 +454,37 @@ int launch_pack(const bf16_t* w, void* wimg, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? CDSEG_OK : CDSEG_ERR_LAUNCH;
 }
 
-template <int C, int DEPTH, int G>
-int launch_conv_depth(const ConvP& p, int grid, const void* wimg, hipStream_t s) {
-  using K = ConvCfg<C>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)conv_rg_kernel<C, DEPTH, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            K::LDS_BYTES) != hipSuccess)
-      return CDSEG_ERR_LAUNCH;
-    attr_done = true;
-  }
-  CdsegProfToken tok;
-  const bool prof = cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);
-  hipLaunchKernelGGL((conv_rg_kernel<C, DEPTH, G>), dim3(grid), dim3(K::WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
-  if (prof) cdseg_prof_end(tok, s);
-  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
-  return CDSEG_OK;
-}
-
 template <int C>
 int launch_conv(const ConvP& p0, const void* wimg, hipStream_t s) {
   using K = ConvCfg<C>;
   ConvP p = p0;
   p.tiles = (int)((p.n + K::ROWS_PER_BLOCK - 1) / K::ROWS_PER_BLOCK);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)conv_rg_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) !=
+        hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
   // persistent blocks: as many as are co-resident (LDS: 2 per CU at C = 32, 1 at C = 64), never more than tiles
   static const int blocks_per_cu = []() { const char* e = getenv("CDSEG_CONV_RG_BLOCKS"); return e ? atoi(e) : 0; }();
-  static const int depth = []() { const char* e = getenv("CDSEG_CONV_DEPTH"); return e ? atoi(e) : K::DEPTH; }();
   int per_cu = K::LDS_BYTES > 80 * 1024 ? 1 : 2;
   if (blocks_per_cu > 0) per_cu = blocks_per_cu;
+  // default: the live-list kernel (C = 32: 8 waves, 3 row buffers, 2 blocks / CU; C = 64: 8 waves with the 256-register
+  // budget of 2 waves / SIMD, 4 row buffers).  CDSEG_CONV_LL=0 runs the register-gather kernel above (A/B, profiles/r02_*)
+  static const int ll = []() { const char* e = getenv("CDSEG_CONV_LL"); return e ? atoi(e) : 1; }();
+  if (ll) {
+    if constexpr (C == 32) return launch_conv_ll<32, 8, 3, 4>(p0, per_cu, wimg, s);
+    else return launch_conv_ll<64, 8, 4, 2>(p0, per_cu, wimg, s);
+  }
   int grid = 256 * per_cu;
   if (grid > p.tiles) grid = (p.tiles + 7) / 8 * 8;  // every XCD keeps a block for its tile range
-  // deep pipelines run one offset per step (more, smaller steps in flight for the same registers)
-  if (depth <= 1) return launch_conv_depth<C, 1, K::G>(p, grid, wimg, s);
-  if (depth == 2) return launch_conv_depth<C, 2, 1>(p, grid, wimg, s);
-  if (depth == 3) return launch_conv_depth<C, 3, 1>(p, grid, wimg, s);
-  return launch_conv_depth<C, 4, 1>(p, grid, wimg, s);
+  CdsegProfToken tok;
+  const bool prof = cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);
+  hipLaunchKernelGGL((conv_rg_kernel<C>), dim3(grid), dim3(K::WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
+  if (prof) cdseg_prof_end(tok, s);
+  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
+  return CDSEG_OK;
 }
 
 }  // namespace
