@@ -8,26 +8,21 @@
 // index -> row -> LDS round trips (PMC, profiles/r01l: VALU 11 %, matrix pipe 2 %, 60 % of the wave cycles idle).
 // This kernel turns the roles around:
 //   * W is STATIONARY: the whole 27 x C x C kernel lives in LDS for the lifetime of a persistent block (C = 32:
-//     55 KB, 2 blocks / CU; C = 64: the 19 face / edge / centre offsets = 152 KB, the 8 corner offsets - rarely
-//     occupied on scanned surfaces - are read from L2), laid out in MFMA A-fragment order (conflict-free b128 reads);
+//     55 KB, 2 blocks / CU; C = 64: the 19 face / edge / centre offsets = 152 KB, the 8 corner offsets are read from
+//     L2), laid out in MFMA A-fragment order (conflict-free b128 reads);
 //   * gathered rows go STRAIGHT into MFMA B-fragment registers: lane (j, c) of v_mfma_f32_16x16x32_bf16 holds
-//     channels 8c..8c+7 of point j, which is one 16-byte load from row nbr[o, j] - no LDS round trip, no barrier,
-//     no zero-filled slots for missing neighbours (the load is simply predicated off);
-//   * waves are independent (no __syncthreads in the main loop): latency is hidden by 4-6 waves per SIMD, each with
-//     the index loads of offset group g+2 and the row loads of group g+1 in flight behind the MFMAs of group g;
+//     channels 8c..8c+7 of point j, which is one 16-byte BUFFER load from row nbr[o, j] - no LDS round trip, no
+//     barrier; a missing neighbour (index -1) becomes an out-of-range buffer offset: zeros, no memory access;
+//   * waves are independent (no __syncthreads in the main loop);
 //   * the product is computed transposed (D^T = W X^T) with the output channels permuted inside the A operand so
 //     that a lane ends up holding C/4 CONSECUTIVE channels of one point: the epilogue is bias + one (two) 16-byte
 //     store(s) per lane, 16 complete rows = 1 KB contiguous per store instruction - no LDS transpose;
-//   * offsets no point of the wave's 32 rows has (z-ordered points: 15-20 of 27) skip their MFMAs (wave-uniform).
-// HBM traffic = features once + kernel map once + output once; W never leaves the CU after the first tile.
-//
-// Two kernels share that layout.  conv_rg_kernel walks all 27 offsets per 32-row wave tile in a software pipeline
-// (index -> row -> MFMA, two buffer sets): every step pays one dependent index -> row memory round trip, and every
-// offset costs its index and row load instructions whether or not any row has it.  conv_ll_kernel (the default) loads
-// the wave's 27 x 32 map block once, coalesced, builds the list of offsets that are present and visits only those,
-// taking a lane's row index from registers (ds_bpermute): no dependent round trip, 3x fewer vector-memory
-// instructions on surface data (C = 32, 8 collated scenes: 80 -> 62 us; C = 64 single scene: 51 -> 30 us, 8 scenes
-// 151 -> 158 us: there the gathers are bound by L2 round trips x outstanding misses per CU, not by issue).
+//   * LIVE LIST: per wave and 32-row tile the 27 x 32 block of the kernel map is loaded ONCE, coalesced and without
+//     duplicates (14 loads; the first version issued 54 index loads and 27 x 2 KS row loads per tile, one dependent
+//     index -> row round trip per offset), a ballot per register gives the offsets any of the 32 rows has, and only
+//     those are visited (z-ordered surface points: 14-16 of 27 per 32 rows on the benchmark scenes), the lane's row index coming from registers.
+// HBM traffic = features once + kernel map once + output once (PMC: profiles/r02_pmc_conv*.txt); W never leaves the
+// CU after the first tile.  History and measurements of the variants: DESIGN.md 4.2.
 #include <cstdlib>
 #include <type_traits>
 
@@ -46,7 +41,7 @@ struct ConvP {
   long n;
   int ldx, ldy;
   int row_shift;        // log2(ldx * 2): byte stride of a feature row (a power of two)
-  int tiles;            // ceil(n / ROWS_PER_BLOCK)
+  int tiles;            // ceil(n / rows per block)
   int dbg;              // timing experiments only (CDSEG_CONV_DBG; results are WRONG when set): 1 = corner offsets
                         // treated as dead, 2 = every neighbour replaced by the row itself (perfectly local gathers)
 };
@@ -59,6 +54,11 @@ __device__ __constant__ int8_t c_slot_of_offset[27] = {
     23, 15, 24, 16, 6, 17, 25, 18, 26 // a = 2
 };
 
+// the same table packed 5 bits per entry (offsets 0-11, 12-23, 24-26) for scalar-register lookups
+struct SlotBits {
+  static constexpr unsigned long long t0 = 0x6097655521450f3ull, t1 = 0x89a187ddc569003ull, t2 = 0x6a59ull;
+};
+
 template <int C>
 struct ConvCfg {
   static constexpr int CT = C / 16;       // 16-channel output tiles
@@ -67,11 +67,9 @@ struct ConvCfg {
   static constexpr int OFF_BYTES = C * C * 2;                // one offset's weights
   static constexpr int LDS_OFFSETS = C <= 32 ? 27 : 19;      // offsets resident in LDS
   static constexpr int LDS_BYTES = LDS_OFFSETS * OFF_BYTES;  // 55,296 / 155,648
-  static constexpr int WAVES = C <= 32 ? 8 : 16;             // C = 32: 2 blocks / CU, C = 64: 1 -> 4 waves / SIMD
+  static constexpr int WAVES = 8;                            // pack kernel block size
   static constexpr int RG = 2;                               // 16-row groups per wave
-  static constexpr int G = C <= 32 ? 3 : 1;                  // offsets per pipeline group (register budget 128)
   static constexpr int ROWS_PER_WAVE = RG * 16;
-  static constexpr int ROWS_PER_BLOCK = WAVES * ROWS_PER_WAVE;
 };
 
 // Fragment-order weight image.  16-byte unit u = ((slot * CT + ct) * KC + kc) * 16 + i holds
@@ -97,165 +95,6 @@ __global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_pack_w_kernel(con
   img[u] = *reinterpret_cast<const uint4*>(w + (long)frag_channel<C>(ct, i) * (27 * C) + o * C + kc * 8);
 }
 
-template <int C>
-__global__ __launch_bounds__(ConvCfg<C>::WAVES * 64) void conv_rg_kernel(ConvP p, const uint4* __restrict__ wimg) {
-  using K = ConvCfg<C>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int jrow = lane & 15;  // point within a 16-row group (B operand column)
-  const int cgrp = lane >> 4;  // channel chunk of the k step (B operand k block) / channel group of the result
-
-  // ---- resident weights: one contiguous copy of the fragment image (L2 -> LDS), once per persistent block
-  {
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int u = tid; u < K::LDS_BYTES / 16; u += K::WAVES * 64) dst[u] = wimg[u];
-  }
-  __syncthreads();
-
-
-  const __amdgpu_buffer_rsrc_t x_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.n * p.ldx * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t nbr_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.nbr, 0, (int)(p.n * 27 * 4), 0x00020000);
-
-  // tiles: XCD x (block id mod 8, performance-only assumption) owns a contiguous range of row tiles so that the
-  // neighbour gathers of z-ordered rows stay in one L2
-  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = (gridDim.x + 7 - xcd) >> 3;
-  const int per = (p.tiles + 7) >> 3;
-  const int t_end = min(p.tiles, (xcd + 1) * per);
-  for (int tile = xcd * per + bx; tile < t_end; tile += nbx) {
-    const long row0 = (long)tile * K::ROWS_PER_BLOCK + wave * K::ROWS_PER_WAVE;
-    if (row0 >= p.n) continue;  // no barrier below: waves are independent
-    long myrow[K::RG];
-    bool rowok[K::RG];
-    unsigned idx_off[K::RG];
-#pragma unroll
-    for (int g = 0; g < K::RG; ++g) {
-      myrow[g] = row0 + g * 16 + jrow;
-      rowok[g] = myrow[g] < p.n;
-      idx_off[g] = (unsigned)((rowok[g] ? myrow[g] : p.n - 1) * 4);
-    }
-    f32x4_t acc[K::RG][K::CT];
-#pragma unroll
-    for (int g = 0; g < K::RG; ++g)
-#pragma unroll
-      for (int ct = 0; ct < K::CT; ++ct) acc[g][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // software pipeline over NS = 27 / G steps of G offsets, two buffer sets in ping-pong (static register names):
-    // while the MFMAs of step s run, the row loads of step s+1 and the index loads of step s+2 are in flight
-    constexpr int G = K::G, NS = 27 / G;
-    static_assert(NS * G == 27 && (NS & 1), "an odd number of steps: pairs + one tail step");
-    int idx[2][G][K::RG];
-    bf16x8_t xb[2][G][K::RG][K::KS];
-    // all gathers are BUFFER loads: an out-of-range offset returns zeros without touching memory and without a
-    // branch (a missing neighbour, index -1, wraps to an offset beyond the end of x)
-    auto load_idx = [&](int step, auto buf) {
-      constexpr int B = decltype(buf)::value;
-#pragma unroll
-      for (int q = 0; q < G; ++q)
-#pragma unroll
-        for (int g = 0; g < K::RG; ++g)  // rows past the end read the last row's map: computed, never stored
-          idx[B][q][g] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, idx_off[g], (step * G + q) * (int)(p.n * 4), 0);
-    };
-    auto load_rows = [&](auto buf) {
-      constexpr int B = decltype(buf)::value;
-#pragma unroll
-      for (int q = 0; q < G; ++q)
-#pragma unroll
-        for (int g = 0; g < K::RG; ++g)
-#pragma unroll
-          for (int ks = 0; ks < K::KS; ++ks) {
-            // -1 << row_shift wraps to the top of the 32-bit offset range: out of bounds -> zeros
-            unsigned src = (unsigned)idx[B][q][g];
-            if (p.dbg & 2) src = idx[B][q][g] >= 0 ? (unsigned)myrow[g] : src;
-            const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
-            const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
-            xb[B][q][g][ks] = __builtin_bit_cast(bf16x8_t, v);
-          }
-    };
-    // which of the step's offsets does ANY of the wave's 32 rows have (wave-uniform bit mask)
-    auto live_mask = [&](auto buf) {
-      constexpr int B = decltype(buf)::value;
-      unsigned m = 0;
-#pragma unroll
-      for (int q = 0; q < G; ++q) {
-        bool any = false;
-#pragma unroll
-        for (int g = 0; g < K::RG; ++g) any |= idx[B][q][g] >= 0;
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) m |= 1u << q;
-      }
-      return m;  // (dbg bit 1 is applied by the caller)
-    };
-    auto mfma_step = [&](int step, unsigned live, auto buf) {
-      constexpr int B = decltype(buf)::value;
-#pragma unroll
-      for (int q = 0; q < G; ++q) {
-        if (!((live >> q) & 1u)) continue;  // wave-uniform: nobody in these 32 rows has this offset
-        const int slot = K::LDS_OFFSETS == 27 ? step * G + q : (int)c_slot_of_offset[step * G + q];
-        if ((p.dbg & 1) && c_slot_of_offset[step * G + q] >= 19) continue;
-#pragma unroll
-        for (int ks = 0; ks < K::KS; ++ks)
-#pragma unroll
-          for (int ct = 0; ct < K::CT; ++ct) {
-            const int unit = ((slot * K::CT + ct) * K::KC + ks * 4 + cgrp) * 16 + jrow;
-            bf16x8_t wf;
-            if (K::LDS_OFFSETS == 27 || slot < K::LDS_OFFSETS)
-              wf = *reinterpret_cast<const bf16x8_t*>(smem + unit * 16);
-            else
-              wf = *reinterpret_cast<const bf16x8_t*>(wimg + unit);  // corner offset of the C = 64 kernel: L2
-#pragma unroll
-            for (int g = 0; g < K::RG; ++g)
-              acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[B][q][g][ks], acc[g][ct], 0, 0, 0);
-          }
-      }
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    load_idx(0, B0{});
-    load_idx(1, B1{});
-    load_rows(B0{});
-#pragma unroll 1
-    for (int step = 0; step + 1 < NS; step += 2) {
-      {
-        const unsigned live = live_mask(B0{});
-        load_rows(B1{});            // step + 1
-        load_idx(step + 2, B0{});   // step + 2 <= NS - 1 (its row addresses / live bits of `step` are consumed)
-        mfma_step(step, live, B0{});
-      }
-      {
-        const unsigned live = live_mask(B1{});
-        load_rows(B0{});            // step + 2
-        if (step + 3 < NS) load_idx(step + 3, B1{});
-        mfma_step(step + 1, live, B1{});
-      }
-    }
-    mfma_step(NS - 1, live_mask(B0{}), B0{});
-    // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
-#pragma unroll
-    for (int g = 0; g < K::RG; ++g) {
-      if (!rowok[g]) continue;
-      bf16_t* dst = p.y + myrow[g] * p.ldy + cgrp * (C / 4);
-#pragma unroll
-      for (int h = 0; h < K::CT / 2; ++h) {
-        // the lane's channels cgrp * C/4 + 8h .. + 7 are consecutive: bias as two float4 (L1-resident)
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-        if (p.bias) {
-          b0 = *reinterpret_cast<const float4*>(p.bias + cgrp * (C / 4) + 8 * h);
-          b1 = *reinterpret_cast<const float4*>(p.bias + cgrp * (C / 4) + 8 * h + 4);
-        }
-        uint4 u;
-        u.x = pack_bf16x2(acc[g][2 * h][0] + b0.x, acc[g][2 * h][1] + b0.y);
-        u.y = pack_bf16x2(acc[g][2 * h][2] + b0.z, acc[g][2 * h][3] + b0.w);
-        u.z = pack_bf16x2(acc[g][2 * h + 1][0] + b1.x, acc[g][2 * h + 1][1] + b1.y);
-        u.w = pack_bf16x2(acc[g][2 * h + 1][2] + b1.z, acc[g][2 * h + 1][3] + b1.w);
-        *reinterpret_cast<uint4*>(dst + 8 * h) = u;
-      }
-    }
-  }
-}
-
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -266,14 +105,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 
-// Live-list variant.  Per wave and 32-row tile:
+// Per wave and 32-row tile:
 //   phase 1  the 27 x 32 block of the kernel map is loaded ONCE, coalesced and without duplicates (lane l holds
 //            offsets 2t + (l >> 5) of row l & 31 in register t: 14 loads instead of 54), and a ballot per register
 //            gives the set of offsets any of the 32 rows has;
-//   phase 2  only those offsets are visited (z-ordered surface points: 5-14 of 27): a lane fetches its row index
+//   phase 2  only those offsets are visited (z-ordered surface points: 14-16 of 27 per 32 rows on the benchmark scenes): a lane fetches its row index
 //            from the register block (ds_bpermute, register picked by the wave-uniform offset), issues the row
 //            loads - no index -> row memory round trip - and the MFMAs of the offset two places back in the list
-//            run meanwhile (three row buffers in rotation).  The list is padded with offset 27 (index -1, loads
+//            run meanwhile (NB row buffers in rotation).  The list is padded with offset 27 (index -1, loads
 //            return zeros without touching memory) so that every step issues the same number of loads.
 // Texture-address work per tile drops from 27 * (2 + 2 KS) to 14 + live * 2 KS wave instructions.
 template <int C, int WAVES, int NB, int OCC>
@@ -337,66 +176,90 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
       }
       return o;
     };
-    auto issue = [&](int o, auto buf) {
-      constexpr int B = decltype(buf)::value;
+    // one list entry = four pieces:
+    //   perm   the lane's row indices of offset o out of the register block (ds_bpermute)
+    //   rows   the row loads (KS per 16-row group)
+    //   wload  the offset's KS * CT weight fragments, ALL requested at once (one LDS round trip per step, not one per
+    //          fragment: 160 -> 122 us at C = 64 together with the two fixes noted below; requesting them a step ahead
+    //          into a second fragment set, and loading the next tile's map block a tile ahead, changed nothing)
+    //   mfmas  the products
+    auto perm = [&](int o, int (&id)[K::RG]) {
       const int v = I[__builtin_amdgcn_readfirstlane(o >> 1)];
 #pragma unroll
-      for (int g = 0; g < K::RG; ++g) {
-        const int srcl = ((o & 1) << 5) + 16 * g + jrow;
-        const int id = __builtin_amdgcn_ds_bpermute(srcl << 2, v);
-        const unsigned src = (unsigned)id;  // -1 << row_shift wraps beyond the end of x: zeros, no memory access
+      for (int g = 0; g < K::RG; ++g) id[g] = __builtin_amdgcn_ds_bpermute((((o & 1) << 5) + 16 * g + jrow) << 2, v);
+    };
+    auto rows = [&](const int (&id)[K::RG], auto buf) {
+      constexpr int B = decltype(buf)::value;
+#pragma unroll
+      for (int g = 0; g < K::RG; ++g)
 #pragma unroll
         for (int ks = 0; ks < K::KS; ++ks) {
-          const unsigned off = (src << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
+          // -1 << row_shift wraps beyond the end of x: zeros, no memory access
+          const unsigned off = ((unsigned)id[g] << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
           xb[B][g][ks] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
         }
-      }
     };
     int lane_unit = cgrp * 16 + jrow;
     asm volatile("" : "+v"(lane_unit));  // opaque per tile: keeps the fragment address arithmetic inside the tile loop
-    auto consume = [&](int o, auto buf) {
-      constexpr int B = decltype(buf)::value;
+    auto wload = [&](int o, bf16x8_t (&wf)[K::KS][K::CT]) {
       if (o >= 27) return;
-      const int slot = K::LDS_OFFSETS == 27 ? o : (int)c_slot_of_offset[o];
+      // slot of the offset from a 5-bit-per-entry table in scalar registers (an indexed read of the __constant__ table
+      // compiles to a VECTOR load + vmcnt(0): it drained the row loads in flight at every step)
+      int slot = o;
+      if (K::LDS_OFFSETS != 27) {
+        const unsigned long long tab = o < 12 ? SlotBits::t0 : (o < 24 ? SlotBits::t1 : SlotBits::t2);
+        const int sh = 5 * (o < 12 ? o : (o < 24 ? o - 12 : o - 24));
+        slot = (int)((tab >> sh) & 31ull);
+      }
       if (K::LDS_OFFSETS == 27 || slot < K::LDS_OFFSETS) {
         const char* base = smem + slot * K::OFF_BYTES + lane_unit * 16;
 #pragma unroll
         for (int ks = 0; ks < K::KS; ++ks)
 #pragma unroll
-          for (int ct = 0; ct < K::CT; ++ct) {
-            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 256);
-#pragma unroll
-            for (int g = 0; g < K::RG; ++g)
-              acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[B][g][ks], acc[g][ct], 0, 0, 0);
-          }
-      } else {  // corner offset of the C = 64 kernel: fragments from L2, two at a time
+          for (int ct = 0; ct < K::CT; ++ct)
+            wf[ks][ct] = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 256);
+      } else {
+        // corner offset of the C = 64 kernel: from L2.  The explicit vmcnt(0) keeps the fragment registers from counting
+        // as "pending on vmcnt" after the join, where EVERY step would then wait for the row loads in flight (and a
+        // per-lane LDS / global address select would become FLAT loads)
         const uint4* base = wimg + slot * (K::OFF_BYTES / 16) + lane_unit;
 #pragma unroll
         for (int ks = 0; ks < K::KS; ++ks)
 #pragma unroll
-          for (int ct = 0; ct < K::CT; ct += 2) {
-            const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 16);
-            const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(base + ((ct + 1) * K::KC + ks * 4) * 16);
-#pragma unroll
-            for (int g = 0; g < K::RG; ++g) {
-              acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xb[B][g][ks], acc[g][ct], 0, 0, 0);
-              acc[g][ct + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xb[B][g][ks], acc[g][ct + 1], 0, 0, 0);
-            }
-          }
+          for (int ct = 0; ct < K::CT; ++ct)
+            wf[ks][ct] = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 16);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
       }
+    };
+    auto mfmas = [&](int o, const bf16x8_t (&wf)[K::KS][K::CT], auto buf) {
+      constexpr int B = decltype(buf)::value;
+      if (o >= 27) return;
+#pragma unroll
+      for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < K::CT; ++ct)
+#pragma unroll
+          for (int g = 0; g < K::RG; ++g)
+            acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xb[B][g][ks], acc[g][ct], 0, 0, 0);
     };
     int o[NB];
     static_for<0, NB - 1>([&](auto J) {
       o[J.value] = pop();
-      issue(o[J.value], J);
+      int id[K::RG];
+      perm(o[J.value], id);
+      rows(id, J);
     });
 #pragma unroll 1
     do {  // NB list entries per trip, no exits in between: at most NB - 1 padding steps per tile
       static_for<0, NB>([&](auto J) {
         constexpr int j = J.value, nb = (j + NB - 1) % NB;
         o[nb] = pop();
-        issue(o[nb], std::integral_constant<int, nb>{});
-        consume(o[j], J);
+        int id[K::RG];
+        perm(o[nb], id);
+        rows(id, std::integral_constant<int, nb>{});
+        bf16x8_t wf[K::KS][K::CT];
+        wload(o[j], wf);
+        mfmas(o[j], wf, J);
       });
     } while (o[0] < 27);
     // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
@@ -457,34 +320,15 @@ int launch_pack(const bf16_t* w, void* wimg, hipStream_t s) {
 template <int C>
 int launch_conv(const ConvP& p0, const void* wimg, hipStream_t s) {
   using K = ConvCfg<C>;
-  ConvP p = p0;
-  p.tiles = (int)((p.n + K::ROWS_PER_BLOCK - 1) / K::ROWS_PER_BLOCK);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)conv_rg_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) !=
-        hipSuccess)
-      return CDSEG_ERR_LAUNCH;
-    attr_done = true;
-  }
   // persistent blocks: as many as are co-resident (LDS: 2 per CU at C = 32, 1 at C = 64), never more than tiles
-  static const int blocks_per_cu = []() { const char* e = getenv("CDSEG_CONV_RG_BLOCKS"); return e ? atoi(e) : 0; }();
+  static const int blocks_per_cu = []() { const char* e = getenv("CDSEG_CONV_BLOCKS"); return e ? atoi(e) : 0; }();
   int per_cu = K::LDS_BYTES > 80 * 1024 ? 1 : 2;
   if (blocks_per_cu > 0) per_cu = blocks_per_cu;
-  // default: the live-list kernel (C = 32: 8 waves, 3 row buffers, 2 blocks / CU; C = 64: 8 waves with the 256-register
-  // budget of 2 waves / SIMD, 4 row buffers).  CDSEG_CONV_LL=0 runs the register-gather kernel above (A/B, profiles/r02_*)
-  static const int ll = []() { const char* e = getenv("CDSEG_CONV_LL"); return e ? atoi(e) : 1; }();
-  if (ll) {
-    if constexpr (C == 32) return launch_conv_ll<32, 8, 3, 4>(p0, per_cu, wimg, s);
-    else return launch_conv_ll<64, 8, 4, 2>(p0, per_cu, wimg, s);
-  }
-  int grid = 256 * per_cu;
-  if (grid > p.tiles) grid = (p.tiles + 7) / 8 * 8;  // every XCD keeps a block for its tile range
-  CdsegProfToken tok;
-  const bool prof = cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);
-  hipLaunchKernelGGL((conv_rg_kernel<C>), dim3(grid), dim3(K::WAVES * 64), K::LDS_BYTES, s, p, (const uint4*)wimg);
-  if (prof) cdseg_prof_end(tok, s);
-  if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
-  return CDSEG_OK;
+  // C = 32: 8 waves, 3 row buffers, 4 waves / SIMD; C = 64: 8 waves on the 256-register budget of 2 waves / SIMD,
+  // 4 row buffers (16 waves x 2 buffers spills and is 1.8x slower; 6 buffers, 12-wave blocks at 3 waves / SIMD and, at
+  // C = 32, 12-wave blocks or 4 buffers: no gain - profiles/r02_conv_livelist_sweep.txt)
+  if constexpr (C == 32) return launch_conv_ll<32, 8, 3, 4>(p0, per_cu, wimg, s);
+  else return launch_conv_ll<64, 8, 4, 2>(p0, per_cu, wimg, s);
 }
 
 }  // namespace
