@@ -1,12 +1,13 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rm -f gpurun_out/r2r_conv.txt
-for sc in 8 4 1; do
-  timeout 120 python tools/bench_conv.py 1 $sc 2>&1 | grep "conv level 1: weight" | sed "s/^/mappf ${sc}sc /" | cut -c1-220 >> gpurun_out/r2r_conv.txt
-  timeout 120 python tools/bench_conv.py 0 $sc 2>&1 | grep "conv level 0: weight" | sed "s/^/mappf ${sc}sc /" | cut -c1-220 >> gpurun_out/r2r_conv.txt
+( timeout 600 python tools/bench_next_rows.py ) > gpurun_out/r02_next_rows.txt 2> gpurun_out/r2t_next.err
+cat gpurun_out/r02_next_rows.txt; tail -3 gpurun_out/r2t_next.err
+rm -f gpurun_out/r02_other_configs.txt
+for cfg in "--dataset scannet200" "--dataset nuscenes" "--robust" "--precision fp32 --scenes-per-forward 4"; do
+  ( timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-agreement $cfg ) 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('bench.py $cfg :', round(d['value']/1e6,2), 'M points/s,', round(d['ms_per_step'],2), 'ms/step,', d['config']['scenes_per_step_per_gpu'], 'scenes/step, mean points/scene', round(d['config']['points_per_scene_mean']), ', attention frac', round(d.get('roofline',{}).get('frac',0),4), ', single-scene latency ms', round(d.get('single_scene_latency_ms',0),2))" >> gpurun_out/r02_other_configs.txt
 done
-cat gpurun_out/r2r_conv.txt
-( timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "conv" ) > gpurun_out/r2r_tests.log 2>&1; tail -3 gpurun_out/r2r_tests.log
-( timeout 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-agreement ) > gpurun_out/r2r_bench.json 2> gpurun_out/r2r_bench.err
-cut -c1-200 gpurun_out/r2r_bench.json
+cat gpurun_out/r02_other_configs.txt
