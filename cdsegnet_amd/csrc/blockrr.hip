@@ -132,12 +132,19 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void head_rr_kernel(HeadRR p) {
 #pragma unroll
       for (int t = 0; t < CT; ++t) xr[t] = *reinterpret_cast<const f32x4_t*>(p.x + rr * p.ldx + q * Q + 4 * t);
       f32x4_t v[CT];
+      {
+        uint4 wl[CT][KS];  // all fragments of the product in one LDS round trip (see tail_rr_kernel)
 #pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        v[t] = *reinterpret_cast<const f32x4_t*>(pr + q * Q + 4 * t);  // + bl (C operand)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-          v[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Wl[(t * KS + s) * 64 + lane]), yf[s], v[t], 0, 0, 0);
+          for (int s = 0; s < KS; ++s) wl[t][s] = Wl[(t * KS + s) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          v[t] = *reinterpret_cast<const f32x4_t*>(pr + q * Q + 4 * t);  // + bl (C operand)
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            v[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wl[t][s]), yf[s], v[t], 0, 0, 0);
+        }
       }
       float mean, rstd;
       ln_stats<CT>(v, inv_c, p.eps, mean, rstd);
@@ -161,15 +168,30 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void head_rr_kernel(HeadRR p) {
       bf16x8_t hf[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) hf[s] = pack8(v[2 * s], v[2 * s + 1]);
-      // qkv: two 16-channel tiles at a time -> 8 consecutive channels per lane -> one 16-byte store
+      // qkv: two 16-channel tiles at a time -> 8 consecutive channels per lane -> one 16-byte store; the fragments of
+      // the next pair are requested before the MFMAs of this one
+      uint4 wq[2][2][KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        wq[0][0][s] = Wq[(0 * KS + s) * 64 + lane];
+        wq[0][1][s] = Wq[(1 * KS + s) * 64 + lane];
+      }
 #pragma unroll
       for (int ot = 0; ot < OT; ot += 2) {
+        const int cur = (ot >> 1) & 1;
+        if (ot + 2 < OT) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            wq[cur ^ 1][0][s] = Wq[((ot + 2) * KS + s) * 64 + lane];
+            wq[cur ^ 1][1][s] = Wq[((ot + 3) * KS + s) * 64 + lane];
+          }
+        }
         f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(pr + 6 * C + q * QQ + 4 * ot);
         f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(pr + 6 * C + q * QQ + 4 * ot + 4);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Wq[(ot * KS + s) * 64 + lane]), hf[s], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Wq[((ot + 1) * KS + s) * 64 + lane]), hf[s], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[cur][0][s]), hf[s], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[cur][1][s]), hf[s], a1, 0, 0, 0);
         }
         if (ok) *reinterpret_cast<bf16x8_t*>(p.qkv + row * p.ldqkv + q * QQ + 4 * ot) = pack8(a0, a1);
       }
@@ -219,16 +241,25 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void tail_rr_kernel(TailRR p) {
       bf16x8_t of[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) of[s] = *reinterpret_cast<const bf16x8_t*>(p.o + rr * p.ldo + q * Q + 8 * s);
-      // x' = (o Wp^T + bp) + x
+      // x' = (o Wp^T + bp) + x.  All CT * KS weight fragments are requested before the first MFMA (one LDS round trip
+      // for the product instead of one per fragment: a wave's chain of ~100 dependent LDS reads per 16 rows was the
+      // kernel's critical path)
       f32x4_t x1[CT];
+      {
+        uint4 wp[CT][KS];
 #pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        f32x4_t a = *reinterpret_cast<const f32x4_t*>(pr + q * Q + 4 * t);
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Wp[(t * KS + s) * 64 + lane]), of[s], a, 0, 0, 0);
-        const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.x + rr * p.ldx + q * Q + 4 * t);
-        x1[t] = a + r;
+          for (int s = 0; s < KS; ++s) wp[t][s] = Wp[(t * KS + s) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          f32x4_t a = *reinterpret_cast<const f32x4_t*>(pr + q * Q + 4 * t);
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wp[t][s]), of[s], a, 0, 0, 0);
+          const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.x + rr * p.ldx + q * Q + 4 * t);
+          x1[t] = a + r;
+        }
       }
       float mean, rstd;
       ln_stats<CT>(x1, inv_c, p.eps, mean, rstd);
@@ -249,21 +280,30 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void tail_rr_kernel(TailRR p) {
       f32x4_t acc2[CT];
 #pragma unroll
       for (int t = 0; t < CT; ++t) acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 1
       for (int u = 0; u < HU; ++u) {
+        // the step's 2 KS fc1 fragments and CT fc2 fragments in one batch: the fc2 ones arrive during the GELU
+        uint4 w1[2][KS], w2[CT];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          w1[0][s] = W1[((2 * u) * KS + s) * 64 + lane];
+          w1[1][s] = W1[((2 * u + 1) * KS + s) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) w2[t] = W2[(t * HU + u) * 64 + lane];
         f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + 32 * u + 4 * q);
         f32x4_t h1 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + 32 * u + 16 + 4 * q);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W1[((2 * u) * KS + s) * 64 + lane]), hf[s], h0, 0, 0, 0);
-          h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W1[((2 * u + 1) * KS + s) * 64 + lane]), hf[s], h1, 0, 0, 0);
+          h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[0][s]), hf[s], h0, 0, 0, 0);
+          h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[1][s]), hf[s], h1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { h0[r] = gelu_erf(h0[r]); h1[r] = gelu_erf(h1[r]); }
         const bf16x8_t Hf = pack8(h0, h1);
 #pragma unroll
         for (int t = 0; t < CT; ++t)
-          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W2[(t * HU + u) * 64 + lane]), Hf, acc2[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w2[t]), Hf, acc2[t], 0, 0, 0);
       }
       if (ok) {
 #pragma unroll

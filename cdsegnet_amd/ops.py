@@ -622,7 +622,7 @@ def stem5(x8, wimg, scale, shift, grid, cluster, parent_nbr3, cinfo, depth, out,
 
 
 def subm_conv3_ok(x):
-    """The weight-stationary register-gather conv (csrc/conv.hip) covers the wide bf16 stages: C = 32 / 64."""
+    """The weight-stationary live-list conv (csrc/conv.hip) covers the wide bf16 stages: C = 32 / 64."""
     on = os.environ.get("CDSEG_CONV_RG", "1") != "0"
     return on and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (32, 64) and x.stride(0) == x.shape[1]
 

@@ -231,7 +231,7 @@ def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
 def test_subm_conv3_weight_stationary_vs_oracle(ops, name, C):
     """csrc/conv.hip (W resident in LDS, gathered rows straight into MFMA fragments, C = 32 / 64 bf16) against the
     oracle's subm_conv3d on bf16-rounded operands, and against the gathered-A GEMM it replaces (same inputs; different
-    summation order only).  Row counts that are not a multiple of the 256 / 512-row block, rows with no neighbour but
+    summation order only).  Row counts that are not a multiple of the 256-row block, rows with no neighbour but
     themselves (rand16), all 27 offsets (corner offsets of the C = 64 kernel come from L2)."""
     fx = load_fixture(f"serialization_{name}.npz")
     zs, perm0, g0, b0, depth, p = _physical(ops, fx)
@@ -283,6 +283,27 @@ def test_subm_conv3_large_random_map(ops):
         out2 = torch.empty_like(out)
         ops.subm_conv3(x, ops.subm_conv3_pack(w), None, nbr, out2)
         assert torch.equal(out, out2)  # deterministic
+
+
+@pytest.mark.parametrize("C", [32, 64])
+def test_subm_conv3_strided_rows(ops, C):
+    """Input and output as column slices of wider buffers (row stride 2C: a power-of-two byte stride, as the ABI asks);
+    the untouched halves keep their contents."""
+    fx = load_fixture("serialization_lidar5000.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    n = len(p)
+    nbr = ops.nbr_table(zs, g0, b0, depth, 3, True)
+    g = torch.Generator().manual_seed(7 * C)
+    xw = torch.randn(n, 2 * C, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(C, 27 * C, generator=g) / (27 * C) ** 0.5).cuda().to(torch.bfloat16)
+    b = torch.randn(C, generator=g).cuda()
+    img = ops.subm_conv3_pack(w)
+    dense = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
+    ops.subm_conv3(xw[:, C:].contiguous(), img, b, nbr, dense)
+    yw = torch.full((n, 2 * C), 3.0, dtype=torch.bfloat16, device="cuda")
+    ops.subm_conv3(xw[:, C:], img, b, nbr, yw[:, :C])
+    assert torch.equal(yw[:, :C], dense)
+    assert torch.equal(yw[:, C:], torch.full((n, C), 3.0, dtype=torch.bfloat16, device="cuda"))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

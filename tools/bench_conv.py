@@ -42,7 +42,7 @@ if ops.subm_conv3_ok(x) and os.environ.get("CDSEG_BENCH_OLD_ONLY") is None:
     o2 = torch.empty_like(o)
     us2 = time_op(lambda: ops.subm_conv3(x, img, b, nbr, o2), iters)
     comp = (n * c * 2 * 2 + n * 27 * 4 + 27 * c * c * 2) / 1e6  # features in + out, dense kernel map, weights
-    print(f"conv level {level}: weight-stationary register-gather kernel {us2:.1f} us/launch "
+    print(f"conv level {level}: weight-stationary live-list kernel {us2:.1f} us/launch "
           f"({2.0 * n * occ * c * c / us2 / 1e6:.1f} TFLOP/s occupied; compulsory HBM bytes {comp:.1f} MB -> "
           f"{comp / us2:.2f} TB/s), max |new - gathered GEMM| = {(o2.float() - o.float()).abs().max().item():.3e}")
 print(f"conv level {level}: n={n} C={c} occupied neighbours/point={occ:.2f}: {us:.1f} us/launch, "

@@ -28,7 +28,7 @@ def main():
     print("\n# per launch shape (grid in threads) for the GEMM / conv / attention kernels")
     rows = list(cur.execute(
         "select name, grid_x, grid_y, count(*), avg(duration), sum(duration) from kernels "
-        "where name like '%gemm_kernel%' or name like '%attn_%' or name like '%stem_conv%' "
+        "where name like '%gemm_%' or name like '%attn_%' or name like '%conv_ll%' or name like '%stem5%' or name like '%_rr_kernel%' or name like '%fused_kernel%' "
         "group by name, grid_x, grid_y order by sum(duration) desc"))
     for n, gx, gy, c, a, s in rows:
         print(f"{c:7d} {s / 1e6 / steps:9.3f} ms/step {a / 1e3:9.2f} us  grid=({gx},{gy})  {short(n)}")
