@@ -668,10 +668,13 @@ class Engine:
         w = self.w
         cb = self.model.backbone._tm_dec0.cross_block2
         att = cb.attn
-        lv = nst.level
-        if cst.level is not lv:
-            raise CdsegError("cross attention needs the c- and n-branch bottlenecks on the same voxel set "
-                             "(ref: ptv3.py:1009 reuses the q padding for kv)")
+        lv, clv = nst.level, cst.level
+        # the reference pads the kv sequence with the q point's padding plan (ptv3.py:1009): the two bottlenecks must
+        # hold the same number of points per batch element.  They are the same voxel set in every shipped config; a
+        # scene whose grid is shallower than the pooling depths can end on different levels with equal counts
+        if clv is not lv and list(clv.offs_host) != list(lv.offs_host):
+            raise CdsegError("cross attention needs the same number of c- and n-branch bottleneck points per batch "
+                             "element (ref: ptv3.py:1009 reuses the q padding for kv)")
         n, cq = nst.x.shape
         self._cpe(nst, "x.q_cpe", nst.xc)
         self._cpe(cst, "x.kv_cpe", cst.xc)
@@ -691,7 +694,7 @@ class Engine:
         ops.gemm(hkv, w["x.kv.w"], kv, bias=w["x.kv.b"])
         K = att.q_patch_size
         q_gidx, widx = lv.slots(nst.curves[att.order_index], K, att.enable_flash)
-        kv_gidx, _ = lv.slots(cst.curves[att.order_index], K, att.enable_flash)
+        kv_gidx, _ = clv.slots(cst.curves[att.order_index], K, att.enable_flash)
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(K, att.enable_flash)
         self._add_work(64.0 * att.num_heads * sum_l2, 4.0 * n * cq * q.element_size())
         o = self._buf(n, cq, self.T)

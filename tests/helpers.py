@@ -37,3 +37,26 @@ def fixture_draws(fx):
 
 def fixture_input(fx):
     return dict(coord=fx["coord"], grid_coord=fx["grid_coord"], feat=fx["feat"], offset=fx["offset"])
+
+
+def tiny_inputs(kind):
+    """Degenerate scenes the reference's patch / pooling logic special-cases: fewer points than one patch, a batch whose
+    elements differ by two orders of magnitude, points that pool down to ONE voxel per batch element before the last
+    stage, a single point."""
+    rng = np.random.default_rng(5)
+    if kind == "one_point":
+        grids = [np.array([[3, 1, 4]])]
+    elif kind == "seven_and_many":
+        grids = [rng.integers(0, 6, (7, 3)), rng.integers(0, 40, (600, 3))]
+    elif kind == "collapses_early":  # all points inside one 4x4x4 block: one voxel after two poolings
+        grids = [rng.integers(0, 4, (30, 3)), rng.integers(8, 12, (25, 3))]
+    else:  # "small": 40 points, less than any patch size
+        grids = [rng.integers(0, 12, (40, 3))]
+    grids = [np.unique(g, axis=0) for g in grids]
+    grids = [g[rng.permutation(len(g))] for g in grids]
+    grid = np.concatenate(grids).astype(np.int64)
+    n = len(grid)
+    coord = (grid * 0.02 + rng.uniform(0, 0.02, (n, 3))).astype(np.float32)
+    feat = rng.standard_normal((n, 6)).astype(np.float32)
+    offset = np.cumsum([len(g) for g in grids]).astype(np.int64)
+    return dict(coord=coord, grid_coord=grid, feat=feat, offset=offset)

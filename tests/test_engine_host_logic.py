@@ -13,7 +13,7 @@ import cdsegnet_amd.engine as engine_mod
 import cdsegnet_amd.models  # noqa: F401
 from cdsegnet_amd.registry import build_model
 from tests import emu_ops
-from tests.helpers import fixture_cfg, fixture_draws, fixture_input, fixture_state_dict, load_fixture
+from tests.helpers import fixture_cfg, fixture_draws, fixture_input, fixture_state_dict, load_fixture, tiny_inputs
 
 
 @pytest.fixture()
@@ -276,3 +276,23 @@ def test_engine_stem5_branch_wiring(emulated):
     finally:
         emu_ops.stem5_ok = keep
     assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("flash", [False, True])
+@pytest.mark.parametrize("kind", ["small", "seven_and_many", "collapses_early", "one_point"])
+def test_engine_degenerate_scenes_vs_oracle(emulated, kind, flash):
+    from oracle import model as OM
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = copy.deepcopy(fixture_cfg(fx)), fixture_state_dict(fx)
+    cfg["backbone"]["enable_flash"] = flash
+    inp = tiny_inputs(kind)
+    n = len(inp["coord"])
+    draws = OM.draw_rng(77, n, cfg["c_in_channels"])
+    ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"], flash_semantics=flash).numpy()
+    model = build_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    model.precision = "fp32"
+    out = model.inference({k: torch.as_tensor(v) for k, v in inp.items()}, eval=False, draws=dict(draws))["seg_logits"].numpy()
+    assert out.shape == ref.shape and np.isfinite(out).all()
+    assert np.abs(out - ref).max() < 2e-4

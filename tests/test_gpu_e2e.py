@@ -18,7 +18,7 @@ from cdsegnet_amd.param_init import fill_state_dict
 from cdsegnet_amd.registry import build_model
 import cdsegnet_amd.models  # noqa: F401
 from oracle import model as OM
-from tests.helpers import fixture_cfg, fixture_draws, fixture_input, fixture_state_dict, load_fixture
+from tests.helpers import fixture_cfg, fixture_draws, fixture_input, fixture_state_dict, load_fixture, tiny_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -582,3 +582,24 @@ def test_inference_many_full_scale_streams_are_race_free():
         assert torch.equal(outs[0], outs[1])
     finally:
         eng.fork_stage = keep
+
+
+@pytest.mark.parametrize("flash", [False, True])
+@pytest.mark.parametrize("kind", ["small", "seven_and_many", "collapses_early", "one_point"])
+def test_degenerate_scenes_vs_oracle(kind, flash):
+    """Fewer points than one patch, a 7-point scene batched with a 600-point one, scenes that pool down to one voxel per
+    batch element before the last stage (the c- and n-branch bottlenecks then sit on different levels with equal
+    counts), a single point: every kernel at its smallest sizes, fp32 against the oracle and bf16 finite."""
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = fixture_cfg(fx), fixture_state_dict(fx)
+    inp = tiny_inputs(kind)
+    n = len(inp["coord"])
+    draws = OM.draw_rng(77, n, cfg["c_in_channels"])
+    ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"], flash_semantics=flash).numpy()
+    model = build(cfg, sd, "fp32", enable_flash=flash)
+    out = run(model, inp, draws)
+    err, agree = report(f"degenerate {kind} flash={flash} fp32 vs oracle", out, ref)
+    assert out.shape == ref.shape and err < 1e-3
+    model.precision = "bf16"
+    o16 = run(model, inp, draws)
+    assert np.isfinite(o16).all() and np.abs(o16 - ref).max() < 0.06
