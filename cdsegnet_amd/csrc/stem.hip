@@ -14,6 +14,8 @@
 //   * folded BN + GELU + both output copies (fp32 residual stream, bf16 shadow) in the epilogue.
 // bf16 operands, fp32 accumulation: the numerics class of the MFMA path it replaces (the fp32 parity mode keeps the
 // exact-fp32 gathered GEMM).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -21,6 +23,7 @@ namespace {
 constexpr int STEM_WAVES = 12;          // 1 block / CU (LDS), 3 waves / SIMD
 constexpr int STEM_LPP = 4;             // lanes per point (C = 32: 8 output channels each)
 constexpr int STEM_PPW = 64 / STEM_LPP;  // points per wave
+constexpr int STEM_RB = 3;              // neighbour rows requested together per list and round (2: 351 us, 3: 345 us at 8 scenes)
 constexpr int STEM_CAP = 24;            // list entries per lane and pass (more: another pass, never seen on scans)
 constexpr int STEM_WROW = 136;          // u32 per offset row of the weight image: 4 pairs x 32 channels + 8 pad (banks)
 
@@ -63,6 +66,7 @@ __global__ void stem_pack_w_kernel(const bf16_t* __restrict__ w /* (32, 125 * 8)
   img[t] = v;
 }
 
+template <int RB>
 __global__ __launch_bounds__(STEM_WAVES * 64) void stem5_kernel(StemP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* Ws = reinterpret_cast<uint32_t*>(smem);                              // 125 x STEM_WROW
@@ -91,14 +95,26 @@ __global__ __launch_bounds__(STEM_WAVES * 64) void stem5_kernel(StemP p) {
     for (int pass = 0;; ++pass) {
       // ---- enumerate: lane q takes the parent cells q, q + 4, ...; candidates [pass * CAP, (pass + 1) * CAP) are listed
       int cnt = 0;
-      if (valid) {
-        for (int cell = q; cell < 27; cell += STEM_LPP) {
+      {
+        // the lane's 7 parent cells: all map entries first, then all child_info words (two memory round trips instead
+        // of two per cell), then the enumeration from registers
+        constexpr int NCELL = (27 + STEM_LPP - 1) / STEM_LPP;
+        int pn[NCELL];
+        int64_t info[NCELL];
+#pragma unroll
+        for (int c = 0; c < NCELL; ++c) {
+          const int cell = q + STEM_LPP * c;
+          pn[c] = (valid && cell < 27) ? p.pnbr[(long)cell * p.m + par] : -1;
+        }
+#pragma unroll
+        for (int c = 0; c < NCELL; ++c) info[c] = pn[c] >= 0 ? p.cinfo[pn[c]] : 0;
+#pragma unroll
+        for (int c = 0; c < NCELL; ++c) {
+          if (pn[c] < 0) continue;
+          const int cell = q + STEM_LPP * c;
           const int dx = cell / 9 - 1, dy = (cell / 3) % 3 - 1, dz = cell % 3 - 1;
-          const int pn = p.pnbr[(long)cell * p.m + par];
-          if (pn < 0) continue;
-          const int64_t info = p.cinfo[pn];
-          const int first = (int)(info >> 8);
-          int occ = (int)(info & 255), rank = 0;
+          const int first = (int)(info[c] >> 8);
+          int occ = (int)(info[c] & 255), rank = 0;
           const int bx = (((gx >> 1) + dx) << 1) - gx, by = (((gy >> 1) + dy) << 1) - gy, bz = (((gz >> 1) + dz) << 1) - gz;
           while (occ) {
             const int oct = __builtin_ctz(occ);
@@ -125,38 +141,46 @@ __global__ __launch_bounds__(STEM_WAVES * 64) void stem5_kernel(StemP p) {
         more |= c > STEM_CAP;
         c4[l] = c < 0 ? 0 : (c > STEM_CAP ? STEM_CAP : c);
       }
-      // ---- accumulate: every lane walks the point's 4 lists in order (fixed summation order)
+      // ---- accumulate: every lane walks the point's 4 lists (fixed summation order: round-major, 3 entries of each
+      // list per round).  The <= 12 neighbour rows of a round are requested together, then consumed: one memory round
+      // trip per round instead of one per neighbour
+      int cmax = 0;
 #pragma unroll
-      for (int l = 0; l < STEM_LPP; ++l) {
-        const uint32_t* li = ptlists + l * STEM_CAP;
-        uint4 xr = make_uint4(0, 0, 0, 0);
-        uint32_t e = 0;
-        if (c4[l] > 0) {
-          e = li[0];
-          xr = p.x[e & 0xffffffu];
-        }
-        for (int c = 0; c < c4[l]; ++c) {
-          const uint32_t ecur = e;
-          const uint4 xc = xr;
-          if (c + 1 < c4[l]) {  // next neighbour's row in flight behind this one's 32 dot products
-            e = li[c + 1];
-            xr = p.x[e & 0xffffffu];
-          }
-          const uint32_t* wr = Ws + (ecur >> 24) * STEM_WROW + q * 8;
-          const uint32_t xs[4] = {xc.x, xc.y, xc.z, xc.w};
+      for (int l = 0; l < STEM_LPP; ++l) cmax = c4[l] > cmax ? c4[l] : cmax;
+      for (int r0 = 0; r0 < cmax; r0 += RB) {
+        uint32_t e[STEM_LPP][RB];
+        uint4 xr[STEM_LPP][RB];
 #pragma unroll
-          for (int kp = 0; kp < 4; ++kp) {
-            const uint4 w0 = *reinterpret_cast<const uint4*>(wr + kp * 32);
-            const uint4 w1 = *reinterpret_cast<const uint4*>(wr + kp * 32 + 4);
-            const uint32_t wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        for (int l = 0; l < STEM_LPP; ++l)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-              acc[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, xs[kp]), __builtin_bit_cast(bf2, wv[j]), acc[j],
-                                                      false);
+          for (int b = 0; b < RB; ++b) {
+            e[l][b] = 0;
+            xr[l][b] = make_uint4(0, 0, 0, 0);
+            if (r0 + b < c4[l]) {
+              e[l][b] = ptlists[l * STEM_CAP + r0 + b];
+              xr[l][b] = p.x[e[l][b] & 0xffffffu];
             }
           }
-        }
+#pragma unroll
+        for (int l = 0; l < STEM_LPP; ++l)
+#pragma unroll
+          for (int b = 0; b < RB; ++b) {
+            if (r0 + b >= c4[l]) continue;
+            const uint32_t* wr = Ws + (e[l][b] >> 24) * STEM_WROW + q * 8;
+            const uint32_t xs[4] = {xr[l][b].x, xr[l][b].y, xr[l][b].z, xr[l][b].w};
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+              const uint4 w0 = *reinterpret_cast<const uint4*>(wr + kp * 32);
+              const uint4 w1 = *reinterpret_cast<const uint4*>(wr + kp * 32 + 4);
+              const uint32_t wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                acc[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, xs[kp]), __builtin_bit_cast(bf2, wv[j]), acc[j],
+                                                        false);
+              }
+            }
+          }
       }
       __builtin_amdgcn_wave_barrier();  // lists are rewritten by the next pass / tile
       if (!__any(more)) break;
@@ -209,7 +233,7 @@ extern "C" int cdseg_stem5(const void* x8, const void* wimg, const float* scale,
   if (n >= (1l << 24) || m <= 0) return CDSEG_ERR_UNSUPPORTED;  // list entries carry 24-bit row ids
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)stem5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)stem5_kernel<STEM_RB>, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS) != hipSuccess)
       return CDSEG_ERR_LAUNCH;
     attr_done = true;
   }
@@ -220,7 +244,7 @@ extern "C" int cdseg_stem5(const void* x8, const void* wimg, const float* scale,
   const long tiles = (n + STEM_PPW - 1) / STEM_PPW;
   long blocks = (tiles + STEM_WAVES - 1) / STEM_WAVES;
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(stem5_kernel, dim3((unsigned)blocks), dim3(STEM_WAVES * 64), STEM_LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(stem5_kernel<STEM_RB>, dim3((unsigned)blocks), dim3(STEM_WAVES * 64), STEM_LDS, (hipStream_t)stream, p);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }
