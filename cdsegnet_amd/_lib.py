@@ -87,6 +87,8 @@ SIGNATURES = {
     "cdseg_nbr_table": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_nbr_table_from_parent": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int,
                                             c_int, c_void_p, c_void_p]),
+    "cdseg_nbr_table_from_info": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p,
+                                          c_void_p]),
     "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "cdseg_pad_plan_batch": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
                                      POINTER(c_long), c_int, c_void_p, c_void_p, c_void_p]),

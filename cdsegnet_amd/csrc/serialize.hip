@@ -327,6 +327,36 @@ __global__ void nbr_from_parent_kernel(const int64_t* __restrict__ zc, const int
   nbr[kmajor ? (long)o * n + i : t] = res;
 }
 
+// The same with the parents' child_info words (first child row << 8 | octant occupancy, cdseg_child_info): the target
+// is first + popcount(occupancy below its octant) - two dependent reads per (point, offset), no scan of the children
+__global__ void nbr_from_info_kernel(const int32_t* __restrict__ grid, const int32_t* __restrict__ cluster,
+                                     const int32_t* __restrict__ pnbr /* (27,m) */, const int64_t* __restrict__ cinfo,
+                                     long n, long m, int depth, int ksize, int kmajor, int32_t* __restrict__ nbr) {
+  const int kv = ksize * ksize * ksize;
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * kv) return;
+  const long i = kmajor ? t % n : t / kv;
+  const int o = kmajor ? (int)(t / n) : (int)(t - i * kv);
+  const int r = ksize >> 1;
+  const int a = o / (ksize * ksize), b = (o / ksize) % ksize, c = o % ksize;
+  const int gx = grid[3 * i], gy = grid[3 * i + 1], gz = grid[3 * i + 2];
+  const int x = gx + a - r, y = gy + b - r, z = gz + c - r;
+  const int lim = 1 << depth;
+  int res = -1;
+  if (o == kv / 2) {
+    res = (int)i;
+  } else if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+    const int dx = (x >> 1) - (gx >> 1), dy = (y >> 1) - (gy >> 1), dz = (z >> 1) - (gz >> 1);
+    const int par = pnbr[(long)((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)) * m + cluster[i]];
+    if (par >= 0) {
+      const int64_t info = cinfo[par];
+      const int occ = (int)(info & 255), oct = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
+      if ((occ >> oct) & 1) res = (int)(info >> 8) + __popc(occ & ((1 << oct) - 1));
+    }
+  }
+  nbr[kmajor ? (long)o * n + i : t] = res;
+}
+
 // attention slot plan (ptv3.py:188-244 in scatter form).  For padded slot p of batch element b:
 //   local < n_b  : rank = local                       (real slot, its output is kept)
 //   local >= n_b : rank = local - K                   (borrowed from the previous patch's tail)
@@ -668,6 +698,19 @@ int cdseg_nbr_table_from_parent(const int64_t* zcode_sorted, const int32_t* grid
   const long total = n * ksize * ksize * ksize;
   hipLaunchKernelGGL(nbr_from_parent_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, zcode_sorted, grid,
                      cluster, parent_nbr3, seg_start, n, m, depth, ksize, kmajor, nbr);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_nbr_table_from_info(const int32_t* grid, const int32_t* cluster, const int32_t* parent_nbr3,
+                              const int64_t* child_info, long n, long m, int depth, int ksize, int kmajor, int32_t* nbr,
+                              void* stream) {
+  if (!grid || !cluster || !parent_nbr3 || !child_info || !nbr) return CDSEG_ERR_ARG;
+  if (n <= 0) return CDSEG_OK;
+  if ((ksize != 3 && ksize != 5) || m <= 0) return CDSEG_ERR_ARG;
+  const long total = n * ksize * ksize * ksize;
+  hipLaunchKernelGGL(nbr_from_info_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, grid, cluster, parent_nbr3,
+                     child_info, n, m, depth, ksize, kmajor, nbr);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

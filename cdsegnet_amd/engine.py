@@ -85,8 +85,8 @@ class Level:
         def build():
             if self.parent is not None:  # derive from the parent level's 3x3x3 map: ~3 cached reads per lookup
                 par, (cluster, seg) = self.parent
-                return ops.nbr_table_from_parent(self.code4[0], self.grid, cluster, par.nbr(3, True), seg, par.n,
-                                                 self.depth, ksize, kmajor)
+                return ops.nbr_table_from_info(self.grid, cluster, par.nbr(3, True), self.child_info(), par.n, self.depth,
+                                               ksize, kmajor)
             return ops.nbr_table(self.code4[0], self.grid, self.batch, self.depth, ksize, kmajor)
         return _shared(self._nbr, (ksize, kmajor), build)
 

@@ -359,6 +359,18 @@ def nbr_table_from_parent(zcode_sorted, grid_i32, cluster, parent_nbr3, seg_star
     return nbr
 
 
+def nbr_table_from_info(grid_i32, cluster, parent_nbr3, child_info_words, m, depth, ksize, kmajor=False):
+    """The same from the parents' child_info words (first child row << 8 | octant occupancy) instead of the children runs:
+    two dependent reads per (point, offset)."""
+    n = grid_i32.shape[0]
+    kv = ksize ** 3
+    nbr = torch.empty((kv, n) if kmajor else (n, kv), dtype=torch.int32, device=grid_i32.device)
+    check(_lib.load().cdseg_nbr_table_from_info(_ptr(grid_i32), _ptr(cluster), _ptr(parent_nbr3), _ptr(child_info_words), n,
+                                                 int(m), int(depth), int(ksize), 1 if kmajor else 0, _ptr(nbr), _stream()),
+          "nbr_table_from_info")
+    return nbr
+
+
 def pad_plan(order, offs, offs_pad, patch, n_pad):
     dev = offs.device
     gidx = torch.empty(n_pad, dtype=torch.int32, device=dev)

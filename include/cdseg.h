@@ -128,6 +128,11 @@ int cdseg_nbr_table(const int64_t* zcode_sorted, const int32_t* grid, const int3
 int cdseg_nbr_table_from_parent(const int64_t* zcode_sorted, const int32_t* grid, const int32_t* cluster,
                                 const int32_t* parent_nbr3, const int32_t* seg_start, long n, long m, int depth, int ksize,
                                 int kmajor, int32_t* nbr, void* stream);
+/* ... and with the parents' child_info words (cdseg_child_info: first child row << 8 | octant occupancy) instead of the
+ * children runs: target = first + popcount(occupancy below the target's octant). */
+int cdseg_nbr_table_from_info(const int32_t* grid, const int32_t* cluster, const int32_t* parent_nbr3,
+                              const int64_t* child_info, long n, long m, int depth, int ksize, int kmajor, int32_t* nbr,
+                              void* stream);
 /* ------------------------------------------------------------------ attention padding plan
  * ref: ptv3.py:188-244 (get_padding_and_inverse) in gather/scatter form: for every padded slot
  * the row to read (gidx) and the row to write (widx, -1 for the borrowed duplicates).

@@ -133,6 +133,34 @@ def nbr_table_from_parent(zs, grid, cluster, parent_nbr3, seg_start, m, depth, k
     return nbr_table(zs, grid, batch, depth, ksize, kmajor)
 
 
+def nbr_table_from_info(grid, cluster, parent_nbr3, cinfo, m, depth, ksize, kmajor=False):
+    """The kernel's own algebra (csrc/serialize.hip: nbr_from_info_kernel), so that the host-logic tests check the derivation
+    end to end: target = first child + popcount(occupancy below the target's octant)."""
+    g = grid.numpy().astype(np.int64)
+    n, r, kv = len(g), ksize // 2, ksize ** 3
+    pn, info, cl = parent_nbr3.numpy().astype(np.int64), cinfo.numpy().astype(np.int64), cluster.numpy().astype(np.int64)
+    out = np.full((n, kv), -1, dtype=np.int32)
+    pop = np.array([bin(v).count("1") for v in range(256)], dtype=np.int64)
+    for o in range(kv):
+        a, b, c = o // (ksize * ksize), (o // ksize) % ksize, o % ksize
+        if o == kv // 2:
+            out[:, o] = np.arange(n)
+            continue
+        t = g + np.array([a - r, b - r, c - r])
+        valid = ((t >= 0) & (t < (1 << depth))).all(1)
+        d = (t >> 1) - (g >> 1)
+        cell = (d[:, 0] + 1) * 9 + (d[:, 1] + 1) * 3 + (d[:, 2] + 1)
+        par = pn[np.clip(cell, 0, 26), cl]
+        ok = valid & (par >= 0)
+        inf = info[np.where(ok, par, 0)]
+        occ, octant = inf & 255, ((t[:, 0] & 1) << 2) | ((t[:, 1] & 1) << 1) | (t[:, 2] & 1)
+        hit = ok & (((occ >> octant) & 1) == 1)
+        res = (inf >> 8) + pop[occ & ((1 << octant) - 1)]
+        out[:, o] = np.where(hit, res, -1)
+    tt = torch.from_numpy(out)
+    return tt.t().contiguous() if kmajor else tt
+
+
 def pad_plan(order, offs, offs_pad, patch, n_pad):
     offs, offs_pad = offs.numpy().astype(np.int64), offs_pad.numpy().astype(np.int64)
     gidx = np.empty(n_pad, dtype=np.int32)

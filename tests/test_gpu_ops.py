@@ -838,9 +838,10 @@ def test_attention_bf16_loose_score_bound_falls_back_to_exact_max(ops):
     assert (got - want).abs().max().item() < 0.03 * (1 + want.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000", "rand16"])
+@pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000", "rand16", "lidar8", "tiny64"])
 def test_kernel_map_from_parent_equals_search(ops, name):
-    """cdseg_nbr_table_from_parent (parent level's 3x3x3 map + children runs) == cdseg_nbr_table (binary search)."""
+    """cdseg_nbr_table_from_parent (parent level's 3x3x3 map + children runs) and cdseg_nbr_table_from_info (the same with
+    the parents' child_info words: first child + popcount of the occupancy) == cdseg_nbr_table (binary search)."""
     fx = load_fixture(f"serialization_{name}.npz")
     zs, perm0, g0, b0, depth, p = _physical(ops, fx)
     code0 = ops.encode4(g0, b0, depth)
@@ -848,11 +849,14 @@ def test_kernel_map_from_parent_equals_search(ops, name):
     m = int(cnt.item())
     gc, bc, cc = ops.pool_gather(seg, m, len(p), 1, g0, b0, code0)
     pn = ops.nbr_table(cc[0].contiguous(), gc, bc, depth - 1, 3, True)
+    cinfo = ops.child_info(zs, seg, m)
     for ksize in (3, 5):
         for kmajor in (False, True):
             want = ops.nbr_table(zs, g0, b0, depth, ksize, kmajor)
             got = ops.nbr_table_from_parent(zs, g0, cl, pn, seg, m, depth, ksize, kmajor)
             assert torch.equal(got, want), (ksize, kmajor)
+            got = ops.nbr_table_from_info(g0, cl, pn, cinfo, m, depth, ksize, kmajor)
+            assert torch.equal(got, want), (ksize, kmajor, "info")
 
 
 @pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 32), (70, 64), (120000, 32), (4097, 128), (14293, 128)])
