@@ -5,6 +5,8 @@
 // rows: the hidden tile (64 x 64) is produced by MFMA from the h rows in LDS, passed through bias + GELU, rounded to
 // bf16 (exactly what the unfused path stored) and consumed from LDS as the A operand of the second product; only
 // h, the residual and the two outputs touch HBM.  bf16 only (the fp32 parity mode keeps the two-GEMM form).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -332,13 +334,16 @@ struct HeadP {
   float eps;
 };
 
-template <int C>
-__global__ __launch_bounds__(256) void cpe_head_fused_kernel(HeadP p) {
+// BM rows per workgroup (4 threads per row): 128 rows halve the weight reloads (Wl + 3 x Wqkv tile per workgroup) and the
+// barriers per row at the same waves per CU (C = 64: 59 KB LDS, 2 x 8 waves instead of 4 x 4)
+template <int C, int BM>
+__global__ __launch_bounds__(4 * BM) void cpe_head_fused_kernel(HeadP p) {
+  constexpr int NT = 4 * BM;
   constexpr int NCA = C / 8;   // 16-byte chunks per row of y / h / W tiles
   constexpr int TN = C / 32;   // 16-wide column tiles per wave (wave: 32 rows x C/2 columns of a C-wide tile)
   constexpr int CLD = C + 4;
-  constexpr int A_BYTES = 64 * C * 2, W_BYTES = C * C * 2;
-  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W_BYTES + 64 * CLD * 4];
+  constexpr int A_BYTES = BM * C * 2, W_BYTES = C * C * 2;
+  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W_BYTES + BM * CLD * 4];
   char* As = smem;
   char* Ws = smem + A_BYTES;
   float* Cs = reinterpret_cast<float*>(smem + A_BYTES + W_BYTES);
@@ -346,15 +351,15 @@ __global__ __launch_bounds__(256) void cpe_head_fused_kernel(HeadP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
-  const long m0 = (long)blockIdx.x * 64;
+  const long m0 = (long)blockIdx.x * BM;
 
   auto load_w = [&](const bf16_t* w) {  // C rows x C
-    for (int id = tid; id < C * NCA; id += 256) {
+    for (int id = tid; id < C * NCA; id += NT) {
       const int row = id / NCA, ch = id % NCA;
       *reinterpret_cast<uint4*>(Ws + mlp_lds_off<NCA>(row, ch)) = *reinterpret_cast<const uint4*>(w + (long)row * C + ch * 8);
     }
   };
-  auto mma_to_cs = [&]() {  // Cs (64 x C) = As (64 x C) Ws^T
+  auto mma_to_cs = [&]() {  // Cs (BM x C) = As (BM x C) Ws^T
     f32x4_t acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256) void cpe_head_fused_kernel(HeadP p) {
           Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (C / 2) + t * 16 + fr] = acc[i][t][r];
   };
 
-  for (int id = tid; id < 64 * NCA; id += 256) {
+  for (int id = tid; id < BM * NCA; id += NT) {
     const int row = id / NCA, ch = id % NCA;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (m0 + row < p.n) v = *reinterpret_cast<const uint4*>(p.y + (m0 + row) * p.ldy + ch * 8);
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void cpe_head_fused_kernel(HeadP p) {
     __syncthreads();
     mma_to_cs();
     __syncthreads();
-    for (int item = tid; item < 64 * GPR; item += 256) {
+    for (int item = tid; item < BM * GPR; item += NT) {
       const int row = item / GPR, cg = item % GPR;
       const long m = m0 + row;
       if (m >= p.n) continue;
@@ -504,9 +509,16 @@ extern "C" int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, cons
   p.y = (const bf16_t*)y; p.wl = (const bf16_t*)wl; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.wqkv = (const bf16_t*)wqkv; p.bqkv = bqkv;
   p.qkv = (bf16_t*)qkv; p.n = n; p.ldy = ldy; p.ldx = ldx; p.ldqkv = ldqkv; p.eps = eps;
-  const dim3 grid((unsigned)((n + 63) / 64));
-  if (channels == 32) hipLaunchKernelGGL(cpe_head_fused_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(cpe_head_fused_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  static const int bm = []() { const char* e = getenv("CDSEG_HEAD_BM"); return e ? atoi(e) : 128; }();
+  if (bm == 128 && n >= 128 * 512) {  // enough 128-row workgroups to fill the chip twice
+    const dim3 grid((unsigned)((n + 127) / 128));
+    if (channels == 32) hipLaunchKernelGGL((cpe_head_fused_kernel<32, 128>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((cpe_head_fused_kernel<64, 128>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  } else {
+    const dim3 grid((unsigned)((n + 63) / 64));
+    if (channels == 32) hipLaunchKernelGGL((cpe_head_fused_kernel<32, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((cpe_head_fused_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  }
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }
