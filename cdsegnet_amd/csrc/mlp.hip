@@ -40,20 +40,25 @@ __device__ __forceinline__ int mlp_lds_off(int row, int chunk) {
 // PROJ: the block's tail after attention in one kernel (ptv3.py:416-427):
 //     x += proj(o) ;  h = LN2(x) ;  x += fc2(GELU(fc1(h))) ;  xc = T(x)
 // the updated residual rows wait in LDS (fp32) while the MLP runs, h never exists in HBM.
-template <int C, int HT, bool PROJ>
-__global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
+// BM rows per workgroup (4 threads per row; 64, or 128 for the C = 128 MLP: the W1 / W2 slices a workgroup streams from
+// L2 - 4 KB per row at BM = 64, more than its HBM bytes - are halved)
+template <int C, int HT, bool PROJ, int BM = 64>
+__global__ __launch_bounds__(4 * BM) void mlp_fused_kernel(MlpP p) {
+  constexpr int NT = 4 * BM;
   constexpr int HID = 4 * C;
   constexpr int NJ = HID / HT;    // hidden tiles
   constexpr int NCA = C / 8;      // 16-byte chunks per h / W1 row (4, 8 or 16)
   constexpr int NCH = HT / 8;     // 16-byte chunks per H / W2-tile row (16 or 8)
   constexpr int TN1 = HT / 32;    // 16-wide hidden column tiles per wave (wave: 32 rows x HT/2 hidden columns)
   constexpr int TN2 = C / 32;     // 16-wide output column tiles per wave (wave: 32 rows x C/2 columns)
-  constexpr int A_BYTES = 64 * C * 2, W1_BYTES = HT * C * 2, H_BYTES = 64 * HT * 2, W2_BYTES = C * HT * 2;
+  constexpr int A_BYTES = BM * C * 2, W1_BYTES = HT * C * 2, H_BYTES = BM * HT * 2, W2_BYTES = C * HT * 2;
   constexpr int CLD = C + 4;
-  static_assert(64 * CLD * 4 <= W1_BYTES + H_BYTES + W2_BYTES, "C tile must fit the W1 + H + W2 region");
-  constexpr int X_BYTES = PROJ ? 64 * CLD * 4 : 0;
+  // the fp32 C tile of the epilogue aliases W1 + H + W2, or - without PROJ, when h is dead by then - everything from As on
+  constexpr bool CS_FROM_A = !PROJ && BM * CLD * 4 > W1_BYTES + H_BYTES + W2_BYTES;
+  static_assert(BM * CLD * 4 <= (CS_FROM_A ? A_BYTES : 0) + W1_BYTES + H_BYTES + W2_BYTES, "C tile must fit");
+  constexpr int X_BYTES = PROJ ? BM * CLD * 4 : 0;
   static_assert(!PROJ || C * C * 2 <= W1_BYTES + H_BYTES + W2_BYTES, "proj weight must fit the W1 + H + W2 region");
-  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + W1_BYTES + H_BYTES + W2_BYTES + X_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // A_BYTES + W1_BYTES + H_BYTES + W2_BYTES + X_BYTES
   char* As = smem;
   char* W1s = smem + A_BYTES;
   char* Hs = W1s + W1_BYTES;
@@ -63,10 +68,10 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
-  const long m0 = (long)blockIdx.x * 64;
+  const long m0 = (long)blockIdx.x * BM;
 
   // h rows -> LDS (once)
-  for (int id = tid; id < 64 * NCA; id += 256) {
+  for (int id = tid; id < BM * NCA; id += NT) {
     const int row = id / NCA, ch = id % NCA;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (m0 + row < p.n) v = *reinterpret_cast<const uint4*>(p.h + (m0 + row) * p.ldh + ch * 8);
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
 
   if constexpr (PROJ) {
     // ---- x' = x + o Wp^T + bp  (As holds o; Wp sits in the W1 / H / W2 region, free until the MLP loop)
-    for (int id = tid; id < C * NCA; id += 256) {
+    for (int id = tid; id < C * NCA; id += NT) {
       const int row = id / NCA, ch = id % NCA;
       *reinterpret_cast<uint4*>(W1s + mlp_lds_off<NCA>(row, ch)) =
           *reinterpret_cast<const uint4*>(p.wp + (long)row * C + ch * 8);
@@ -160,12 +165,12 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
 #pragma unroll 1
   for (int j = 0; j < NJ; ++j) {
     // W1 rows [HT j, HT j + HT) and W2 columns [HT j, HT j + HT) -> LDS
-    for (int id = tid; id < HT * NCA; id += 256) {
+    for (int id = tid; id < HT * NCA; id += NT) {
       const int row = id / NCA, ch = id % NCA;
       *reinterpret_cast<uint4*>(W1s + mlp_lds_off<NCA>(row, ch)) =
           *reinterpret_cast<const uint4*>(p.w1 + (long)(HT * j + row) * C + ch * 8);
     }
-    for (int id = tid; id < C * NCH; id += 256) {
+    for (int id = tid; id < C * NCH; id += NT) {
       const int row = id / NCH, ch = id % NCH;
       *reinterpret_cast<uint4*>(W2s + mlp_lds_off<NCH>(row, ch)) =
           *reinterpret_cast<const uint4*>(p.w2 + (long)row * HID + HT * j + ch * 8);
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
   }
 
   // ---- epilogue through an fp32 C tile (aliases W1s + Hs + W2s): + b2 + residual, row-contiguous 16-byte accesses
-  float* Cs = reinterpret_cast<float*>(W1s);
+  float* Cs = reinterpret_cast<float*>(CS_FROM_A ? As : W1s);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
         Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (C / 2) + t * 16 + fr] = acc2[i][t][r];
   __syncthreads();
   constexpr int GPR = C / 4;
-  for (int item = tid; item < 64 * GPR; item += 256) {
+  for (int item = tid; item < BM * GPR; item += NT) {
     const int row = item / GPR, cg = item % GPR;
     const long m = m0 + row;
     if (m >= p.n) continue;
@@ -258,6 +263,22 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpP p) {
   }
 }
 
+template <int C, int HT, bool PROJ, int BM>
+int launch_mlp(const MlpP& p, hipStream_t s) {
+  constexpr int CLD = C + 4;
+  constexpr int LDS = BM * C * 2 + HT * C * 2 + BM * HT * 2 + C * HT * 2 + (PROJ ? BM * CLD * 4 : 0);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (LDS > 64 * 1024 && hipFuncSetAttribute((const void*)mlp_fused_kernel<C, HT, PROJ, BM>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const dim3 grid((unsigned)((p.n + BM - 1) / BM));
+  hipLaunchKernelGGL((mlp_fused_kernel<C, HT, PROJ, BM>), grid, dim3(4 * BM), LDS, s, p);
+  return hipGetLastError() == hipSuccess ? CDSEG_OK : CDSEG_ERR_LAUNCH;
+}
+
 }  // namespace
 
 // x (n, ldx) fp32 += fc2(GELU(fc1(h))) with h (n, ldh) bf16; xc (n, ldxc) bf16 copy of the new x, or NULL.
@@ -275,14 +296,14 @@ extern "C" int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const flo
   p.h = (const bf16_t*)h; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2;
   p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldh = ldh; p.ldx = ldx; p.ldxc = ldxc;
   p.wp = nullptr; p.bp = nullptr; p.ln_g = nullptr; p.ln_b = nullptr; p.ln_eps = 0.f;
-  const dim3 grid((unsigned)((n + 63) / 64));
   // 64-wide hidden tiles: 20 / 32 / 56 KB of LDS per workgroup (C = 32 / 64 / 128).  128-wide tiles were measured 2-3 %
   // slower end to end at C = 64 (56 KB: two workgroups per CU instead of five) and equal at C = 32.
-  if (channels == 32) hipLaunchKernelGGL((mlp_fused_kernel<32, 64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else if (channels == 64) hipLaunchKernelGGL((mlp_fused_kernel<64, 64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((mlp_fused_kernel<128, 64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  CDSEG_CHECK_LAUNCH();
-  return CDSEG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  static const int bm = []() { const char* e = getenv("CDSEG_MLP_BM"); return e ? atoi(e) : 128; }();
+  if (channels == 32) return launch_mlp<32, 64, false, 64>(p, s);
+  if (channels == 64) return launch_mlp<64, 64, false, 64>(p, s);
+  if (bm == 128 && n >= 128 * 512) return launch_mlp<128, 64, false, 128>(p, s);  // 80 KB: two 8-wave workgroups per CU
+  return launch_mlp<128, 64, false, 64>(p, s);
 }
 
 // Block tail after attention in one launch (ptv3.py:416-427):
@@ -303,11 +324,8 @@ extern "C" int cdseg_attn_tail_fused(const void* o, int ldo, const void* wp, con
   p.h = (const bf16_t*)o; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2;
   p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldh = ldo; p.ldx = ldx; p.ldxc = ldxc;
   p.wp = (const bf16_t*)wp; p.bp = bp; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps;
-  const dim3 grid((unsigned)((n + 63) / 64));
-  if (channels == 32) hipLaunchKernelGGL((mlp_fused_kernel<32, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((mlp_fused_kernel<64, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  CDSEG_CHECK_LAUNCH();
-  return CDSEG_OK;
+  if (channels == 32) return launch_mlp<32, 64, true, 64>(p, (hipStream_t)stream);
+  return launch_mlp<64, 64, true, 64>(p, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -859,7 +859,8 @@ def test_kernel_map_from_parent_equals_search(ops, name):
             assert torch.equal(got, want), (ksize, kmajor, "info")
 
 
-@pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 32), (70, 64), (120000, 32), (4097, 128), (14293, 128)])
+@pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 32), (70, 64), (120000, 32), (4097, 128), (14293, 128),
+                                 (65536 + 77, 128)])  # >= 64 k rows at C = 128: the 128-row workgroups
 def test_mlp_fused_vs_two_gemms_and_fp64(ops, M, C):
     """cdseg_mlp_fused (hidden activation kept in LDS) against the two-GEMM form and an fp64 reference that rounds
     the hidden activation to bf16 at the same place (ptv3.py:299-322, :423-427)."""
@@ -922,7 +923,8 @@ def test_attn_tail_fused_equals_proj_ln_mlp_sequence(ops, M, C):
     assert (xa.cpu() - ref).abs().max().item() < 3e-2
 
 
-@pytest.mark.parametrize("M,C,tb", [(1000, 32, True), (4097, 64, False), (64, 64, True), (120000, 32, False)])
+@pytest.mark.parametrize("M,C,tb", [(1000, 32, True), (4097, 64, False), (64, 64, True), (120000, 32, False),
+                                    (70001, 64, True)])  # >= 64 k rows: the 128-row workgroups, ragged last tile
 def test_cpe_head_fused_equals_linear_ln_qkv_sequence(ops, M, C, tb):
     """cdseg_cpe_head_fused == cpe linear GEMM (LN_cpe + residual + t bias + LN1 in its epilogue) followed by the qkv
     GEMM, bit for bit (ptv3.py:401-414)."""

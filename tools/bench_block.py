@@ -25,3 +25,12 @@ for n, C in ((120000 * scenes, 32), (120000 * scenes, 64), (55818 * scenes, 64))
     t_old = time_op(lambda: ops.attn_tail_fused(o, wp, bp, g1, e1, w1, b1, w2, b2, x, xc), 10)
     t_new = time_op(lambda: ops.attn_tail_rr(o, timg, bp, g1, e1, b1, b2, x, xc), 10)
     print(f"tail n={n} C={C}: fused {t_old:.1f} us, register-resident {t_new:.1f} us ({tb / t_new:.2f} TB/s on {tb:.0f} MB)")
+
+# the C = 128 stage's MLP (weights too large for the register-resident tail: the 64 / 128-row tile kernel of mlp.hip)
+n, C = 14293 * scenes, 128
+r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+h, x, xc = r(n, C).to(bf), r(n, C), torch.empty(n, C, dtype=bf, device=dev)
+w1, w2, b1, b2 = (r(4 * C, C) / C ** 0.5).to(bf), (r(C, 4 * C) / (4 * C) ** 0.5).to(bf), r(4 * C), r(C)
+t = time_op(lambda: ops.mlp_fused(h, w1, b1, w2, b2, x, xc), 10)
+mb = n * (C * 2 + C * 8 + C * 2) / 1e6
+print(f"mlp n={n} C={C}: {t:.1f} us ({mb / t:.2f} TB/s on {mb:.0f} MB)")
