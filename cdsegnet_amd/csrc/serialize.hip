@@ -10,6 +10,10 @@
 //   .../point_transformer_v3m1_base.py:188-244                      get_padding_and_inverse
 //   .../point_transformer_v3m1_base.py:477-492                      pooling clusters
 #include "common.h"
+
+#ifndef CDSEG_MERGE_SORT_LIMIT
+#define CDSEG_MERGE_SORT_LIMIT 262144
+#endif
 #include "curves.h"
 
 #include <cstring>
@@ -471,10 +475,16 @@ int cdseg_encode4(const int32_t* grid, const int32_t* batch, long n, int depth, 
   return CDSEG_OK;
 }
 
+// rocPRIM's default switches to merge sort (block sort + ~13 merge passes at 864 k keys) up to 1 M items; these keys have
+// 30-40 significant bits, i.e. 4-5 Onesweep passes: merge sort only where it wins (a few block-sort tiles)
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
+                                              CDSEG_MERGE_SORT_LIMIT>;
+
 size_t cdseg_sort_ws_bytes(long n) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                            (int32_t*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0, false);
+  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                              (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 64u,
+                                              (hipStream_t)0, false);
   size_t scan_bytes = 0;
   (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n,
                           rocprim::plus<int32_t>(), (hipStream_t)0, false);
@@ -501,8 +511,8 @@ int cdseg_sort_pairs(const int64_t* keys_in, int64_t* keys_out, const int32_t* v
     off = (((size_t)n * sizeof(int32_t)) + 255) & ~(size_t)255;
   }
   size_t tmp_bytes = ws_bytes - off;
-  hipError_t e = rocprim::radix_sort_pairs(w + off, tmp_bytes, (const uint64_t*)keys_in, (uint64_t*)keys_out, vin,
-                                           vals_out, (size_t)n, 0u, (unsigned)end_bit, s, false);
+  hipError_t e = rocprim::radix_sort_pairs<SortConfig>(w + off, tmp_bytes, (const uint64_t*)keys_in, (uint64_t*)keys_out,
+                                                       vin, vals_out, (size_t)n, 0u, (unsigned)end_bit, s, false);
   if (e != hipSuccess) return CDSEG_ERR_LAUNCH;
   return CDSEG_OK;
 }
