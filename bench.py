@@ -12,11 +12,12 @@ A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-
 ~120k voxels each - sizes 103k..137k, mean 120k - 6-ch features, 20 classes, bf16), inputs already resident in HBM.
 Scenes are independent units: every rank runs its own scenes, no data-path collective ("scaling": "weak").  Every lane
 (HIP stream) gets one collated forward of 8 scenes (the reference's collate_fn batching), three forwards are in flight.
-`value` counts all points of all scenes; `single_scene_latency_ms` is the one-scene-at-a-time (bs = 1) latency.
+`value` counts all points of all scenes; `single_scene_latency_ms` is the one-scene-at-a-time (bs = 1) latency, the
+median of 9 synchronised calls.
 RCCL is used once to broadcast the weights from rank 0 and for the final timing / counter reductions.
 
-Prints ONE JSON line on rank 0.  `roofline` (window attention, the north-star kernel) and `roofline_conv` (the sparse
-convs, the largest share of kernel time) are timed with HIP events around every launch ON THE LAUNCH STREAM, in a pass
+Prints ONE JSON line on rank 0.  `roofline` (window attention, the north-star kernel) and `roofline_conv` (all k = 3 sparse
+convs of the forward) are timed with HIP events around every launch ON THE LAUNCH STREAM, in a pass
 right after the timed region that replays the timed configuration's own forward (the same 8 collated scenes) with
 nothing else on the GPU; `cpu_baseline` is the CPU oracle on the host cores.
 """
