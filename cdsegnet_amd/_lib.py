@@ -68,6 +68,8 @@ SIGNATURES = {
     "cdseg_encode4": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "cdseg_sort_ws_bytes": (c_size_t, [c_long]),
     "cdseg_sort_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_size_t, c_void_p]),
+    "cdseg_sort_curves_ws_bytes": (c_size_t, [c_long, c_int]),
+    "cdseg_sort_curves": (c_int, [c_void_p, POINTER(c_int), c_int, c_long, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cdseg_invert_perm": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
     "cdseg_widen_i32": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
     "cdseg_gather_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),

@@ -55,6 +55,8 @@ def _shared(cache, key, build):
     return ent[0]
 
 
+FUSED_CURVE_SORT = os.environ.get("CDSEG_SORT_CURVES", "1") != "0"  # A/B switch: one sort per curve instead
+
 class Level:
     """One voxel resolution of the scene, points in (batch | z) sorted order."""
 
@@ -432,6 +434,11 @@ class Engine:
             used = sorted({CURVES.index(o) for o in bb.order} - {0})
             if used:
                 lv0 = plan.levels[0]
+                # the level-0 orders of all curves in use with ONE sort (Onesweep's cost is mostly fixed)
+                if end_bit + 2 <= 64 and FUSED_CURVE_SORT and not all(c in lv0._order for c in used):
+                    srt = ops.sort_curves(code0, used, end_bit)
+                    for k, c in enumerate(used):
+                        lv0._order[c] = (srt[k], ops.current_stream_id(), None)
                 derived = ops.coarse_orders([t[0] for t in tmp], [lv0.order(c) for c in used], host[:len(coarse)])
                 for i, cum in enumerate(coarse):
                     for k, c in enumerate(used):

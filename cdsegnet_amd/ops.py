@@ -219,6 +219,22 @@ def sort_pairs(keys, vals=None, end_bit=64):
     return keys_out, vals_out
 
 
+def sort_curves(code4, rows, end_bit):
+    """Orders (rank -> row, int32) of the curve rows ``rows`` of code4 (4, n) with ONE radix sort (the curve slot rides in
+    the key bits above end_bit): returns a (len(rows), n) int32 tensor, row k = argsort of code4[rows[k]]."""
+    _need_gpu(code4)
+    lib = _lib.load()
+    n, count = code4.shape[1], len(rows)
+    orders = torch.empty((count, n), dtype=torch.int32, device=code4.device)
+    if n == 0 or count == 0:
+        return orders
+    ws = workspace(lib.cdseg_sort_curves_ws_bytes(n, count), code4.device)
+    arr = (ctypes.c_int * count)(*[int(r) for r in rows])
+    check(lib.cdseg_sort_curves(_ptr(code4), arr, count, n, int(end_bit), _ptr(orders), _ptr(ws), ws.numel(), _stream()),
+          "sort_curves")
+    return orders
+
+
 def invert_perm(perm):
     _need_gpu(perm)
     inv = torch.empty_like(perm)

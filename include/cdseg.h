@@ -71,6 +71,12 @@ int cdseg_encode4(const int32_t* grid, const int32_t* batch, long n, int depth, 
 size_t cdseg_sort_ws_bytes(long n);
 int cdseg_sort_pairs(const int64_t* keys_in, int64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, long n,
                      int end_bit, void* ws, size_t ws_bytes, void* stream);
+/* Orders of `count` (<= 4) curves of the same n points with ONE sort: codes (4, n) int64 (row r = curve r), rows[count] =
+ * the curve rows wanted (host array), orders (count, n) int32 out (= count argsorts, ref: structure.py:83).  The curve
+ * slot rides in the key bits above end_bit (end_bit + 2 <= 64).  ws from cdseg_sort_curves_ws_bytes(n, count). */
+size_t cdseg_sort_curves_ws_bytes(long n, int count);
+int cdseg_sort_curves(const int64_t* codes, const int* rows, int count, long n, int end_bit, int32_t* orders, void* ws,
+                      size_t ws_bytes, void* stream);
 /* inv[perm[i]] = i.  ref: structure.py:84-90 (scatter_ of arange) */
 int cdseg_invert_perm(const int32_t* perm, long n, int32_t* inv, void* stream);
 int cdseg_widen_i32(const int32_t* src, long n, int64_t* dst, void* stream);

@@ -37,6 +37,11 @@ def sort_pairs(keys, vals=None, end_bit=64):
     return ks, v
 
 
+def sort_curves(code4, rows, end_bit):
+    return torch.stack([torch.sort(code4[r], stable=True)[1].int() for r in rows]) if len(rows) else \
+        torch.empty((0, code4.shape[1]), dtype=torch.int32)
+
+
 def invert_perm(perm):
     inv = torch.empty_like(perm)
     inv[perm.long()] = torch.arange(len(perm), dtype=perm.dtype)

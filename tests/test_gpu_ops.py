@@ -839,6 +839,22 @@ def test_attention_bf16_loose_score_bound_falls_back_to_exact_max(ops):
 
 
 @pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000", "rand16", "lidar8", "tiny64"])
+def test_sort_curves_equals_one_sort_per_curve(ops, name):
+    """cdseg_sort_curves (all curve orders of a level with one radix sort, the curve slot in the key bits above end_bit)
+    == cdseg_sort_pairs per curve; also a subset / permutation of the rows."""
+    fx = load_fixture(f"serialization_{name}.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    code4 = ops.encode4(g0, b0, depth)
+    nb = int(b0.max().item()) + 1
+    end_bit = 3 * depth + max(1, nb.bit_length())
+    for rows in ([1, 2, 3], [3, 1], [2], [0, 1, 2, 3]):
+        got = ops.sort_curves(code4, rows, end_bit)
+        for k, r in enumerate(rows):
+            want = ops.sort_pairs(code4[r].contiguous(), None, end_bit=end_bit)[1]
+            assert torch.equal(got[k], want), (rows, r)
+
+
+@pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000", "rand16", "lidar8", "tiny64"])
 def test_kernel_map_from_parent_equals_search(ops, name):
     """cdseg_nbr_table_from_parent (parent level's 3x3x3 map + children runs) and cdseg_nbr_table_from_info (the same with
     the parents' child_info words: first child + popcount of the occupancy) == cdseg_nbr_table (binary search)."""
