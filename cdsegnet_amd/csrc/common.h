@@ -77,4 +77,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B from per-lane global addresses to the lane-linear LDS range
+// [lds_dst, lds_dst + 1024).  Issued from inline asm with M0 (the LDS base) written in the same statement: hipcc drains
+// vmcnt(0) around compiler-visible LDS-DMA.  The compiler does not count it: wait with an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

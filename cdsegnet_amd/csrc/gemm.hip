@@ -602,14 +602,6 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
 //     hipcc drains vmcnt(0) around compiler-visible LDS-DMA, and no other VMEM instruction lives in the loop.
 __device__ uint4 g_zero_page[8];  // 128 zero bytes: the source of a missing neighbour's row chunk
 
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
 template <int BM>
 struct DmaCfg {
   static constexpr int WAVES = BM / 16, NT = WAVES * 64, BN = 128, BK = 64;

@@ -62,6 +62,12 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters, flo
       MFMA(acc1); EXP(5); EXP(6); EXP(7); EXP(8); EXP(9); PERM(2); PERM(3); PERM(4);
       MFMA(acc2); EXP(10); EXP(11); EXP(12); EXP(13); EXP(14); EXP(15); PERM(5); PERM(6); PERM(7);
     }
+    if (KIND == 19) {  // the round-3 tile: RNE packs (v_cvt_pk_bf16_f32) instead of the truncating v_perm
+#define CVTP(i) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[i]) : "v"(e[2 * (i)]), "v"(e[2 * (i) + 1]))
+      MFMA(acc0); EXP(0); EXP(1); EXP(2); EXP(3); EXP(4); CVTP(0); CVTP(1);
+      MFMA(acc1); EXP(5); EXP(6); EXP(7); EXP(8); EXP(9); CVTP(2); CVTP(3); CVTP(4);
+      MFMA(acc2); EXP(10); EXP(11); EXP(12); EXP(13); EXP(14); EXP(15); CVTP(5); CVTP(6); CVTP(7);
+    }
     if (KIND == 7) {  // 10 exps on the transcendental unit, 6 scores by a 7-op polynomial on the plain VALU
 #define P7(i) FMA(i); FMA((i + 1) & 15); FMA((i + 2) & 15); FMA((i + 3) & 15); FMA((i + 4) & 15); FMA((i + 5) & 15); FMA((i + 6) & 15)
       MFMA(acc0); EXP(0); P7(0); EXP(1); P7(1); EXP(2); EXP(3); PERM(0); PERM(1);
@@ -138,7 +144,10 @@ void run(const char* name) {
   printf("%-46s", name);
   for (int W : {1, 2, 4}) {
     const int blocks = 256 * W;
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 64, 1.0f);
+    // warm-up with the full iteration count: a short first launch leaves the chip on its idle clock and the timed
+    // launch then ramps up while it runs (round 2's ns columns of the first rows were taken at ~1.1 GHz)
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
@@ -152,16 +161,18 @@ void run(const char* name) {
     double mean = 0;
     for (auto v : h) mean += (double)v;
     mean /= h.size();
-    // s_memtime counts at a fixed 100 MHz on gfx9: report wall ns per iteration per SIMD as well
-    printf("  W=%d: %8.1f ticks/iter/wave, %7.2f ns/iter/SIMD", W, mean / iters, ms * 1e6 / iters / 1.0 / 1.0 / 1.0 * 1.0 / 1.0);
+    // ticks = shader cycles (s_memtime); a SIMD runs its W waves concurrently, so cycles per iteration and SIMD
+    // = ticks / W; the clock the chip held = cycles / wall time
+    const double cyc = mean / iters / W, ns = ms * 1e6 / iters / W;
+    printf("  W=%d: %6.1f cyc/iter/SIMD %6.2f ns (%4.2f GHz)", W, cyc, ns, cyc / ns);
   }
   printf("\n");
   hipFree(d);
 }
 
 int main() {
-  printf("ns/iter/SIMD = kernel wall time / iterations (every SIMD runs W waves of `iters` iterations concurrently);\n"
-         "divide by W for the per-wave-iteration throughput cost, multiply by the clock (GHz) for cycles\n");
+  printf("every SIMD of the chip runs W waves of the same loop; cyc/iter/SIMD = mean wave cycles per iteration / W\n"
+         "(throughput cost of one iteration on one SIMD), ns = kernel wall time / iterations / W, GHz = their ratio\n");
   run<0>("16 exp");
   run<1>("16 fma");
   run<2>("16 exp + 16 fma");
@@ -177,7 +188,8 @@ int main() {
   run<4>("3 mfma32x32x16");
   run<14>("1 mfma32 + 4 mfma16x16x32");
   run<5>("3 mfma + 16 exp");
-  run<6>("3 mfma + 16 exp + 8 perm (today's tile)");
+  run<6>("3 mfma + 16 exp + 8 perm (round-2 tile)");
+  run<19>("3 mfma + 16 exp + 8 cvt_pk (round-3 tile)");
   run<8>("3 mfma + 64 fma");
   run<7>("3 mfma + 10 exp + 42 fma + 8 perm (hybrid)");
   run<10>("3 mfma + 8 exp + 56 fma + 8 perm (hybrid)");
