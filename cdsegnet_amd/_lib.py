@@ -136,7 +136,6 @@ SIGNATURES = {
                                 c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "cdseg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p]),
-    "cdseg_attention_status": (c_int, []),
     "cdseg_prof_enable": (c_int, [c_int]),
     "cdseg_prof_summary": (c_int, [POINTER(ctypes.c_double), POINTER(c_long)]),
     "cdseg_prof_summary_class": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_long)]),

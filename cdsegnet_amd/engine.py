@@ -159,10 +159,10 @@ class State:
 
 class Engine:
     def __init__(self, model, precision="bf16"):
-        if precision not in ("bf16", "fp32"):
+        if precision not in ("bf16", "bf16+head", "fp32"):
             raise ValueError(precision)
         self.model, self.precision = model, precision
-        self.T = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.T = torch.float32 if precision == "fp32" else torch.bfloat16
         self.device = None
         self.w = None
         self.rng_offset = 0
@@ -181,6 +181,11 @@ class Engine:
         # (27 x int32 per point), the weights once per launch
         self.conv_bytes = 0.0
         self.attn_bytes = 0.0  # algorithmic attention bytes: q, k, v read once + o written once per launch
+        # stages of a bf16 forward that run through the exact-fp32 twin engine instead (keys: n_emb, c_emb, n_enc0..4,
+        # c_enc0..2, x, n_dec3..0, c_dec1..0, n_head, c_head).  The error budget of the bf16 mode is measured with it
+        # (tools/bf16_budget.py); precision "bf16+head" is hi = {"n_head"}.
+        self.hi = frozenset(("n_head", "c_head")) if precision == "bf16+head" else frozenset()
+        self._twin = None
 
     # ------------------------------------------------------------------ weights
     def prepare(self, device):
@@ -352,6 +357,24 @@ class Engine:
                                                            mod.attn.scale, 1e-5, t)
         self._scratch = {}
         self._scratch_bytes = {}
+
+    def _eng(self, key):
+        """The engine that runs stage `key`: this one, or its exact-fp32 twin for the stages named in self.hi."""
+        if key not in self.hi or self.T == torch.float32:
+            return self
+        if self._twin is None:
+            self._twin = Engine(self.model, "fp32")
+            self._twin.use_native_blocks = self.use_native_blocks
+        self._twin.prepare(self.device)
+        return self._twin
+
+    def _fit(self, st, exact=False):
+        """Bring a State's shadow copy to this engine's dtype (stages of different precision meet here).  exact: the
+        shadow is a plain rounding of the fp32 residual stream (true behind a Block), so an fp32 stage reads the
+        stream itself."""
+        if st is not None and st.xc.dtype != self.T:
+            st.xc = st.x if (exact and self.T == torch.float32) else st.xc.to(self.T)
+        return st
 
     def scratch(self, nbytes):
         key = ops.current_stream_id()  # one scratch arena per stream (the two branches run concurrently)
@@ -912,21 +935,26 @@ class Engine:
 
         def enc_stage(st, branch, s, cum, perm):
             enc = getattr(getattr(bb, f"_{branch}_enc"), f"enc{s}")
+            e = self._eng(f"{branch}_enc{s}")
+            e._fit(st)
             if s > 0:
-                st = self.run_pooling(plan, st, f"{branch}_enc{s}.down", cum[s], perm)
+                st = e.run_pooling(plan, st, f"{branch}_enc{s}.down", cum[s], perm)
             for name, mod in enc._modules.items():
                 if name.startswith("block"):
                     key = f"{branch}_enc{s}.{name}"
-                    self.run_block(st, mod, key, tb.get(key))
+                    e.run_block(st, mod, key, tb.get(key))
             return st
 
         def dec_stage(st, branch, s):
             dec = getattr(getattr(bb, f"_{branch}_dec"), f"dec{s}")
-            st = self.run_unpooling(plan, st, f"{branch}_dec{s}.up", dec.up)
+            e = self._eng(f"{branch}_dec{s}")
+            e._fit(st)
+            e._fit(st.parent)  # the skip feature saved by the encoder
+            st = e.run_unpooling(plan, st, f"{branch}_dec{s}.up", dec.up)
             for name, mod in dec._modules.items():
                 if name.startswith("block"):
                     key = f"{branch}_dec{s}.{name}"
-                    self.run_block(st, mod, key, tb.get(key))
+                    e.run_block(st, mod, key, tb.get(key))
             return st
 
         # ref: ptv3.py:1781-1794.  The reference interleaves the two encoders (c0 n0 c1 n1 n2 c2 n3 n4); that order
@@ -940,7 +968,7 @@ class Engine:
             n_perms = [None, p_n1, p_n2, p_n3, p_n4]
 
             def c_branch():
-                st = self.run_embedding(plan, c_feat, c_perm, "c_emb", c_curves)
+                st = self._eng("c_emb").run_embedding(plan, c_feat, c_perm, "c_emb", c_curves)
                 st = enc_stage(st, "c", 0, c_cum, None)
                 st = enc_stage(st, "c", 1, c_cum, p_c1)
                 return enc_stage(st, "c", 2, c_cum, p_c2)
@@ -948,7 +976,7 @@ class Engine:
             fork = self.fork_stage if (dev.type == "cuda" and self.fork_stage is not None) else None
             SHARE_EVENTS.on = fork is not None
             cst = c_branch() if fork is None else None
-            nst = self.run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
+            nst = self._eng("n_emb").run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
             join = None
             for s in range(bb.n_num_stages):
                 if fork is not None and s == fork:
@@ -956,9 +984,12 @@ class Engine:
                 nst = enc_stage(nst, "n", s, n_cum, n_perms[s])
             if join is not None:
                 ops.wait_event(join)
-            self.run_cross_block(nst, cst)
+            e = self._eng("x")
+            e._fit(nst)
+            e._fit(cst)
+            e.run_cross_block(nst, cst)
         else:
-            nst = self.run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
+            nst = self._eng("n_emb").run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
             for s in range(bb.n_num_stages):
                 nst = enc_stage(nst, "n", s, n_cum, next(pi) if s > 0 else None)
         self.trace = {"n_bottleneck": nst.x}
@@ -967,14 +998,18 @@ class Engine:
         if cond and want_c:
             for s in reversed(range(bb.c_num_stages - 1)):
                 cst = dec_stage(cst, "c", s)
+            e = self._eng("c_head")
+            e._fit(cst, exact=True)
             c_out = torch.empty((n, w["c_head.w"].shape[0]), dtype=torch.float32, device=dev)
-            ops.gemm(cst.xc, w["c_head.w"], c_out, bias=w["c_head.b"])
+            ops.gemm(cst.xc, e.w["c_head.w"], c_out, bias=e.w["c_head.b"])
         for s in reversed(range(bb.n_num_stages - 1)):
             nst = dec_stage(nst, "n", s)
         # head, scattered back to the caller's point order (ref: ptv3.py:1813)
         if "n_head.w" in w:
+            e = self._eng("n_head")
+            e._fit(nst, exact=True)
             logits = torch.empty((n, w["n_head.w"].shape[0]), dtype=torch.float32, device=dev)
-            ops.gemm(nst.xc, w["n_head.w"], logits, bias=w["n_head.b"], out_idx=plan.perm0)
+            ops.gemm(nst.xc, e.w["n_head.w"], logits, bias=e.w["n_head.b"], out_idx=plan.perm0)
         else:
             logits = torch.empty((n, nst.x.shape[1]), dtype=torch.float32, device=dev)
             ops.scatter_rows(nst.x, plan.perm0, logits)

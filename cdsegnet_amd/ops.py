@@ -682,11 +682,6 @@ def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=Non
     return out
 
 
-def attention_status():
-    """Raise if any attention launch so far gave up waiting inside the kernel (device sync; tests / benchmarks)."""
-    check(_lib.load().cdseg_attention_status(), "attention (a wave gave up waiting for a K/V stage)")
-
-
 def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out, work=0.0):
     """q/k/v: 2-D views (rows, H*16) of the projection buffers (any row stride); out (rows, H*16).
     work: algorithmic FLOPs of this launch (4 * 16 * H * sum_p L_p^2), only used by the bench timer."""

@@ -214,10 +214,6 @@ int cdseg_layernorm(const void* x, int x_dtype, int ldx, const float* gamma, con
 int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const int32_t* q_gidx,
                     const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
                     int num_heads, int max_len, float scale, void* out, int ldo, int dtype, void* stream);
-/* The persistent bf16 form hands K/V stages between the waves of a workgroup through LDS flags; a wave that waited
- * ~1 s for a flag gives up (the launch ends with wrong rows instead of hanging) and records it on the device.
- * Returns CDSEG_OK if no launch so far did; synchronises the device.  Tests and benchmarks call it after their runs. */
-int cdseg_attention_status(void);
 
 /* HIP-event timing of the attention launches on their own stream (bench.py's live roofline measurement):
  * enable(1) starts recording, summary() (after a device sync) returns the summed durations. */

@@ -62,8 +62,6 @@ for _ in range(rounds):
     for _ in range(iters): run()
     e1.record(); torch.cuda.synchronize()
     us.append(1e3 * e0.elapsed_time(e1) / iters)
-if hasattr(ops, "attention_status"):
-    ops.attention_status()
 us.sort()
 med, mn = us[len(us) // 2], us[0]
 tag = os.path.basename(os.environ.get("CDSEG_AB_LIB", "libcdseg_hip.so"))
