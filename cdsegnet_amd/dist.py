@@ -37,14 +37,27 @@ def shard_scenes(sizes, rank=None, world=None):
     return mine
 
 
+def engine_casts(name, t):
+    """True for the state_dict tensors Engine.prepare converts to the compute dtype as they are (engine.py: lin / conv /
+    stem / pool / unpool).  Not: 1-D tensors (biases, norms: fp32), the timestep MLPs (``fc_t1/2``, ``t_mlp``: fp32
+    GEMVs), the heads (fp32 in precision 'bf16+head'), ``proj_cat`` (multiplied by the skip factor before its cast)."""
+    if t.dim() < 2:
+        return False
+    return not (".t_mlp." in name or ".fc_t1." in name or ".fc_t2." in name or name.startswith(("fc_t1.", "fc_t2.")) or
+                ".proj_cat." in name or "_head." in name)
+
+
 def broadcast_model(model, src=0, weight_dtype=None):
     """Broadcast every state_dict entry (parameters + BatchNorm buffers) from `src`: ONE flat buffer per storage
     class, so the whole model is two or three collectives.
 
     * floating tensors travel as float32 (exact) - except, when ``weight_dtype`` is given (the engine's compute
-      dtype, e.g. torch.bfloat16), the >= 2-D weights (Linear / sparse-conv kernels: the tensors the engine converts
-      to that dtype anyway, 99.8 % of the bytes): 203 MB instead of 405 MB for the full model.  Every rank,
-      INCLUDING src, then holds the rounded weights, so the replicas stay bit-identical;
+      dtype, e.g. torch.bfloat16), the weights the engine casts to that dtype UNCHANGED (``engine_casts``: the Linear /
+      sparse-conv kernels of the Blocks, stems, poolings and un-poolings - 99 % of the bytes): 203 MB instead of
+      405 MB for the full model.  Rounding those before the broadcast is what Engine.prepare does to them anyway, so an
+      N-GPU run computes the same logits as the 1-GPU run of the same checkpoint.  The tensors the engine keeps in
+      fp32 (timestep MLPs, logit heads) or transforms before its cast (``proj_cat``, scaled by the skip factor first)
+      travel exact.  Every rank, INCLUDING src, then holds the same values;
     * integer buffers (``num_batches_tracked`` int64) travel in their own dtype.
     """
     if not is_dist():
@@ -55,16 +68,16 @@ def broadcast_model(model, src=0, weight_dtype=None):
         return model
     dev = tensors[0].device
 
-    def klass(t):
+    def klass(name, t):
         if not t.is_floating_point():
             return t.dtype
-        if weight_dtype is not None and t.dim() >= 2:
+        if weight_dtype is not None and engine_casts(name, t):
             return weight_dtype
         return torch.float32
 
     groups = {}
-    for t in tensors:
-        groups.setdefault(klass(t), []).append(t)
+    for name, t in sd.items():
+        groups.setdefault(klass(name, t), []).append(t)
     with torch.no_grad():
         for dt_, ts in groups.items():
             flat = torch.cat([t.detach().reshape(-1).to(dt_) for t in ts]).to(dev)

@@ -737,6 +737,66 @@ class Engine:
                      res=nst.x)
         self._mlp(nst, "x.q_norm2", "x.fc")
 
+    # ------------------------------------------------------------------ accounting
+    def forward_work(self, plan):
+        """Algorithmic FLOPs (2 x multiply-add) of ONE single-step forward on `plan`, by kernel class - SURVEY.md 8(d)'s
+        formulas on the plan's real sizes: sparse convs count the OCCUPIED neighbours only, attention 4 * L^2 * 16 per
+        patch-head, the dead c-decoder is not counted.  Synchronises (reads the kernel maps' occupancy): for reports."""
+        bb, w = self.model.backbone, self.w
+        cache = {}
+
+        def occ(lv, k):
+            if (lv.cum, k) not in cache:
+                cache[(lv.cum, k)] = float((lv.nbr(k, True) >= 0).sum().item())
+            return cache[(lv.cum, k)]
+
+        out = dict(conv=0.0, linear=0.0, attention=0.0, stem=0.0, pool_unpool=0.0, head=0.0)
+
+        def block(mod, pre, lv):
+            c, hid = mod.channels, w[pre + ".fc1.w"].shape[0]
+            out["conv"] += 2.0 * occ(lv, 3) * c * c
+            out["linear"] += 2.0 * lv.n * (5.0 * c * c + 2.0 * c * hid)
+            out["attention"] += 64.0 * mod.attn.num_heads * lv.pad(mod.attn.patch_size, mod.attn.enable_flash)[6]
+
+        def stages(branch, cum, n_stages):
+            for s in range(n_stages):
+                lv = plan.levels[cum[s]]
+                enc = getattr(getattr(bb, f"_{branch}_enc"), f"enc{s}")
+                if s > 0:
+                    pw = w[f"{branch}_enc{s}.down.proj.w"]
+                    out["pool_unpool"] += 2.0 * plan.levels[cum[s - 1]].n * pw.shape[0] * pw.shape[1]
+                for name, mod in enc._modules.items():
+                    if name.startswith("block"):
+                        block(mod, f"{branch}_enc{s}.{name}", lv)
+
+        lv0 = plan.levels[0]
+        stem_in = w["n_emb.w"].shape[1] // 125
+        out["stem"] += 2.0 * occ(lv0, 5) * min(stem_in, bb._n_embedding.stem.conv.in_channels) * w["n_emb.w"].shape[0]
+        stages("n", plan.n_cum, bb.n_num_stages)
+        if bb.condition:
+            out["stem"] += 2.0 * occ(lv0, 5) * bb._c_embedding.stem.conv.in_channels * w["c_emb.w"].shape[0]
+            stages("c", plan.c_cum, bb.c_num_stages)
+            cb = bb._tm_dec0.cross_block2
+            lq, lc = plan.levels[plan.n_cum[-1]], plan.levels[plan.c_cum[-1]]
+            cq, ck = cb.q_channels, cb.kv_channels
+            out["conv"] += 2.0 * occ(lq, 3) * cq * cq + 2.0 * occ(lc, 3) * ck * ck
+            out["linear"] += 2.0 * lq.n * (cq * cq * 3 + 2.0 * cq * w["x.fc1.w"].shape[0]) + 2.0 * lc.n * (ck * ck + ck * 2 * cq)
+            out["attention"] += 64.0 * cb.attn.num_heads * lq.pad(cb.attn.q_patch_size, cb.attn.enable_flash)[6]
+        for s in reversed(range(bb.n_num_stages - 1)):
+            lf, lc = plan.levels[plan.n_cum[s]], plan.levels[plan.n_cum[s + 1]]
+            pre = f"n_dec{s}.up"
+            out["pool_unpool"] += 2.0 * lc.n * w[pre + ".proj.w"].numel() + 2.0 * lf.n * w[pre + ".skip.w"].numel()
+            if (pre + ".cat_a.w") in w:
+                out["pool_unpool"] += 2.0 * lc.n * w[pre + ".cat_b.w"].numel() + 2.0 * lf.n * w[pre + ".cat_a.w"].numel()
+            dec = getattr(bb._n_dec, f"dec{s}")
+            for name, mod in dec._modules.items():
+                if name.startswith("block"):
+                    block(mod, f"n_dec{s}.{name}", lf)
+        if "n_head.w" in w:
+            out["head"] += 2.0 * lv0.n * w["n_head.w"].numel()
+        out["total"] = sum(out.values())
+        return out
+
     # ------------------------------------------------------------------ randomness
     def draw(self, n, feat_shape, c_ch, noise_level, n_perms, always_noise=False):
         """The reference's CPU-generator consumption order (SURVEY.md finding 3)."""

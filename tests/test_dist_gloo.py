@@ -101,3 +101,50 @@ def test_two_ranks_gloo(tmp_path):
                 assert np.array_equal(out, r[f"logits{int(i)}"])
     finally:
         engine_mod.ops = old
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cdsegnet_amd.models  # noqa: F401
+        from cdsegnet_amd import configs
+        from cdsegnet_amd.param_init import fill_state_dict
+        from cdsegnet_amd.registry import build_model
+        model = build_model(configs.mini_config()).eval()
+        if rank == 0:
+            model.load_state_dict(fill_state_dict(model.state_dict(), seed=3))
+        ref = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+        cdist.broadcast_model(model, src=0, weight_dtype=torch.bfloat16)
+        sd = model.state_dict()
+        torch.save({k: v.clone() for k, v in sd.items()}, os.path.join(out_dir, f"sd{rank}.pt"))
+        if rank == 0:
+            torch.save(ref, os.path.join(out_dir, "ref.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_low_precision_broadcast_rounds_only_what_the_engine_casts(tmp_path):
+    """ADVICE r2: a bf16 broadcast must round exactly the tensors Engine.prepare casts to the compute dtype unchanged;
+    the timestep MLPs, the heads and proj_cat (scaled before its cast) travel exact, so an N-GPU run computes the
+    1-GPU run's logits."""
+    port = _free_port()
+    mp.spawn(_bcast_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sd0, sd1, ref = (torch.load(tmp_path / f, weights_only=True) for f in ("sd0.pt", "sd1.pt", "ref.pt"))
+    rounded = exact = 0
+    for k, v in ref.items():
+        assert torch.equal(sd0[k], sd1[k]), k  # replicas identical, src included
+        if v.is_floating_point() and cdist.engine_casts(k, v):
+            assert torch.equal(sd0[k], v.to(torch.bfloat16).to(v.dtype)), k
+            rounded += 1
+        else:
+            assert torch.equal(sd0[k], v), k
+            exact += 1
+    assert rounded > 20 and exact > 20
+    names = list(ref)
+    for frag in (".t_mlp.weight", "fc_t1.weight", "fc_t2.weight", "_n_head.weight", "_c_head.weight", ".proj_cat.0.weight"):
+        hit = [k for k in names if k.endswith(frag) or frag in k]
+        assert hit and not any(cdist.engine_casts(k, ref[k]) for k in hit), frag
+    for frag in (".attn.qkv.weight", ".cpe.0.weight", ".mlp.0.fc1.weight", ".stem.conv.weight", ".down.proj.weight"):
+        hit = [k for k in names if k.endswith(frag)]
+        assert hit and all(cdist.engine_casts(k, ref[k]) for k in hit), frag

@@ -603,3 +603,49 @@ def test_degenerate_scenes_vs_oracle(kind, flash):
     model.precision = "bf16"
     o16 = run(model, inp, draws)
     assert np.isfinite(o16).all() and np.abs(o16 - ref).max() < 0.06
+
+
+def test_mixed_precision_stages_and_fp32_head():
+    """Engine.hi (round 3): a bf16 forward with EVERY stage routed through the exact-fp32 twin engine is the fp32
+    forward bit for bit; precision 'bf16+head' (the benchmarked default: logit head in fp32 on the fp32 residual stream)
+    stays within the bf16 bounds of the reference golden and differs from pure bf16 only by the head's rounding."""
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = fixture_cfg(fx), fixture_state_dict(fx)
+    ref = run(build(cfg, sd, "fp32", enable_flash=False), fixture_input(fx), fixture_draws(fx))
+    model = build(cfg, sd, "bf16", enable_flash=False)
+    model.engine().hi = frozenset(["n_emb", "c_emb", "x", "n_head", "c_head"] + [f"n_enc{s}" for s in range(5)] +
+                                  [f"c_enc{s}" for s in range(3)] + [f"n_dec{s}" for s in range(4)])
+    allhi = run(model, fixture_input(fx), fixture_draws(fx))
+    assert np.array_equal(allhi, ref)
+    pure = run(build(cfg, sd, "bf16", enable_flash=False), fixture_input(fx), fixture_draws(fx))
+    head = run(build(cfg, sd, "bf16+head", enable_flash=False), fixture_input(fx), fixture_draws(fx))
+    e_pure, _ = report("bf16 vs reference", pure, fx["logits"])
+    e_head, a_head = report("bf16+head vs reference", head, fx["logits"])
+    assert e_head < 0.04 and a_head > 0.985
+    assert float(np.abs(head - pure).max()) < 0.02  # one bf16 rounding of a 16..64-wide feature row times the head weights
+    # a single fp32 stage in the middle of a bf16 forward (dtype hand-over in both directions, skip features included)
+    model = build(cfg, sd, "bf16", enable_flash=False)
+    model.engine().hi = frozenset(["n_enc2", "n_dec1"])
+    mid = run(model, fixture_input(fx), fixture_draws(fx))
+    e_mid, a_mid = report("bf16 with n_enc2 + n_dec1 in fp32 vs reference", mid, fx["logits"])
+    assert e_mid < 0.04 and a_mid > 0.985
+
+
+def test_forward_work_accounting():
+    """Engine.forward_work: the algorithmic FLOP count of the bench line (SURVEY 8(d) formulas on the plan's sizes)."""
+    cfg = configs.cdsegnet_config("scannet")
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0), strict=True)
+    model = model.cuda().eval()
+    sc = synth.room_scene(0, 20000)
+    inp = {k: sc[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    model.inference(to_dev(inp), eval=False)
+    eng = model.engine()
+    wk = eng.forward_work(eng.last_plan)
+    n = len(sc["coord"])
+    per_point = wk["total"] / n / 1e6
+    print(f"[measure] forward_work at {n} points: {per_point:.2f} MFLOP/point, by class "
+          f"{ {k: round(v / 1e9, 2) for k, v in wk.items()} } GFLOP")
+    assert 2.0 < per_point < 8.0  # SURVEY 8(d): 5.1 MFLOP/point at 120k (attention share grows with the patch fill)
+    assert all(v > 0 for v in wk.values())
+    assert abs(wk["total"] - sum(v for k, v in wk.items() if k != "total")) < 1e-3 * wk["total"]
