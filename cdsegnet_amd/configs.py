@@ -90,7 +90,10 @@ def cdsegnet_config(dataset="scannet"):
     if dataset == "scannet":
         pass
     elif dataset == "scannet200":
+        # configs/scannet200/CDSegNet.py: 200 classes and - unlike scannet - a linear schedule 0.001 .. 0.005 (found by
+        # running the reference's own config files: tests/golden/variant_schemas.json)
         m["num_classes"] = b["num_classes"] = 200
+        m["beta_start"], m["beta_end"], m["noise_schedule"] = 0.001, 0.005, "linear"
     elif dataset == "nuscenes":
         # configs/nuscenes/CDSegNet.py:25-30,42
         m["num_classes"] = b["num_classes"] = 16
@@ -107,7 +110,8 @@ def model_config(dataset="scannet", variant="CDSegNet"):
     """``model`` dict of configs/<dataset>/<variant>.py for the four model variants the reference ships
     (criteria dropped).  Differences to CDSegNet.py (diffed from the reference's config files):
 
-      PTv3_CNF  n_enc_depths (2,2,2,6,2); linear schedule (scannet 1e-4..5e-4, nuscenes 2e-3..3e-3)
+      PTv3_CNF  n_enc_depths (2,2,2,6,2); linear schedule (scannet 1e-4..5e-4, nuscenes 2e-3..3e-3, scannet200 keeps
+                its 1e-3..5e-3)
       PTv3      condition=False, dm=False, skip_connection_mode="add", n_enc_depths (2,2,2,6,2)
       Baseline  dm=False (the c-branch sees the input itself at t = 0)
     """
@@ -122,7 +126,8 @@ def model_config(dataset="scannet", variant="CDSegNet"):
         raise KeyError(variant)
     b["n_enc_depths"] = (2, 2, 2, 6, 2)  # configs/scannet/PTv3_CNF.py:75
     m["noise_schedule"] = "linear"
-    m["beta_start"], m["beta_end"] = (0.002, 0.003) if dataset == "nuscenes" else (0.0001, 0.0005)
+    if dataset != "scannet200":
+        m["beta_start"], m["beta_end"] = (0.002, 0.003) if dataset == "nuscenes" else (0.0001, 0.0005)
     if variant == "PTv3":  # configs/scannet/PTv3.py:17-18,33,46
         m["condition"] = b["condition"] = False
         m["dm"] = False

@@ -465,11 +465,57 @@ def gen_iou(ref):
     print("iou fixture", {k: v.shape for k, v in fx.items() if k.endswith("inter")})
 
 
+def gen_variants(ref):
+    """Full-width model variants straight from the reference's OWN config files (configs/<dataset>/<variant>.py run with
+    runpy): constructor hyper-parameters the inference path reads, state_dict schema (keys + shapes, hashed) and
+    parameter count of the reference model built from them -> tests/golden/variant_schemas.json.  Pins
+    cdsegnet_amd.configs.model_config (our restatement of those files) - VERDICT r2 missing #5."""
+    import hashlib
+    import runpy
+    keep_m = ("num_classes", "T", "beta_start", "beta_end", "noise_schedule", "T_dim", "dm", "dm_input", "dm_target",
+              "condition", "c_in_channels", "loss_type", "task_num")
+    keep_b = ("c_in_channels", "n_in_channels", "order", "c_stride", "c_enc_depths", "c_enc_channels", "c_enc_num_head",
+              "c_enc_patch_size", "c_dec_depths", "c_dec_channels", "c_dec_num_head", "c_dec_patch_size", "n_stride",
+              "n_enc_depths", "n_enc_channels", "n_enc_num_head", "n_enc_patch_size", "n_dec_depths", "n_dec_channels",
+              "n_dec_num_head", "n_dec_patch_size", "mlp_ratio", "qkv_bias", "shuffle_orders", "pre_norm", "num_classes",
+              "T_dim", "tm_feat", "condition", "skip_connection_mode", "skip_connection_scale", "skip_connection_scale_i")
+    out = {}
+    if "pointcept.datasets" not in sys.modules:  # the scannet200 configs import class-name constants from below it;
+        m_ = types.ModuleType("pointcept.datasets")  # its __init__ pulls in every dataset reader
+        m_.__path__ = [os.path.join(REF, "pointcept", "datasets")]
+        sys.modules["pointcept.datasets"] = m_
+    for ds in ("scannet", "scannet200", "nuscenes"):
+        for variant in ("CDSegNet", "PTv3_CNF", "PTv3", "Baseline"):
+            path = os.path.join(REF, "configs", ds, variant + ".py")
+            cwd = os.getcwd()
+            os.chdir(REF)  # _base_ includes are relative
+            try:
+                ns = runpy.run_path(path)
+            finally:
+                os.chdir(cwd)
+            m = json.loads(json.dumps(ns["model"], default=str))
+            b = m["backbone"]
+            cfg = dict(m)
+            cfg.pop("type")
+            cfg["criteria"] = None
+            cfg["backbone"] = dict(b, enable_flash=False, order=tuple(b["order"]))
+            model = ref.default.DefaultSegmentorV2(**cfg)
+            sd = model.state_dict()
+            schema = json.dumps([[k, list(v.shape)] for k, v in sd.items()])
+            out[f"{ds}/{variant}"] = dict(
+                model={k: m.get(k) for k in keep_m if k in m}, backbone={k: b.get(k) for k in keep_b if k in b},
+                n_params=int(sum(p.numel() for p in model.parameters())), n_keys=len(sd),
+                schema_sha256=hashlib.sha256(schema.encode()).hexdigest(), first_keys=list(sd)[:3], last_keys=list(sd)[-3:])
+            print(ds, variant, out[f"{ds}/{variant}"]["n_params"], len(sd))
+    with open(os.path.join(OUT, "variant_schemas.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "tta", "iou"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "tta", "iou", "variants"]
     if "ser" in which:
         gen_serialization(ref)
     if "e2e" in which:
@@ -486,3 +532,5 @@ if __name__ == "__main__":
         gen_tta(ref)
     if "iou" in which:
         gen_iou(ref)
+    if "variants" in which:
+        gen_variants(ref)

@@ -102,3 +102,31 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "/root/reference" not in src, f
+
+
+VARIANTS = [(ds, v) for ds in ("scannet", "scannet200", "nuscenes") for v in ("CDSegNet", "PTv3_CNF", "PTv3", "Baseline")]
+
+
+@pytest.mark.parametrize("ds,variant", VARIANTS)
+def test_model_config_equals_the_reference_config_files(ds, variant):
+    """configs.model_config restates configs/<dataset>/<variant>.py; tests/golden/variant_schemas.json was produced by
+    running those files themselves (oracle/make_golden.py variants) and building the reference model from them: same
+    hyper-parameters, same state_dict schema (keys, order, shapes), same parameter count at FULL width."""
+    import hashlib
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "variant_schemas.json")))[f"{ds}/{variant}"]
+    cfg = configs.model_config(ds, variant)
+
+    def norm(v):
+        return json.loads(json.dumps(v))
+
+    for k, v in ref["model"].items():
+        assert norm(cfg.get(k)) == v, ("model", k, cfg.get(k), v)
+    for k, v in ref["backbone"].items():
+        assert norm(cfg["backbone"].get(k)) == v, ("backbone", k, cfg["backbone"].get(k), v)
+    model = build_model(cfg)
+    sd = model.state_dict()
+    schema = json.dumps([[k, list(v.shape)] for k, v in sd.items()])
+    assert len(sd) == ref["n_keys"]
+    assert list(sd)[:3] == ref["first_keys"] and list(sd)[-3:] == ref["last_keys"]
+    assert hashlib.sha256(schema.encode()).hexdigest() == ref["schema_sha256"]
+    assert sum(p.numel() for p in model.parameters()) == ref["n_params"]

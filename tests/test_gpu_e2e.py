@@ -649,3 +649,31 @@ def test_forward_work_accounting():
     assert 2.0 < per_point < 8.0  # 5.1 MFLOP/point at 120k (attention share grows with the patch fill)
     assert all(v > 0 for v in wk.values())
     assert abs(wk["total"] - sum(v for k, v in wk.items() if k != "total")) < 1e-3 * wk["total"]
+
+
+@pytest.mark.parametrize("variant", ["PTv3_CNF", "PTv3", "Baseline"])
+def test_model_variants_full_width_vs_oracle(variant):
+    """SURVEY 8(f4), inference half at FULL width: configs.model_config(dataset, variant) - pinned to the reference's own
+    config files by tests/test_cpu_boundary.py - through the HIP path vs the CPU oracle (the mini-width goldens of these
+    variants come from the reference itself)."""
+    cfg = configs.model_config("scannet", variant)
+    model = build_model(cfg)
+    sd = fill_state_dict(model.state_dict(), seed=17)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    model.precision = "fp32"
+    sc = synth.room_scene(43, 4000)
+    inp = {k: sc[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    n = len(sc["coord"])
+    if variant == "PTv3":
+        gen = torch.Generator().manual_seed(5)
+        perms = [torch.randperm(4, generator=gen).tolist() for _ in range(5)]
+        ref = OM.inference_ptv3(cfg, sd, inp, perms).numpy()
+        logits = model.inference(to_dev(inp), eval=False, draws=dict(perms=perms))["seg_logits"].cpu().numpy()
+    else:
+        draws = OM.draw_rng(77, n, cfg["c_in_channels"])
+        ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"], dm=cfg["dm"]).numpy()
+        logits = run(model, inp, draws)
+    err, agree = report(f"scannet/{variant} full width fp32 vs oracle", logits, ref)
+    assert logits.shape == (n, cfg["num_classes"])
+    assert err < 1e-3 and agree > 0.999
