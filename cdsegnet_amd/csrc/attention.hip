@@ -535,9 +535,7 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
   const int nqt = (max_len + tile - 1) / tile;
   const int ph = num_patches * num_heads;
   int qsplit = ph >= 384 ? 1 : (ph >= 160 ? 2 : 4);
-#ifdef CDSEG_EXPERIMENTS
-  if (const char* e = getenv("CDSEG_ATTN_QSPLIT")) qsplit = atoi(e);  // tuning knob (power of two)
-#endif
+  qsplit = cdseg_knob("CDSEG_ATTN_QSPLIT", qsplit);  // (power of two)
   const int max_split = (nqt + ATTN_WAVES - 1) / ATTN_WAVES;
   while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
   p.num_patches = num_patches;

@@ -88,4 +88,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave
                : "memory");
 }
 
+// Tuning knobs are constants in the product library.  Experimental builds (-DCDSEG_EXPERIMENTS, tools/build_ab.py ->
+// tools/_ab/, loaded by the benchmark tools only) read them from the environment for A/B runs.
+#ifdef CDSEG_EXPERIMENTS
+#include <cstdlib>
+static inline int cdseg_knob(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#else
+#define cdseg_knob(name, dflt) (dflt)
+#endif
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

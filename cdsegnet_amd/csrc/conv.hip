@@ -42,7 +42,6 @@ struct ConvP {
   int ldx, ldy;
   int row_shift;        // log2(ldx * 2): byte stride of a feature row (a power of two)
   int tiles;            // ceil(n / rows per block)
-  int dbg;              // timing experiments only (CDSEG_CONV_DBG; results are WRONG when set): 1 = corner offsets
                         // treated as dead, 2 = every neighbour replaced by the row itself (perfectly local gathers)
 };
 
@@ -161,7 +160,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
       if ((unsigned)m != 0u) live |= 1u << (2 * t);
       if ((unsigned)(m >> 32) != 0u) live |= 1u << (2 * t + 1);
     }
-    if (p.dbg & 1) live &= ~0x5140145u;  // corner offsets
     f32x4_t acc[K::RG][K::CT];
 #pragma unroll
     for (int g = 0; g < K::RG; ++g)
@@ -321,7 +319,7 @@ template <int C>
 int launch_conv(const ConvP& p0, const void* wimg, hipStream_t s) {
   using K = ConvCfg<C>;
   // persistent blocks: as many as are co-resident (LDS: 2 per CU at C = 32, 1 at C = 64), never more than tiles
-  static const int blocks_per_cu = []() { const char* e = getenv("CDSEG_CONV_BLOCKS"); return e ? atoi(e) : 0; }();
+  static const int blocks_per_cu = cdseg_knob("CDSEG_CONV_BLOCKS", 0);
   int per_cu = K::LDS_BYTES > 80 * 1024 ? 1 : 2;
   if (blocks_per_cu > 0) per_cu = blocks_per_cu;
   // C = 32: 8 waves, 3 row buffers, 4 waves / SIMD; C = 64: 8 waves on the 256-register budget of 2 waves / SIMD,
@@ -355,8 +353,6 @@ extern "C" int cdseg_subm_conv3(const void* x, int ldx, const void* wimg, const 
   ConvP p;
   p.x = (const bf16_t*)x; p.bias = bias; p.nbr = nbr_kmajor; p.y = (bf16_t*)y;
   p.n = n; p.ldx = ldx; p.ldy = ldy; p.tiles = 0;
-  static const int dbg = []() { const char* e = getenv("CDSEG_CONV_DBG"); return e ? atoi(e) : 0; }();
-  p.dbg = dbg;
   p.row_shift = 0;
   while ((1 << p.row_shift) < ldx * 2) ++p.row_shift;
   if ((1 << p.row_shift) != ldx * 2) return CDSEG_ERR_UNSUPPORTED;  // feature rows with a power-of-two stride only

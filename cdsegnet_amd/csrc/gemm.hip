@@ -792,10 +792,6 @@ constexpr int gemm_smem_bytes() {
   return (ab > c ? ab : c) + 1024;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 
 // (A persistent weight-stationary variant for the short-K linears of the big stages - W slice resident in LDS /
 // registers, the next row tile's A in flight during the epilogue - was measured and dropped: 41 us vs 29 us on the
@@ -804,25 +800,25 @@ int env_int(const char* name, int dflt) {
 template <typename CT, int NCH, bool GATHER>
 int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   constexpr int BK = NCH * (16 / (int)sizeof(CT));
-  static const int split_target = env_int("CDSEG_GEMM_SPLIT_TARGET", 512);
-  static const int split_max = env_int("CDSEG_GEMM_SPLIT_MAX", 32);
-  static const int xmode_env = env_int("CDSEG_GEMM_XMODE", -1);
+  static const int split_target = cdseg_knob("CDSEG_GEMM_SPLIT_TARGET", 512);
+  static const int split_max = cdseg_knob("CDSEG_GEMM_SPLIT_MAX", 32);
+  static const int xmode_env = cdseg_knob("CDSEG_GEMM_XMODE", -1);
   const bool ln = p.ln_pre_g || p.ln_post_g;
   // sparse convs: 128-row tiles (8 waves): half the W re-reads per row through L2 -> LDS, the path every conv level is
   // bound by (stage-0 conv of a 4-scene batch 196 -> 123 us, +2 % end to end).  The same tiles for the wide deep-stage
   // linears were neutral (-1 %) and are not instantiated.
-  static const int conv_bm = env_int("CDSEG_CONV_BM", 128);
+  static const int conv_bm = cdseg_knob("CDSEG_CONV_BM", 128);
   const bool tall = GATHER && NCH == 16 && conv_bm >= 128 && p.M > 64 && !ln;
   // deep stages (C >= 256: few rows, 3.5 - 14 MB of weights per conv): 256-row tiles, 16 waves - per K step the block
   // moves 64 KB of A + 32 KB of W for 2048 MFMA cycles instead of 32 + 32 KB for 1024
-  static const int deep_bm = env_int("CDSEG_CONV_DEEP_BM", 256);
+  static const int deep_bm = cdseg_knob("CDSEG_CONV_DEEP_BM", 256);
   const bool deep = tall && sizeof(CT) == 2 && deep_bm == 256 && p.N >= 256 && p.M >= 512;
   int bm = deep ? 256 : (tall ? 128 : 64);
   // LDS-DMA main loop (bf16, K % 64 == 0, N > 64): 128-row tiles for plain linears too (CDSEG_GEMM_DMA_BM overrides)
   int dma_use_bm = -1;
   if constexpr (NCH == 16 && sizeof(CT) == 2) {
-    static const int dma_on0 = env_int("CDSEG_GEMM_DMA", 1);
-    static const int dma_bm0 = env_int("CDSEG_GEMM_DMA_BM", 0);
+    static const int dma_on0 = cdseg_knob("CDSEG_GEMM_DMA", 1);
+    static const int dma_bm0 = cdseg_knob("CDSEG_GEMM_DMA_BM", 0);
     if (dma_on0 && p.N > 64 && (p.K % 64) == 0 && (!GATHER || (p.kshift >= 6 && p.kvol <= 27)) && p.M >= 128) {
       // measured (tools/bench_gemm.py --scenes 8): 128-row tiles win for the sparse convs, for long row counts and for the
       // wide deep-stage linears (qkv / fc1 at C = 512: 34.9 / 39.0 us vs 48.9 / 50.3 with 64-row tiles)
@@ -840,7 +836,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   const long nkc = ((long)p.kvol * p.K + BK - 1) / BK;
   const long blocks = (long)gm * gn;
   const bool can_fix = p.ws && p.vec_ok && !p.out_idx;
-  static const int plain_min_nkc = env_int("CDSEG_GEMM_SPLIT_MIN_NKC", 16);
+  static const int plain_min_nkc = cdseg_knob("CDSEG_GEMM_SPLIT_MIN_NKC", 16);
   if (can_fix && blocks < 256 && nkc >= (GATHER ? 4 : plain_min_nkc)) {
     int smax = (int)(nkc / 2);
     if (smax > split_max) smax = split_max;
@@ -876,8 +872,8 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   bool launched = false;
   // bf16, K a multiple of 64, wide outputs: the LDS-DMA pipelined main loop
   if constexpr (NCH == 16 && sizeof(CT) == 2) {
-    static const int dma_on = env_int("CDSEG_GEMM_DMA", 1);
-    static const int dma_bm = env_int("CDSEG_GEMM_DMA_BM", 0);
+    static const int dma_on = cdseg_knob("CDSEG_GEMM_DMA", 1);
+    static const int dma_bm = cdseg_knob("CDSEG_GEMM_DMA_BM", 0);
     const bool fused_ln_here = ln && gn == 1 && splits == 1;  // complete rows in one 64-row block: stays on the old loop
     if (dma_on && bn == 128 && (p.K % 64) == 0 && (!GATHER || (p.kshift >= 6 && p.kvol <= 27)) && !fused_ln_here &&
         p.M >= 128 && dma_use_bm == bm) {

@@ -299,7 +299,7 @@ extern "C" int cdseg_mlp_fused(const void* h, int ldh, const void* w1, const flo
   // 64-wide hidden tiles: 20 / 32 / 56 KB of LDS per workgroup (C = 32 / 64 / 128).  128-wide tiles were measured 2-3 %
   // slower end to end at C = 64 (56 KB: two workgroups per CU instead of five) and equal at C = 32.
   hipStream_t s = (hipStream_t)stream;
-  static const int bm = []() { const char* e = getenv("CDSEG_MLP_BM"); return e ? atoi(e) : 128; }();
+  static const int bm = cdseg_knob("CDSEG_MLP_BM", 128);
   if (channels == 32) return launch_mlp<32, 64, false, 64>(p, s);
   if (channels == 64) return launch_mlp<64, 64, false, 64>(p, s);
   if (bm == 128 && n >= 128 * 512) return launch_mlp<128, 64, false, 128>(p, s);  // 80 KB: two 8-wave workgroups per CU
@@ -527,7 +527,7 @@ extern "C" int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, cons
   p.y = (const bf16_t*)y; p.wl = (const bf16_t*)wl; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.wqkv = (const bf16_t*)wqkv; p.bqkv = bqkv;
   p.qkv = (bf16_t*)qkv; p.n = n; p.ldy = ldy; p.ldx = ldx; p.ldqkv = ldqkv; p.eps = eps;
-  static const int bm = []() { const char* e = getenv("CDSEG_HEAD_BM"); return e ? atoi(e) : 128; }();
+  static const int bm = cdseg_knob("CDSEG_HEAD_BM", 128);
   if (bm == 128 && n >= 128 * 512) {  // enough 128-row workgroups to fill the chip twice
     const dim3 grid((unsigned)((n + 127) / 128));
     if (channels == 32) hipLaunchKernelGGL((cpe_head_fused_kernel<32, 128>), grid, dim3(512), 0, (hipStream_t)stream, p);

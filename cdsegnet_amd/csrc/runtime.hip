@@ -86,7 +86,10 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
   int rc;
 
   // ---- CPE: x += LN(Linear(SubMConv3d(xc)))  [+ t bias];  h = LN1(x)      (ptv3.py:401-413)
-  if (d->cpe_conv_wimg && T == CDSEG_BF16 && (C == 32 || C == 64)) {
+  // (the weight-stationary kernel addresses its buffers with 32-bit offsets: inputs past those limits - 16.7 M rows at
+  // C = 64 - take the gathered GEMM below, which handled them before that kernel existed)
+  const bool conv_fits = n * 27 * 4 < (1l << 31) && n * (long)C * 2 < (1l << 31) - 65536;
+  if (d->cpe_conv_wimg && T == CDSEG_BF16 && (C == 32 || C == 64) && conv_fits) {
     // wide stages: weight-stationary register-gather conv (conv.hip)
     rc = cdseg_subm_conv3(io->xc_in, C, d->cpe_conv_wimg, (const float*)d->cpe_conv_b, io->nbr, n, C, L.y, C, stream);
     if (rc != CDSEG_OK) return rc;
@@ -96,7 +99,7 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
     a.N = C; a.K = C; a.out = L.y; a.ldo = C; a.out_dtype = T;
     if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
   }
-  static const bool fused_head = []() { const char* e = getenv("CDSEG_FUSED_HEAD"); return !(e && e[0] == '0'); }();
+  static const bool fused_head = cdseg_knob("CDSEG_FUSED_HEAD", 1) != 0;
   const bool head = fused_head && T == CDSEG_BF16 && (C == 32 || C == 64);
   if (head && d->head_img) {
     // wide stages: weights resident in LDS, activations in registers (blockrr.hip)
@@ -146,11 +149,7 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
                               T, stream)) != CDSEG_OK)
       return rc;
   }
-  static const bool fused_tail = []() {
-    const char* e = getenv("CDSEG_FUSED_TAIL");
-    const char* m = getenv("CDSEG_FUSED_MLP");
-    return !(e && e[0] == '0') && !(m && m[0] == '0');
-  }();
+  static const bool fused_tail = cdseg_knob("CDSEG_FUSED_TAIL", 1) != 0 && cdseg_knob("CDSEG_FUSED_MLP", 1) != 0;
   if (fused_tail && T == CDSEG_BF16 && (C == 32 || C == 64) && d->hidden == 4 * C) {
     // big stages: proj + residual + LN2 + MLP in one launch; h and the hidden activation never leave the CU
     void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
@@ -176,8 +175,8 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
       return rc;
   }
   // ---- MLP: x += fc2(GELU(fc1(h)));  xc = T(x)                            (ptv3.py:423-427)
-  static const bool fused_mlp = []() { const char* e = getenv("CDSEG_FUSED_MLP"); return !(e && e[0] == '0'); }();
-  static const int fused_maxc = []() { const char* e = getenv("CDSEG_FUSED_MLP_MAXC"); return e ? atoi(e) : 128; }();
+  static const bool fused_mlp = cdseg_knob("CDSEG_FUSED_MLP", 1) != 0;
+  static const int fused_maxc = cdseg_knob("CDSEG_FUSED_MLP_MAXC", 128);
   if (fused_mlp && T == CDSEG_BF16 && (C == 32 || C == 64 || C == 128) && C <= fused_maxc && d->hidden == 4 * C) {
     // big stages: one kernel, the 4C hidden activation stays in LDS (mlp.hip)
     void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;

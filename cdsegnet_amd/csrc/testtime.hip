@@ -79,7 +79,10 @@ __global__ void tta_kernel(const float* __restrict__ in, TtaP p, int apply_scale
   if (i >= n) return;
   const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
   if (p.rotate) {
-    // np.dot(coord, rot_t.T): out_j = sum_k in_k R[j][k], accumulated left to right with fused multiply-adds
+    // np.dot(coord, rot_t.T): out_j = sum_k in_k R[j][k], accumulated left to right with fused multiply-adds.
+    // Bit-identical to numpy's BLAS dgemm for the reference's test-time angles (multiples of pi / 2: every product is
+    // exact or a 6e-17 cross term) - for an arbitrary angle the last bit may differ from the BLAS summation order, and a
+    // coordinate that sits within 1 ulp of a voxel border can then land in the neighbouring voxel of GridSample.
     double o[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) o[j] = fma((double)z, p.r[3 * j + 2], fma((double)y, p.r[3 * j + 1], (double)x * p.r[3 * j]));

@@ -55,7 +55,7 @@ def _shared(cache, key, build):
     return ent[0]
 
 
-FUSED_CURVE_SORT = os.environ.get("CDSEG_SORT_CURVES", "1") != "0"  # A/B switch: one sort per curve instead
+FUSED_CURVE_SORT = True  # the level-0 orders of all curves in use from ONE sort (False: one sort per curve; tools A/B)
 
 class Level:
     """One voxel resolution of the scene, points in (batch | z) sorted order."""
@@ -171,9 +171,6 @@ class Engine:
         self._pad_keys = None
         self._side = {}
         self.fork_stage = 1  # dominant-branch encoder stage at which the noise-branch encoder is forked (None: serial)
-        env = os.environ.get("CDSEG_FORK_STAGE")
-        if env is not None:
-            self.fork_stage = None if env.lower() in ("none", "-1", "") else int(env)
         self._work_lock = threading.Lock()
         self._tls = threading.local()  # per host thread: device-RNG cursor
         self.attn_work = 0.0  # algorithmic attention FLOPs issued so far (4 * 16 * H * sum_p L_p^2 per launch)
@@ -671,8 +668,7 @@ class Engine:
         x = self._buf(fine.n, cout, torch.float32)
         xc = self._buf(fine.n, cout, self.T)
         if mod.skip_connection_mode == "add":
-            if f != 1.0:
-                raise NotImplementedError("scaled skip connection in 'add' mode (off in every shipped config)")
+            assert f == 1.0, "rejected by SerializedUnpooling.__init__"
             child = self._buf(coarse.n, cout, torch.float32)
             ops.gemm(st.xc, w[pre + ".proj.w"], child, bias=w[pre + ".proj.b"], scale=w[pre + ".proj_bn.scale"],
                      shift=w[pre + ".proj_bn.shift"], act=ops.ACT_GELU)
@@ -842,8 +838,11 @@ class Engine:
         if self.model.noise_source == "device":
             # device-noise mode: the stream ids come from torch's CPU generator itself (one draw per call, after the
             # order shuffles), so the logits are a function of the generator state alone: torch.manual_seed(s) followed
-            # by the same calls reproduces them, whatever ran before in the process
-            return int(torch.randint(0, 2 ** 31 - 1024, (1,)).item())
+            # by the same calls reproduces them, whatever ran before in the process.  62-bit base: the windows of
+            # RNG_RESERVE consecutive ids of two scenes practically never overlap (a 31-bit base collided by the
+            # birthday bound within ~10^4 scenes).  One draw per inference from the CPU generator; call from ONE host
+            # thread (predraw / inference_many do)
+            return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         seed = torch.initial_seed()
         if seed != self._rng_seed:  # a new torch.manual_seed restarts the counter (used by feat_noise_source="device")
             self._rng_seed, self.rng_offset = seed, 0

@@ -157,8 +157,12 @@ class SerializedUnpooling(nn.Module):
             if skip_connection_scale_i is not None:
                 f *= 0.8 ** (int(skip_connection_scale_i) - 1)
             if f != 1.0:
-                raise NotImplementedError("skip-connection scaling with skip_connection_mode='add' "
-                                          "(no shipped CDSegNet / PTv3 config uses it)")
+                raise NotImplementedError(
+                    f"SerializedUnpooling(skip_connection_mode='add') with a skip scale of {f:g} "
+                    f"(skip_connection_scale={skip_connection_scale!r}, skip_connection_scale_i={skip_connection_scale_i!r}): "
+                    "the 'add' epilogue has no post-activation scalar.  No shipped CDSegNet / PTv3 config asks for it; use "
+                    "skip_connection_mode='cat' (the scale is folded into proj_cat) or skip_connection_scale=False with "
+                    "skip_connection_scale_i=None")
         else:
             raise ValueError(f"skip_connection_mode={skip_connection_mode!r}")
 

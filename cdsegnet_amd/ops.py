@@ -503,7 +503,7 @@ def mlp_fused_ok(h, hidden):
     """The fused MLP kernel covers bf16 with C = 32 / 64 / 128 and the standard 4x hidden width."""
     c = h.shape[1]
     return (h.dtype == torch.bfloat16 and c in FUSED_MLP_CHANNELS and hidden == 4 * c and
-            c <= int(os.environ.get("CDSEG_FUSED_MLP_MAXC", "128")) and os.environ.get("CDSEG_FUSED_MLP", "1") != "0")
+            c <= 128)
 
 
 def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
@@ -517,7 +517,7 @@ def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
 
 def cpe_head_fused_ok(y):
     """cpe linear + LN + residual + LN1 + qkv in one launch: bf16, C = 32 / 64."""
-    return (y.dtype == torch.bfloat16 and y.shape[1] in (32, 64) and os.environ.get("CDSEG_FUSED_HEAD", "1") != "0")
+    return y.dtype == torch.bfloat16 and y.shape[1] in (32, 64)
 
 
 def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
@@ -533,8 +533,7 @@ def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
 def attn_tail_fused_ok(o, hidden):
     """proj + LayerNorm + MLP in one launch: bf16, C = 32 / 64."""
     c = o.shape[1]
-    return (o.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c and
-            os.environ.get("CDSEG_FUSED_TAIL", "1") != "0" and os.environ.get("CDSEG_FUSED_MLP", "1") != "0")
+    return o.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c
 
 
 def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5):
@@ -549,13 +548,13 @@ def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5)
 
 def block_rr_ok(channels, dtype):
     """Register-resident Block head / tail kernels (csrc/blockrr.hip): bf16, C = 32 / 64."""
-    return os.environ.get("CDSEG_BLOCK_RR", "1") != "0" and dtype == torch.bfloat16 and channels in (32, 64)
+    return dtype == torch.bfloat16 and channels in (32, 64)
 
 
 def block_rr_head_on():
     """The register-resident HEAD is off by default: the 64-row-tile fused head already streams at ~4.3 TB/s and measured
     5-10 % faster (tools/bench_block.py); the register-resident TAIL is 1.4-1.65x faster than its predecessor."""
-    return os.environ.get("CDSEG_BLOCK_RR_HEAD", "0") == "1"
+    return False
 
 
 def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
@@ -620,7 +619,7 @@ def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start
 
 def stem5_ok(cout, dtype):
     """The map-free stem kernel (csrc/stem.hip) covers the shipped stems: 32 output channels, bf16."""
-    return os.environ.get("CDSEG_STEM5", "1") != "0" and cout == 32 and dtype == torch.bfloat16
+    return cout == 32 and dtype == torch.bfloat16
 
 
 def child_info(zcode_sorted, seg_start, m):
@@ -651,8 +650,9 @@ def stem5(x8, wimg, scale, shift, grid, cluster, parent_nbr3, cinfo, depth, out,
 
 def subm_conv3_ok(x):
     """The weight-stationary live-list conv (csrc/conv.hip) covers the wide bf16 stages: C = 32 / 64."""
-    on = os.environ.get("CDSEG_CONV_RG", "1") != "0"
-    return on and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (32, 64) and x.stride(0) == x.shape[1]
+    n = x.shape[0]  # (32-bit buffer offsets inside the kernel: larger inputs take the gathered GEMM)
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (32, 64) and x.stride(0) == x.shape[1] and
+            n * 27 * 4 < 2 ** 31 and n * x.shape[1] * 2 < 2 ** 31 - 65536)
 
 
 def subm_conv3_pack(w):

@@ -668,7 +668,7 @@ def test_model_variants_full_width_vs_oracle(variant):
     if variant == "PTv3":
         gen = torch.Generator().manual_seed(5)
         perms = [torch.randperm(4, generator=gen).tolist() for _ in range(5)]
-        ref = OM.inference_ptv3(cfg, sd, inp, perms).numpy()
+        ref = OM.inference_ptv3(cfg["backbone"], sd, inp, perms).numpy()
         logits = model.inference(to_dev(inp), eval=False, draws=dict(perms=perms))["seg_logits"].cpu().numpy()
     else:
         draws = OM.draw_rng(77, n, cfg["c_in_channels"])
