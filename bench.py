@@ -74,6 +74,11 @@ def parse():
                          "scenes-per-forward x lanes scenes (one batch per lane)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="independent forwards in flight per GPU (HIP streams); 1 = strictly one forward at a time")
+    ap.add_argument("--shard", type=int, default=0, metavar="S",
+                    help="strong-scaling mode (BASELINE config 4's shape: --dataset nuscenes --points 40000 --shard 64): ONE "
+                         "global list of S mixed-size scenes, LPT-sharded over the ranks (cdsegnet_amd.dist.shard_scenes), "
+                         "every rank runs its share through inference_many (--scenes-per-forward collated per forward), the "
+                         "per-class counters are all-reduced and the mIoU printed; a step = all S scenes")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no model, gloo when there is no GPU): what the CPU test runs")
     return ap.parse_args()
@@ -113,6 +118,11 @@ def make_scenes(args, rank, count):
             sc = synth.perturb_scene(sc, seed=seed, sigma=0.05, drop=0.5, voxel=0.05 if args.dataset == "nuscenes" else 0.02)
         scenes.append(sc)
     return scenes
+
+
+def shard_sizes(args):
+    """Target sizes of the global scene list of --shard: deterministic, mixed (0.6 .. 1.4 x --points)."""
+    return [int(round(args.points * (0.6 + 0.8 * ((i * 37) % args.shard) / max(1, args.shard - 1)))) for i in range(args.shard)]
 
 
 def cpu_baseline(cfg, sd, points, dataset, threads):
@@ -216,6 +226,70 @@ def paper_protocol(args, model, cfg, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def shard_mode(args, model, cfg, dev, rank, world, dist):
+    """--shard S: strong scaling over ONE global list of S scenes (see parse())."""
+    from cdsegnet_amd import dist as cdist, synth
+    sizes = shard_sizes(args)
+    mine = cdist.shard_scenes(sizes, rank, world)
+    scenes = []
+    for i in mine:
+        sc = synth.lidar_scene(9000 + i, sizes[i]) if args.dataset == "nuscenes" else synth.room_scene(9000 + i, sizes[i])
+        scenes.append(sc)
+    dicts = []
+    for sc in scenes:
+        d = {k: torch.as_tensor(sc[k]).to(dev) for k in ("coord", "grid_coord", "feat", "offset")}
+        d["offset_host"] = [int(v) for v in sc["offset"]]
+        dicts.append(d)
+    my_pts = int(sum(len(sc["coord"]) for sc in scenes))
+    torch.manual_seed(54421566 + rank)
+
+    def step():
+        return model.inference_many([dict(d) for d in dicts], lanes=args.lanes, batch=args.scenes_per_forward) if dicts else []
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = None
+    for _ in range(args.steps):
+        outs = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    counts = torch.zeros(3, cfg["num_classes"], dtype=torch.int64, device=dev)
+    for sc, o in zip(scenes, outs or []):
+        counts += cdist.confusion_counts(o["seg_logits"].argmax(1), torch.as_tensor(sc["segment"]).to(dev), cfg["num_classes"])
+    cdist.reduce_counts(counts)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    pts = torch.tensor([my_pts], dtype=torch.int64, device=dev)
+    per_rank = torch.zeros(world, dtype=torch.int64, device=dev)
+    per_rank[rank] = my_pts
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        el = float(tmax.item())
+        m = cdist.metrics(counts)
+        print(json.dumps({
+            "metric": "points/sec/node (one global scene list sharded over the GPUs, 1-step)", "value": int(pts.item()) * args.steps / el,
+            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision != "fp32" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.shard} {args.dataset}-shaped scenes ({min(sizes)}..{max(sizes)} voxels), LPT-sharded over "
+                                   f"{world} GPU(s), {args.scenes_per_forward} collated per forward, {args.lanes} forwards in flight",
+                       "precision": args.precision, "points_per_rank": per_rank.tolist(), "host_hints": ["offset_host"]},
+            "scenes_per_s": args.shard * args.steps / el,
+            "eval_counters": {"mIoU_random_init": m["mIoU"], "points_counted": int(counts[2].sum())}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -235,12 +309,29 @@ def main():
             dist.barrier()
         t = torch.tensor([1.0 + rank], dtype=torch.float64, device=dev)
         ones = torch.ones(1, dtype=torch.int64, device=dev)
+        extra = {}
+        if args.shard:  # the --shard plumbing without the model: partition, per-rank loads, counter all-reduce
+            from cdsegnet_amd import dist as cdist
+            sizes = shard_sizes(args)
+            mine = cdist.shard_scenes(sizes, rank, world)
+            seen = torch.zeros(args.shard, dtype=torch.int64, device=dev)
+            seen[mine] = 1
+            load = torch.zeros(world, dtype=torch.int64, device=dev)
+            load[rank] = sum(sizes[i] for i in mine)
+            counts = torch.zeros(3, 16, dtype=torch.int64, device=dev)
+            counts[2, rank % 16] = load[rank]
+            if world > 1:
+                dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+                dist.all_reduce(load, op=dist.ReduceOp.SUM)
+            cdist.reduce_counts(counts)
+            extra = {"shard_scenes": args.shard, "every_scene_on_exactly_one_rank": bool((seen == 1).all()),
+                     "points_per_rank": load.tolist(), "points_total": int(sum(sizes)), "points_counted": int(counts[2].sum())}
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ones.item()), "max_over_ranks": float(t.item()),
-                              "backend": "nccl" if have_gpu else "gloo"}))
+                              "backend": "nccl" if have_gpu else "gloo", **extra}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -272,6 +363,8 @@ def main():
 
     if args.protocol == "paper":
         return paper_protocol(args, model, cfg, dev, rank, world, dist)
+    if args.shard:
+        return shard_mode(args, model, cfg, dev, rank, world, dist)
     scenes_per_step = args.scenes_per_forward * args.lanes
     scenes = make_scenes(args, rank, scenes_per_step)
     dicts = []

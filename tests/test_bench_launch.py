@@ -42,3 +42,14 @@ def test_bench_under_an_external_launcher_reads_the_environment():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2
+
+
+def test_bench_shard_mode_plumbing_two_ranks():
+    """--shard (BASELINE config 4's shape: 64 LiDAR sweeps over the GPUs of a node): ONE global scene list, LPT-sharded,
+    counters all-reduced - the plumbing on two gloo ranks (the model itself needs a GPU)."""
+    res = _run(["--gpus", "2", "--dry-run", "--shard", "64", "--dataset", "nuscenes", "--points", "40000"])
+    assert res["n_gpus"] == 2 and res["shard_scenes"] == 64
+    assert res["every_scene_on_exactly_one_rank"]
+    a, b = res["points_per_rank"]
+    assert a + b == res["points_total"] == res["points_counted"]
+    assert abs(a - b) <= 0.02 * res["points_total"]  # LPT balance
