@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcdseg_hip.so")
-SOURCES = ["serialize.hip", "gemm.hip", "elementwise.hip", "attention.hip", "conv.hip", "stem.hip", "mlp.hip", "blockrr.hip", "runtime.hip", "testtime.hip", "prof.hip", "abi.hip"]
+SOURCES = ["serialize.hip", "gemm.hip", "elementwise.hip", "attention.hip", "conv.hip", "stem.hip", "mlp.hip", "blockrr.hip", "runtime.hip", "testtime.hip", "train.hip", "prof.hip", "abi.hip"]
 HEADERS = ["common.h", "curves.h", "prof.h", os.path.join("..", "..", "include", "cdseg.h")]
 ARCH = "gfx950"
 

@@ -903,3 +903,38 @@ def serialization(grid_coord, batch, orders=("z", "z-trans", "hilbert", "hilbert
         orders_.append(widen(perm))
         inverses.append(widen(invert_perm(perm)))
     return torch.stack(codes), torch.stack(orders_), torch.stack(inverses), depth
+
+
+# ------------------------------------------------------------------ training path, first slice (csrc/train.hip)
+def attention_bwd(q, k, v, q_gidx, kv_gidx, widx, patch_start, patch_start_host, num_heads, scale, dout, dq, dk, dv):
+    """Gradients of `attention` (fp32): dq / dk / dv (views of zero-initialised buffers, any row stride) += at the
+    gathered rows.  patch_start_host: the same patch table as Python ints (tile count of the launch)."""
+    _need_gpu(q, dout)
+    if q.dtype != torch.float32:
+        raise _lib.CdsegError("attention_bwd: exact-fp32 mode only (first slice of the training path)")
+    ps = [int(x) for x in patch_start_host]
+    num_patches = len(ps) - 1
+    tiles = sum((ps[i + 1] - ps[i] + 63) // 64 for i in range(num_patches))
+    lib = _lib.load()
+    ws = torch.empty(max(1, lib.cdseg_attention_bwd_ws_bytes(ps[-1], int(num_heads))), dtype=torch.uint8, device=q.device)
+    check(lib.cdseg_attention_bwd(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),
+                                  _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads), ps[-1], tiles,
+                                  float(scale), _ptr(dout), dout.stride(0), _ptr(dq), _ptr(dk), _ptr(dv), dq.stride(0),
+                                  dk.stride(0), dv.stride(0), dt(q), _ptr(ws), ws.numel(), _stream()), "attention_bwd")
+
+
+def layernorm_bwd(x, gamma, dy, dx, accumulate=False, eps=1e-5, dgamma=None, dbeta=None):
+    """dx (=, or += with accumulate) of y = LayerNorm(x) * gamma + beta; fp32."""
+    _need_gpu(x, dy)
+    check(_lib.load().cdseg_layernorm_bwd(_ptr(x), x.stride(0), _ptr(gamma), float(eps), _ptr(dy), dy.stride(0), _ptr(dx),
+                                          dx.stride(0), int(bool(accumulate)), _ptr(dgamma), _ptr(dbeta), x.shape[0],
+                                          x.shape[1], _stream()), "layernorm_bwd")
+    return dx
+
+
+def gelu_bwd(u, dy):
+    """dy * GELU'(u) on the pre-activation u (erf form); fp32, contiguous."""
+    _need_gpu(u, dy)
+    dx = torch.empty_like(u)
+    check(_lib.load().cdseg_gelu_bwd(_ptr(u), _ptr(dy), _ptr(dx), u.numel(), _stream()), "gelu_bwd")
+    return dx

@@ -413,6 +413,25 @@ typedef struct cdseg_block_io {
 size_t cdseg_block_scratch_bytes(const cdseg_block_desc* desc, long n);
 int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, void* stream);
 
+/* ------------------------------------------------------------------ training path, first slice (exact fp32)
+ * ref: pointcept/models/default.py:424-493 (training forward), pointcept/engines/train.py:216-271 (loss.backward());
+ *      what autograd differentiates: ptv3.py:246-296 (SerializedAttention core), ptv3.py:399-428 (Block tail).
+ * cdseg_attention_bwd: gradients of cdseg_attention's inputs.  dout (rows, H*16) is the gradient of its output; dq / dk /
+ *   dv are ACCUMULATED into (+=, the caller zeroes them) at the gathered rows - a point that the padding plan put into
+ *   two slots collects both (the backward of the reference's `qkv[order]` gather); slots without an output row (widx -1)
+ *   receive no output gradient but still act as keys.  num_slots = patch_start[num_patches]; num_tiles = sum over patches
+ *   of ceil(L / 64).  ws: cdseg_attention_bwd_ws_bytes.  dtype: CDSEG_F32 only so far.
+ * cdseg_layernorm_bwd: dx (=, or += when accumulate) for y = LayerNorm(x) * gamma + beta; optional dgamma / dbeta (+=).
+ * cdseg_gelu_bwd: dx = dy * d/du GELU(u) on the pre-activation u (erf form, torch.nn.GELU()). */
+size_t cdseg_attention_bwd_ws_bytes(long num_slots, int num_heads);
+int cdseg_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const int32_t* q_gidx,
+                        const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
+                        int num_heads, long num_slots, int num_tiles, float scale, const void* dout, int lddo, void* dq,
+                        void* dk, void* dv, int lddq, int lddk, int lddv, int dtype, void* ws, size_t ws_bytes, void* stream);
+int cdseg_layernorm_bwd(const float* x, int ldx, const float* gamma, float eps, const float* dy, int lddy, float* dx, int lddx,
+                        int accumulate, float* dgamma, float* dbeta, long m, int c, void* stream);
+int cdseg_gelu_bwd(const float* u, const float* dy, float* dx, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -465,6 +465,51 @@ def gen_iou(ref):
     print("iou fixture", {k: v.shape for k, v in fx.items() if k.endswith("inter")})
 
 
+def gen_train(ref):
+    """Training path, first slice: ONE Block of the reference under autograd.  The mini model runs its single-step
+    forward with gradients enabled; hooks capture the residual stream in front of norm1 (x0), the qkv projection
+    (retain_grad), the Block's output y and the padded patch plan of its curve; d<y, g>/d qkv comes from
+    torch.autograd (what pointcept/engines/train.py:216-271's loss.backward() does for this Block)."""
+    cfg = configs.mini_config()
+    model, sd = ref_model(ref, cfg, seed=12)
+    scene = frozen("train_block_tail", lambda: synth.room_scene(61, 2600))
+    blk = model.backbone._n_enc.enc1.block0
+    pre = "backbone._n_enc.enc1.block0"
+    cap = {}
+    hooks = [
+        blk.norm1.register_forward_pre_hook(lambda m, a: cap.__setitem__("x0", a[0].feat.detach().clone())),
+        blk.attn.qkv.register_forward_hook(lambda m, a, o: (o.retain_grad(), cap.__setitem__("qkv", o))[1]),
+    ]
+
+    def on_block(m, a, out):
+        oi = m.attn.order_index
+        pad, unpad, cu = out["pad"], out["unpad"], out["cu_seqlens_key"]
+        cap["order"] = out.serialized_order[oi][pad].clone()
+        cap["inverse"] = unpad[out.serialized_inverse[oi]].clone()
+        cap["cu"] = cu.clone()
+        cap["y"] = out.feat
+    hooks.append(blk.register_forward_hook(on_block))
+    torch.manual_seed(77)
+    with torch.enable_grad():
+        for p_ in model.parameters():
+            p_.requires_grad_(True)
+        model.inference(to_torch_input(scene), eval=False)
+        y = cap["y"]
+        g = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+        (y * g).sum().backward()
+    for h in hooks:
+        h.remove()
+    fx = dict(x0=cap["x0"].numpy(), dy=g.numpy(), y=y.detach().numpy(), d_qkv=cap["qkv"].grad.numpy(),
+              order=cap["order"].numpy().astype(np.int64), inverse=cap["inverse"].numpy().astype(np.int64),
+              cu=cap["cu"].numpy().astype(np.int64), num_heads=np.int64(blk.attn.num_heads), prefix=np.array(pre))
+    for k, v in sd.items():
+        if k.startswith(pre + ".") and (".norm" in k or ".attn." in k or ".mlp." in k):
+            fx["sd." + k] = v.numpy()
+    save_fixture(os.path.join(OUT, "train_block_tail.npz"), **fx)
+    print("train_block_tail", fx["x0"].shape, "slots", fx["order"].shape, "patches", len(fx["cu"]) - 1,
+          "|d_qkv|", float(np.abs(fx["d_qkv"]).mean()))
+
+
 def gen_variants(ref):
     """Full-width model variants straight from the reference's OWN config files (configs/<dataset>/<variant>.py run with
     runpy): constructor hyper-parameters the inference path reads, state_dict schema (keys + shapes, hashed) and
@@ -515,7 +560,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "tta", "iou", "variants"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "tta", "iou", "variants", "train"]
     if "ser" in which:
         gen_serialization(ref)
     if "e2e" in which:
@@ -534,3 +579,5 @@ if __name__ == "__main__":
         gen_iou(ref)
     if "variants" in which:
         gen_variants(ref)
+    if "train" in which:
+        gen_train(ref)

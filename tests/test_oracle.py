@@ -272,3 +272,15 @@ def test_tta_pipeline_oracle_vs_reference():
         f0 = r["fragments"][0]
         g_ref = fx[f"aug{a}_grid"][fx[f"aug{a}_frag0_index"]]
         assert sorted(map(tuple, f0["grid_coord"])) == sorted(map(tuple, g_ref))
+
+
+def test_train_oracle_matches_the_reference_autograd():
+    """oracle/train.py (the checker of the training path's first slice) against the reference's own Block under
+    autograd (tests/golden/train_block_tail.npz, produced by oracle/make_golden.py train)."""
+    from oracle import train as OT
+    fx = load_fixture("train_block_tail.npz")
+    pre = str(fx["prefix"])
+    sd = {k[3:]: fx[k] for k in fx.files if k.startswith("sd.")}
+    y, g = OT.block_tail_qkv_grad(sd, pre, fx["x0"], fx["order"], fx["inverse"], fx["cu"], int(fx["num_heads"]), fx["dy"])
+    assert float(np.abs(y.numpy() - fx["y"]).max()) < 1e-5
+    assert float(np.abs(g.numpy() - fx["d_qkv"]).max()) < 1e-6

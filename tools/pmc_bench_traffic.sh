@@ -2,7 +2,7 @@
 # never combined with a trace domain).  usage: bash tools/pmc_bench_traffic.sh <out.json>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-out=${1:-$R/gpurun_out/r02_attention_traffic.json}
+out=${1:-$R/gpurun_out/r03_attention_traffic.json}
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$ctr
   ( cd $R && timeout -k 5 400 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmcb_$ctr -o out -- \
