@@ -68,6 +68,9 @@ struct GemmP {
   void* ln_out;
   int ldln, ln_out_dtype;
   float ln_eps;
+#ifdef CDSEG_EXPERIMENTS
+  int dbg;  // timing experiments (tools/_ab builds; results are wrong): 1 = no MFMAs, 2 = no DMA, 4 = no epilogue
+#endif
 };
 
 template <int NCH>
@@ -151,6 +154,52 @@ __device__ __forceinline__ void epilogue4(const GemmP& g, long m, int n, float4 
       if (g.out2 && !g.out2_pre_add) store_val(g.out2, g.out2_dtype, m * g.ldo2 + ne, x);
     }
   }
+}
+
+// Plain bf16 outputs (qkv, fc1, the conv outputs: bias / folded BN / activation only, no residual, no second output, no
+// scatter): 8 consecutive columns per lane = ONE 16-byte store.  The 8-byte stores of epilogue4 made these launches
+// store-issue bound: the qkv / fc1 GEMMs of the deep stages spent 70 % of their time in the epilogue
+// (profiles/r03_gemm_phase_ablation.txt: 66 us with, 19 us without it at 114k x 128 -> 384).
+__device__ __forceinline__ bool plain_bf16_out(const GemmP& g) {
+  return g.out_dtype == CDSEG_BF16 && g.vec_ok && !g.out2 && !g.res && !g.add_src && !g.colbias && !g.out_idx && !g.ln_pre_g &&
+         !g.ln_post_g && (g.N & 7) == 0 && (g.ldo & 7) == 0;
+}
+
+struct Cols8 {  // per-column epilogue constants of a lane's 8 columns (loaded once per tile, ahead of the C staging)
+  float4 b0, b1, sc0, sc1, sh0, sh1;
+};
+
+__device__ __forceinline__ Cols8 load_cols8(const GemmP& g, int n) {
+  Cols8 c;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f), one = make_float4(1.f, 1.f, 1.f, 1.f);
+  c.b0 = c.b1 = c.sh0 = c.sh1 = z;
+  c.sc0 = c.sc1 = one;
+  if (n < g.N) {
+    if (g.bias) { c.b0 = *reinterpret_cast<const float4*>(g.bias + n); c.b1 = *reinterpret_cast<const float4*>(g.bias + n + 4); }
+    if (g.scale) {
+      c.sc0 = *reinterpret_cast<const float4*>(g.scale + n); c.sc1 = *reinterpret_cast<const float4*>(g.scale + n + 4);
+      c.sh0 = *reinterpret_cast<const float4*>(g.shift + n); c.sh1 = *reinterpret_cast<const float4*>(g.shift + n + 4);
+    }
+  }
+  return c;
+}
+
+__device__ __forceinline__ void epilogue8_bf16(const GemmP& g, long m, int n, float4 a, float4 b, const Cols8& c) {
+  a.x += c.b0.x; a.y += c.b0.y; a.z += c.b0.z; a.w += c.b0.w; b.x += c.b1.x; b.y += c.b1.y; b.z += c.b1.z; b.w += c.b1.w;
+  if (g.scale) {
+    a.x = a.x * c.sc0.x + c.sh0.x; a.y = a.y * c.sc0.y + c.sh0.y; a.z = a.z * c.sc0.z + c.sh0.z; a.w = a.w * c.sc0.w + c.sh0.w;
+    b.x = b.x * c.sc1.x + c.sh1.x; b.y = b.y * c.sc1.y + c.sh1.y; b.z = b.z * c.sc1.z + c.sh1.z; b.w = b.w * c.sc1.w + c.sh1.w;
+  }
+  if (g.act != CDSEG_ACT_NONE) {
+    a.x = apply_act(a.x, g.act); a.y = apply_act(a.y, g.act); a.z = apply_act(a.z, g.act); a.w = apply_act(a.w, g.act);
+    b.x = apply_act(b.x, g.act); b.y = apply_act(b.y, g.act); b.z = apply_act(b.z, g.act); b.w = apply_act(b.w, g.act);
+  }
+  uint4 o;
+  o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w); o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+#ifdef CDSEG_EXPERIMENTS
+  if ((g.dbg & 8) && o.x != 0x12345678u) return;   // everything but the store
+#endif
+  *reinterpret_cast<uint4*>((bf16_t*)g.out + m * g.ldo + n) = o;
 }
 
 // ---- row-wise epilogue on a lane's float4 groups (columns c0 + 4 * (part + L * i)) of row m.
@@ -305,6 +354,13 @@ __global__ __launch_bounds__(256) void row_finish_kernel(GemmP g) {
   finish_row<2>(g, m, true, lane, 64, groups, 0, v);
 }
 
+#ifdef CDSEG_GEMM_TIMING
+__device__ unsigned long long g_gemm_t[8 * 16384];  // per block: realtime in / out, cycles of the main loop / epilogue
+extern "C" int cdseg_debug_gemm_timing(unsigned long long* host_dst, size_t count) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_t), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
+
 // ---- accumulators -> LDS C tile -> fused epilogue, 64 rows at a time (shared by both main loops).
 // Wave (wm, wn) owns rows wm * 32 .. + 32, columns wn * BN/2 .. of the BM x BN tile; smem is free for reuse.
 template <int BN, int BM>
@@ -317,9 +373,22 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[2][
   // ---- accumulators -> LDS C tile -> epilogue, 64 rows at a time.  MFMA C layout: col = lane & 15,
   // row = (lane >> 4) * 4 + r
   float* Cs = reinterpret_cast<float*>(smem);
+  const bool plain = !g.fix && plain_bf16_out(g);
+  Cols8 cols;
+  if (plain) cols = load_cols8(g, n0 + 8 * (tid % (BN / 8)));  // in flight behind the C staging: was a dependent L2 round trip per item
+  // (barriers of the C staging: LDS hazards only.  __syncthreads() also waits for vmcnt(0), i.e. for the GLOBAL STORES of
+  // the previous 64 rows to be acknowledged - ~1.5 us per tile in which the block did nothing, in-kernel stamps
+  // tools/gemm_timing.py: the epilogue took 5.3k cycles, as long as two K steps)
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
 #pragma unroll 1
   for (int hh = 0; hh < BM / 64; ++hh) {
-    if (hh) __syncthreads();  // the previous 64 rows have left the C tile
+#ifdef CDSEG_GEMM_TIMING
+    if (tid == 0 && blockIdx.x < 16384) g_gemm_t[(size_t)blockIdx.x * 8 + 4 + 2 * hh] = __builtin_readcyclecounter();
+#endif
+    if (hh) lds_barrier();  // the previous 64 rows have left the C tile
     int zcol = 0;  // opaque zero in the column index: keeps the per-column epilogue vectors from being hoisted out of
     if constexpr (BM > 64) asm volatile("v_mov_b32 %0, 0" : "=v"(zcol));  // the loop (and into 100+ extra VGPRs)
     if ((wm >> 1) == hh) {
@@ -332,7 +401,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[2][
           for (int r = 0; r < 4; ++r)
             Cs[(rbase + i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
     }
-    __syncthreads();
+    lds_barrier();
+#ifdef CDSEG_GEMM_TIMING
+    if (tid == 0 && blockIdx.x < 16384) g_gemm_t[(size_t)blockIdx.x * 8 + 5 + 2 * hh] = __builtin_readcyclecounter();
+#endif
     const long mb = m0 + 64 * hh;
     constexpr int GPR = BN / 4;  // float4 groups per row
     if (g.fix) {
@@ -358,6 +430,18 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[2][
         v[i] = (part + 4 * i < ng) ? *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * (part + 4 * i))
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
       finish_row<MAXG>(g, m, m < g.M, part, 4, ng, 0, v);
+    } else if (plain) {
+      // plain bf16 output: row-contiguous groups of 8 columns, one 16-byte store each (NT is a multiple of the groups per
+      // row: a lane always has the same 8 columns, whose bias / folded-BN constants were fetched ahead of the staging)
+      static_assert(NT % (GPR / 2) == 0, "a lane's columns must not change between items");
+      for (int item = tid; item < 64 * (GPR / 2); item += NT) {
+        const int row = item / (GPR / 2), cg = item % (GPR / 2);
+        const long m = mb + row;
+        const int n = n0 + 8 * cg;
+        if (m >= g.M || n >= g.N) continue;
+        epilogue8_bf16(g, m, n, *reinterpret_cast<const float4*>(Cs + row * CLD + 8 * cg),
+                       *reinterpret_cast<const float4*>(Cs + row * CLD + 8 * cg + 4), cols);
+      }
     } else {
       // epilogue on row-contiguous groups of 4 columns
       for (int item = tid; item < 64 * GPR; item += NT) {
@@ -602,19 +686,23 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
 //     hipcc drains vmcnt(0) around compiler-visible LDS-DMA, and no other VMEM instruction lives in the loop.
 __device__ uint4 g_zero_page[8];  // 128 zero bytes: the source of a missing neighbour's row chunk
 
-template <int BM>
+template <int BM, bool GATHER = true>
 struct DmaCfg {
   static constexpr int WAVES = BM / 16, NT = WAVES * 64, BN = 128, BK = 64;
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
   static constexpr int A_PW = (BM / 8) / WAVES, W_PW = (BN / 8) / WAVES;  // DMA instructions per wave and step (2, 16 / WAVES)
   static constexpr int STAGES = 2 * (A_BYTES + W_BYTES);
-  static constexpr int ITAB = BM * 27 * 4;
-  static constexpr int LDS = STAGES + ITAB + 1024;
+  static constexpr int ITAB = GATHER ? BM * 27 * 4 : 0;  // the plain Linears carry no kernel-map table: with it a 128-row
+  static constexpr int LDS = STAGES + ITAB + 1024;         // block took 79.6 KB of LDS and the CU held ONE block, not two
 };
+
 
 template <int BM, bool GATHER>
 __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
-  using D = DmaCfg<BM>;
+#ifdef CDSEG_GEMM_TIMING
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), tc0 = __builtin_readcyclecounter();
+#endif
+  using D = DmaCfg<BM, GATHER>;
   constexpr int BN = 128, TN = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tail = smem + D::STAGES + D::ITAB;
@@ -761,10 +849,16 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     const int st = (kc - kc0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of step kc (the only VMEM in flight) has landed
     __builtin_amdgcn_s_barrier();                     // ... everybody's has, and nobody still reads the other stage
+#ifdef CDSEG_EXPERIMENTS
+    if (!(g.dbg & 2))
+#endif
     if (kc + 1 < kc1) {
       issue(kc + 1, st ^ 1);
       if (kc + 2 < kc1) fetch_idx(kc + 2);
     }
+#ifdef CDSEG_EXPERIMENTS
+    if (g.dbg & 1) continue;
+#endif
     const char* As = smem + st * D::A_BYTES;
     const char* Bs = smem + 2 * D::A_BYTES + st * D::W_BYTES;
 #pragma unroll
@@ -783,7 +877,24 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     }
   }
   __syncthreads();  // all fragment reads done: the stages become the C tile
+#ifdef CDSEG_EXPERIMENTS
+  if (g.dbg & 4) { if (acc[0][0][0] == 12345.678f) ((float*)g.out)[0] = acc[1][1][1]; return; }
+#endif
+#ifdef CDSEG_GEMM_TIMING
+  const unsigned long long tc1 = __builtin_readcyclecounter();
+#endif
   tile_epilogue<BN, BM>(g, acc, smem, tid, lane, wm, wn, m0, n0, zs);
+#ifdef CDSEG_GEMM_TIMING
+  if (tid == 0 && blockIdx.x < 16384) {
+    unsigned long long* d = g_gemm_t + (size_t)blockIdx.x * 8;
+    d[0] = rt0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = tc1 - tc0;
+    const unsigned long long tend = __builtin_readcyclecounter();
+    d[3] = tend - tc1;
+    // d[4..7] hold absolute stamps (start of half 0, after its staging barrier, start of half 1, after its barrier)
+    const unsigned long long a0 = d[4], a1 = d[5], b0 = d[6], b1 = d[7];
+    d[4] = a1 - a0; d[5] = b0 - a1; d[6] = b1 - b0; d[7] = tend - b1;
+  }
+#endif
 }
 
 template <typename CT, int BN, int NCH, int BM>
@@ -883,29 +994,32 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
         static bool a256 = false;
         if (!a256) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<256, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  DmaCfg<256>::LDS) != hipSuccess)
+                                  DmaCfg<256, GATHER>::LDS) != hipSuccess)
             return CDSEG_ERR_LAUNCH;
           a256 = true;
         }
-        hipLaunchKernelGGL((gemm_dma_kernel<256, GATHER>), grid, dim3(1024), DmaCfg<256>::LDS, s, p);
+        constexpr int lds256 = DmaCfg<256, GATHER>::LDS;
+        hipLaunchKernelGGL((gemm_dma_kernel<256, GATHER>), grid, dim3(1024), lds256, s, p);
       } else if (bm == 128) {
         static bool a128 = false;
         if (!a128) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<128, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  DmaCfg<128>::LDS) != hipSuccess)
+                                  DmaCfg<128, GATHER>::LDS) != hipSuccess)
             return CDSEG_ERR_LAUNCH;
           a128 = true;
         }
-        hipLaunchKernelGGL((gemm_dma_kernel<128, GATHER>), grid, dim3(512), DmaCfg<128>::LDS, s, p);
+        constexpr int lds128 = DmaCfg<128, GATHER>::LDS;
+        hipLaunchKernelGGL((gemm_dma_kernel<128, GATHER>), grid, dim3(512), lds128, s, p);
       } else {
         static bool a64 = false;
         if (!a64) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<64, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  DmaCfg<64>::LDS) != hipSuccess)
+                                  DmaCfg<64, GATHER>::LDS) != hipSuccess)
             return CDSEG_ERR_LAUNCH;
           a64 = true;
         }
-        hipLaunchKernelGGL((gemm_dma_kernel<64, GATHER>), grid, dim3(256), DmaCfg<64>::LDS, s, p);
+        constexpr int lds64 = DmaCfg<64, GATHER>::LDS;
+        hipLaunchKernelGGL((gemm_dma_kernel<64, GATHER>), grid, dim3(256), lds64, s, p);
       }
     }
   }
@@ -984,6 +1098,9 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   const int esz = a->compute_dtype == CDSEG_F32 ? 4 : 2;
   if (((long)a->lda * esz) & 15) return CDSEG_ERR_ARG;  // 16-byte row alignment for the vector loads
   GemmP p;
+#ifdef CDSEG_EXPERIMENTS
+  p.dbg = cdseg_knob("CDSEG_GEMM_DBG", 0);
+#endif
   p.A = a->A; p.W = a->W; p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.res = a->res;
   p.add_src = a->add_src; p.add_idx = a->add_idx; p.nbr = a->nbr; p.out_idx = a->out_idx;
   p.out = a->out; p.out2 = a->out2; p.M = a->M; p.N = a->N; p.K = a->K; p.kvol = a->kvol;

@@ -10,6 +10,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cdsegnet_amd import _lib  # noqa: E402
+if os.environ.get("CDSEG_AB_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["CDSEG_AB_LIB"])
 from cdsegnet_amd import ops, synth  # noqa: E402
 
 

@@ -6,5 +6,5 @@ TAG=${1:-r3}
 ( timeout 1500 python -m pytest tests -m gpu -x -q -s ) > gpurun_out/${TAG}_tests.log 2>&1
 tail -3 gpurun_out/${TAG}_tests.log
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/${TAG}_smoke.log 2>&1; tail -2 gpurun_out/${TAG}_smoke.log
-( timeout 600 python bench.py ) > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+( timeout 600 python bench.py ${BENCH_ARGS} ) > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 cat gpurun_out/${TAG}_bench.json
