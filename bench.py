@@ -9,7 +9,7 @@ under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
 
 A step = one SSI pass (DefaultSegmentorV2.inference: PTv3 dual backbone + cross-attention fusion) over one batch of
 --scenes-per-forward x --lanes (8 x 3 = 24) DISTINCT synthetic ScanNet-shaped scenes per GPU (BASELINE.json configs[1]:
-~120k voxels each - sizes 103k..137k, mean 120k - 6-ch features, 20 classes, bf16), inputs already resident in HBM.
+~120k voxels each - sizes 103k..137k, mean 120k - 6-ch features, 20 classes, IEEE-half trunk + fp32 heads by default), inputs already resident in HBM.
 Scenes are independent units: every rank runs its own scenes, no data-path collective ("scaling": "weak").  Every lane
 (HIP stream) gets one collated forward of 8 scenes (the reference's collate_fn batching), three forwards are in flight.
 `value` counts all points of all scenes; `single_scene_latency_ms` is the one-scene-at-a-time (bs = 1) latency, the
@@ -41,9 +41,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "bf16+head": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16+head": 2500.0, "fp16": 2500.0, "fp16+head": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 CPU_THREADS = 16  # fastest of {8, 16, 32, 64, 128} torch threads on the GPU box host (tools/cpu_sweep.py, profiles/r02_cpu_sweep.txt)
+
+
+def dtype_name(precision):
+    """The arithmetic type of the path for the bench line's `dtype`."""
+    return "f32" if precision == "fp32" else ("f16" if precision.startswith("fp16") else "bf16")
 
 
 def parse():
@@ -56,10 +61,11 @@ def parse():
     ap.add_argument("--robust", action="store_true",
                     help="BASELINE config 5: every scene gets Gaussian coord noise sigma = 0.05 m + 50 %% random drop and is "
                          "re-voxelised (~half the points, scattered voxels)")
-    ap.add_argument("--precision", default="bf16+head", choices=["bf16+head", "bf16", "fp32"],
-                    help="bf16+head (default): bf16 MFMA operands, fp32 accumulation and residual stream, the logit head "
-                         "GEMM in exact fp32 on the fp32 stream (free, profiles/r03_bf16_budget.txt); bf16: the head in bf16 "
-                         "too; fp32: the 1e-3 parity mode")
+    ap.add_argument("--precision", default="fp16+head", choices=["fp16+head", "fp16", "bf16+head", "bf16", "fp32"],
+                    help="<16-bit type>[+head]: 16-bit MFMA operands and activations (fp16 = IEEE half, the reference's own "
+                         "attention dtype, 11-bit mantissa; bf16 = bfloat16, 8-bit), fp32 accumulation and residual stream; "
+                         "+head: the logit head GEMM in exact fp32 on the fp32 stream (free, profiles/r03_bf16_budget.txt); "
+                         "fp32: the 1e-3 parity mode")
     ap.add_argument("--protocol", default="throughput", choices=["throughput", "paper"],
                     help="paper: the reference's timing protocol (tools/test_time.py:36-37,79 + configs/scannet/"
                          "CDSegNet_time.py): 312 distinct scenes, one at a time (bs = 1), no TTA, wall clock")
@@ -68,7 +74,7 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=120000)
     ap.add_argument("--cpu-threads", type=int, default=CPU_THREADS)
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the roofline pass after the timed region")
-    ap.add_argument("--no-agreement", action="store_true", help="skip the bf16-vs-fp32 agreement leg")
+    ap.add_argument("--no-agreement", action="store_true", help="skip the 16-bit-vs-fp32 agreement leg")
     ap.add_argument("--scenes-per-forward", type=int, default=8,
                     help="scenes collated into one forward (the reference's collate_fn batching); one step = "
                          "scenes-per-forward x lanes scenes (one batch per lane)")
@@ -217,7 +223,7 @@ def paper_protocol(args, model, cfg, dev, rank, world, dist):
         print(json.dumps({
             "metric": "seconds for the 312-scene val split, 1-step inference, bs = 1 (reference protocol tools/test_time.py)",
             "value": sec, "unit": "s", "n_gpus": world, "steps": n_scenes, "warmup": 3, "ms_per_step": 1e3 * sec * world / n_scenes,
-            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision != "fp32" else "f32",
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": dtype_name(args.precision),
             "data": "synthetic",
             "config": {"workload": f"312 distinct synthetic ScanNet-shaped scenes, one at a time, no TTA, {int(tp.item()) / n_scenes:.0f} voxels mean",
                        "precision": args.precision, "reference_figure": "56 s on an RTX 3090 (BASELINE.md; real scans, other hardware)"},
@@ -279,7 +285,7 @@ def shard_mode(args, model, cfg, dev, rank, world, dist):
         print(json.dumps({
             "metric": "points/sec/node (one global scene list sharded over the GPUs, 1-step)", "value": int(pts.item()) * args.steps / el,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision != "fp32" else "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype_name(args.precision),
             "data": "synthetic",
             "config": {"workload": f"{args.shard} {args.dataset}-shaped scenes ({min(sizes)}..{max(sizes)} voxels), LPT-sharded over "
                                    f"{world} GPU(s), {args.scenes_per_forward} collated per forward, {args.lanes} forwards in flight",
@@ -341,7 +347,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from cdsegnet_amd import configs, ops
+    from cdsegnet_amd import _lib, configs, ops
     from cdsegnet_amd import dist as cdist
     from cdsegnet_amd.param_init import fill_state_dict
     from cdsegnet_amd.registry import build_model
@@ -355,7 +361,9 @@ def main():
         model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     low = args.precision != "fp32"
-    T = torch.bfloat16 if low else torch.float32
+    variant = "f16" if args.precision.startswith("fp16") else "bf16"  # which build of the library this run calls
+    T = ops.LP_DTYPES[variant] if low else torch.float32
+    _lib.use(variant).__enter__()  # this thread's direct op calls (kernel timer) go to the engine's build
     if world > 1:  # weights: one RCCL broadcast from rank 0 in the compute dtype (replaces the DDP-ctor broadcast)
         cdist.broadcast_model(model, src=0, weight_dtype=T if T != torch.float32 else None)
     model.precision = args.precision
@@ -469,7 +477,7 @@ def main():
         torch.cuda.synchronize()
         iso["paper_s"] = time.perf_counter() - t1
 
-    # ---- bf16 accuracy on a bench scene: same draws through the exact-fp32 HIP path (rank 0)
+    # ---- 16-bit accuracy on a bench scene: same draws through the exact-fp32 HIP path (rank 0)
     agreement = None
     if rank == 0 and low and not args.no_agreement:
         d0 = dict(dicts[0])
@@ -480,8 +488,17 @@ def main():
         a = model.inference(dict(d0), eval=False, draws=dict(draws))["seg_logits"].clone()
         model.precision = "fp32"
         b = model.inference(dict(d0), eval=False, draws=dict(draws))["seg_logits"]
-        agreement = dict(points=sizes[0], argmax_agreement=float((a.argmax(1) == b.argmax(1)).float().mean()),
-                         max_abs_logit_diff=float((a - b).abs().max()), mean_abs_logit=float(b.abs().mean()),
+        top2 = b.topk(2, dim=1).values
+        margin = top2[:, 0] - top2[:, 1]  # fp32 top-1 / top-2 margin of every point
+        flipped = a.argmax(1) != b.argmax(1)
+        agreement = dict(points=sizes[0], precision=args.precision,
+                         argmax_agreement=float((~flipped).float().mean()),
+                         max_abs_logit_diff=float((a - b).abs().max()), rms_logit_diff=float((a - b).pow(2).mean().sqrt()),
+                         mean_abs_logit=float(b.abs().mean()),
+                         # random-init weights give near-ties: where the arg-max flips, how far apart were the two classes?
+                         fp32_margin_median=float(margin.median()),
+                         points_with_margin_below_0p01=float((margin < 0.01).float().mean()),
+                         largest_margin_that_flipped=float(margin[flipped].max()) if bool(flipped.any()) else 0.0,
                          reference="exact-fp32 HIP path (within 5e-6 of the reference's CPU logits, tests/)")
         model.precision = args.precision
         model.noise_source = "device"
@@ -511,7 +528,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if low else "f32",
+            "dtype": dtype_name(args.precision),
             "data": "synthetic",
             "config": {"workload": f"{shape}-shape scenes{' after coord noise 0.05 m + 50 % drop + re-voxelisation' if args.robust else ''}"
                                    f", CDSegNet 1-step inference (PT-v3m1 dual backbone, 101.4M params, random-init), "
@@ -530,7 +547,7 @@ def main():
             achieved = iso["attn_work"] / (iso["attn_ms"] * 1e-3) / 1e12
             res["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                "kernel": "attn_bf16_kernel" if low else "attn_f32_kernel",
+                "kernel": ("attn_bf16_kernel" + (" (IEEE-half build: half Q K^T, bfloat16 P V)" if variant == "f16" else "")) if low else "attn_f32_kernel",
                 "launches_per_forward": iso["attn_launches"] / r, "avg_launch_us": 1e3 * iso["attn_ms"] / iso["attn_launches"],
                 "algorithmic_gflop_per_forward": iso["attn_work"] / r / 1e9, "kernel_ms_per_forward": iso["attn_ms"] / r,
                 "algorithmic_bytes_per_launch": iso["attn_bytes"] / max(1, iso["attn_launches"]),
@@ -551,7 +568,7 @@ def main():
                 "wall_ms": iso["forward_wall_ms"], "achieved_tflops": wk["total"] / (iso["forward_wall_ms"] * 1e-3) / 1e12,
                 "frac_of_mfma_peak": wk["total"] / (iso["forward_wall_ms"] * 1e-3) / 1e12 / peak,
                 "mflop_per_point": wk["total"] / iso["points"] / 1e6,
-                "compulsory_bytes": "inputs 60 B / point + logits + the weights once (203 MB bf16): the forward is not HBM-bound as a whole",
+                "compulsory_bytes": "inputs 60 B / point + logits + the weights once (203 MB in 16 bits): the forward is not HBM-bound as a whole",
                 "flops": "SURVEY 8(d) formulas on the plan's real sizes; sparse convs count occupied neighbours only; the dead c-decoder is not run"}
             if iso["conv_ms"] > 0:
                 gbs = iso["conv_bytes"] / (iso["conv_ms"] * 1e-3) / 1e9
@@ -579,7 +596,7 @@ def main():
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = "profiles/r03_attention_traffic.json (offline rocprofv3 --pmc passes over bench.py's own forwards)"
         if agreement:
-            res["bf16_agreement"] = agreement
+            res["agreement_vs_fp32"] = agreement
         m = cdist.metrics(counts)
         res["eval_counters"] = {"mIoU_random_init": m["mIoU"], "points_counted": int(counts[2].sum())}
         if args.cpu_baseline and world == 1:

@@ -5,10 +5,12 @@ module raises.  (`python -m cdsegnet_amd.build` or `__graft_entry__.build()` bui
 """
 import ctypes
 import os
+import threading
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_long, c_size_t, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcdseg_hip.so")
+LIB_PATH = os.path.join(HERE, "libcdseg_hip.so")          # 16-bit type = bfloat16
+LIB_PATH_F16 = os.path.join(HERE, "libcdseg_hip_f16.so")  # 16-bit type = IEEE half (same sources, -DCDSEG_LP_F16)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SWISH = 0, 1, 2
@@ -158,24 +160,50 @@ SIGNATURES = {
     "cdseg_axpy": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
 }
 
-_lib = None
+_libs = {}
+_tls = threading.local()  # .variant: which build the calling host thread's ops go to ("bf16" default, "f16")
+VARIANTS = ("bf16", "f16")
 
 
-def load():
-    """Load the HIP library; raises CdsegError (never falls back) if it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def active():
+    return getattr(_tls, "variant", "bf16")
+
+
+class use:
+    """`with _lib.use("f16"):` routes the calling thread's ops to the IEEE-half build of the library."""
+
+    def __init__(self, variant):
+        if variant not in VARIANTS:
+            raise ValueError(variant)
+        self.variant = variant
+
+    def __enter__(self):
+        self.prev = active()
+        _tls.variant = self.variant
+        return self
+
+    def __exit__(self, *exc):
+        _tls.variant = self.prev
+        return False
+
+
+def load(variant=None):
+    """Load the HIP library (the calling thread's active build); raises CdsegError (never falls back) if it is absent."""
+    v = variant or active()
+    lib = _libs.get(v)
+    if lib is not None:
+        return lib
+    path = LIB_PATH if v == "bf16" else LIB_PATH_F16
+    if not os.path.exists(path):
         raise CdsegError(
-            f"{LIB_PATH} is missing: the MI355X HIP extension was not built. "
+            f"{path} is missing: the MI355X HIP extension was not built. "
             "Run `python -m cdsegnet_amd.build` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[v] = lib
     return lib
 
 

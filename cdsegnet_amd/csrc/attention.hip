@@ -120,7 +120,7 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 // one 32-key x 32-query tile of S^T = K Q'^T + C  (Q' = Q * scale * log2 e, C = -bound: see below)
 __device__ __forceinline__ f32x16_t qk_tile(const char* k_lane, bf16x8_t qf, const f32x16_t& c0) {
   const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lane);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, c0, 0, 0, 0);
+  return mfma_32x32x16_bf16(kf, qf, c0);
 }
 
 __device__ __forceinline__ float tile_max(const f32x16_t& s, float m) {
@@ -152,20 +152,19 @@ __device__ __forceinline__ void pv_tile(const f32x16_t& s, int kt, int h, int L,
   for (int mf = 0; mf < 2; ++mf) {
     union { bf16x8_t v; uint32_t u[4]; } pf;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
+    for (int j = 0; j < 4; ++j) pf.u[j] = pack_truebf16x2(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1]);
     const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(va + 512 * mf));
     const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(va + 512 * mf + 256));
     const bf16x8_t vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o, 0, 0, 0);
+    o = mfma_32x32x16_truebf16(vf, pf.v, o);
   }
 }
 
 __device__ __forceinline__ float sq8_bf16(const uint4& a) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  float t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.x), __builtin_bit_cast(bf2, a.x), 0.f, false);
-  t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.y), __builtin_bit_cast(bf2, a.y), t, false);
-  t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.z), __builtin_bit_cast(bf2, a.z), t, false);
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.w), __builtin_bit_cast(bf2, a.w), t, false);
+  float t = dot2_bf16(a.x, a.x, 0.f);
+  t = dot2_bf16(a.y, a.y, t);
+  t = dot2_bf16(a.z, a.z, t);
+  return dot2_bf16(a.w, a.w, t);
 }
 
 __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
@@ -268,6 +267,19 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     for (int i = 0; i < 4; ++i) {
       const int pc = wave + ATTN_WAVES * i;
       if (pc < nkt) {
+        if (LP_IS_F16) {
+          // half build: Q and K stay half (the scores keep 11-bit operands), the P V product runs in bfloat16 - P =
+          // exp2(s - bound) needs fp32's exponent range (the bound may be loose by tens of octaves, half underflows at
+          // 2^-24) - so the lane rewrites the 8 V values it fetched itself as bfloat16, in place
+          uint4* vp = reinterpret_cast<uint4*>(smem + KV_STAGE + pc * 1024 + lane * 16);
+          uint4 u = *vp;
+          float a0, a1;
+          unpack_bf16x2(u.x, a0, a1); u.x = pack_truebf16x2(a0, a1);
+          unpack_bf16x2(u.y, a0, a1); u.y = pack_truebf16x2(a0, a1);
+          unpack_bf16x2(u.z, a0, a1); u.z = pack_truebf16x2(a0, a1);
+          unpack_bf16x2(u.w, a0, a1); u.w = pack_truebf16x2(a0, a1);
+          *vp = u;
+        }
         float t = sq8_bf16(*reinterpret_cast<const uint4*>(Ks + pc * 1024 + lane * 16));
         t += __shfl_xor(t, 1, 64);  // the key's other half
         kn2 = fmaxf(kn2, t);
@@ -306,8 +318,11 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
       union { bf16x8_t v; uint32_t u[4]; } qs;
       const uint32_t qr[4] = {q_cur.x, q_cur.y, q_cur.z, q_cur.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        qs.u[j] = pack_bf16x2(__uint_as_float(qr[j] << 16) * c, __uint_as_float(qr[j] & 0xffff0000u) * c);
+      for (int j = 0; j < 4; ++j) {
+        float lo, hi;
+        unpack_bf16x2(qr[j], lo, hi);
+        qs.u[j] = pack_bf16x2(lo * c, hi * c);
+      }
       qf = qs.v;
       asm volatile("" : "+v"(qf));
     }

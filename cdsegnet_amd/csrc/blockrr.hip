@@ -143,7 +143,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void head_rr_kernel(HeadRR p) {
           v[t] = *reinterpret_cast<const f32x4_t*>(pr + q * Q + 4 * t);  // + bl (C operand)
 #pragma unroll
           for (int s = 0; s < KS; ++s)
-            v[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wl[t][s]), yf[s], v[t], 0, 0, 0);
+            v[t] = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wl[t][s]), yf[s], v[t]);
         }
       }
       float mean, rstd;
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void head_rr_kernel(HeadRR p) {
         f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(pr + 6 * C + q * QQ + 4 * ot + 4);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[cur][0][s]), hf[s], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[cur][1][s]), hf[s], a1, 0, 0, 0);
+          a0 = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[cur][0][s]), hf[s], a0);
+          a1 = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[cur][1][s]), hf[s], a1);
         }
         if (ok) *reinterpret_cast<bf16x8_t*>(p.qkv + row * p.ldqkv + q * QQ + 4 * ot) = pack8(a0, a1);
       }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void tail_rr_kernel(TailRR p) {
           f32x4_t a = *reinterpret_cast<const f32x4_t*>(pr + q * Q + 4 * t);
 #pragma unroll
           for (int s = 0; s < KS; ++s)
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wp[t][s]), of[s], a, 0, 0, 0);
+            a = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wp[t][s]), of[s], a);
           const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.x + rr * p.ldx + q * Q + 4 * t);
           x1[t] = a + r;
         }
@@ -295,15 +295,15 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void tail_rr_kernel(TailRR p) {
         f32x4_t h1 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + 32 * u + 16 + 4 * q);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[0][s]), hf[s], h0, 0, 0, 0);
-          h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[1][s]), hf[s], h1, 0, 0, 0);
+          h0 = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[0][s]), hf[s], h0);
+          h1 = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[1][s]), hf[s], h1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { h0[r] = gelu_erf(h0[r]); h1[r] = gelu_erf(h1[r]); }
         const bf16x8_t Hf = pack8(h0, h1);
 #pragma unroll
         for (int t = 0; t < CT; ++t)
-          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w2[t]), Hf, acc2[t], 0, 0, 0);
+          acc2[t] = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w2[t]), Hf, acc2[t]);
       }
       if (ok) {
 #pragma unroll

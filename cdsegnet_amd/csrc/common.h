@@ -5,9 +5,15 @@
 
 #include "../../include/cdseg.h"
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits (storage type)
+// The 16-bit storage / MFMA operand type of the build.  The library is compiled twice from the same sources:
+//   libcdseg_hip.so      bfloat16 (8-bit mantissa, fp32's exponent range)                      precision "bf16*"
+//   libcdseg_hip_f16.so  IEEE half (-DCDSEG_LP_F16: 11-bit mantissa, |x| <= 65504, conversions SATURATE) precision "fp16*"
+// Same MFMA rate, same bytes; every name below keeps "bf16" (the default build) and means "the build's 16-bit type";
+// the ABI's CDSEG_BF16 dtype code likewise.  The reference's own GPU path computes its attention in half
+// (point_transformer_v3m1_base.py:282 `qkv.half()`).
+typedef uint16_t bf16_t;  // raw bits (storage type)
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA bf16 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA 16-bit A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 MFMA accumulator
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
@@ -20,15 +26,80 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accu
     if (e__ != hipSuccess) return CDSEG_ERR_LAUNCH;            \
   } while (0)
 
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+
+// bfloat16 whatever the build's 16-bit type is (the attention kernel keeps its probabilities in bfloat16: they need
+// fp32's exponent range, see attention.hip)
+typedef __bf16 hw_truebf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_truebf16x2(float lo, float hi) {
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_truebf16x2_t));
+}
+__device__ __forceinline__ f32x16_t mfma_32x32x16_truebf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+#ifdef CDSEG_LP_F16
+typedef _Float16 hw_lp_t;
+typedef _Float16 hw_lpx2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 hw_lpx8_t __attribute__((ext_vector_type(8)));
+constexpr uint32_t LP_ONE_BITS = 0x3C00u;  // 1.0
+constexpr bool LP_IS_F16 = true;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+
+// both halves of a packed pair (v_cvt_f32_f16 + its SDWA form)
+__device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) {
+  const hw_lpx2_t h = __builtin_bit_cast(hw_lpx2_t, u);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
+
+// float -> half, round-to-nearest-even, saturating at +-65504 (v_med3_f32 + v_cvt_pk_f16_f32): an activation outlier
+// of a trained checkpoint clamps instead of turning the rest of the forward into inf / NaN
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  const _Float16 b = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+  return __builtin_bit_cast(uint16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const hw_f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_lpx2_t));
+}
+
+// values known to lie inside the range (probabilities, pre-scaled operands): no clamp
+__device__ __forceinline__ uint32_t pack_bf16x2_inrange(float lo, float hi) {
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_lpx2_t));
+}
+
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(hw_lpx2_t, a), __builtin_bit_cast(hw_lpx2_t, b), c, false);
+}
+
+__device__ __forceinline__ f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hw_lpx8_t, a), __builtin_bit_cast(hw_lpx8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hw_lpx8_t, a), __builtin_bit_cast(hw_lpx8_t, b), c, 0, 0, 0);
+}
+#else
+typedef __bf16 hw_lp_t;
+typedef __bf16 hw_lpx2_t __attribute__((ext_vector_type(2)));
+constexpr uint32_t LP_ONE_BITS = 0x3F80u;  // 1.0
+constexpr bool LP_IS_F16 = false;
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
 
+__device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) {
+  lo = __uint_as_float(u << 16);
+  hi = __uint_as_float(u & 0xffff0000u);
+}
+
 // float -> bfloat16, round-to-nearest-even (= torch's cast): the compiler lowers these to
 // gfx950's v_cvt_pk_bf16_f32, one instruction per pair
-typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   const __bf16 b = (__bf16)f;
   return __builtin_bit_cast(uint16_t, b);
@@ -36,9 +107,23 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   const hw_f32x2_t v = {lo, hi};
-  const hw_bf16x2_t b = __builtin_convertvector(v, hw_bf16x2_t);
+  const hw_lpx2_t b = __builtin_convertvector(v, hw_lpx2_t);
   return __builtin_bit_cast(uint32_t, b);
 }
+
+__device__ __forceinline__ uint32_t pack_bf16x2_inrange(float lo, float hi) { return pack_bf16x2(lo, hi); }
+
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hw_lpx2_t, a), __builtin_bit_cast(hw_lpx2_t, b), c, false);
+}
+
+__device__ __forceinline__ f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
         for (int ct = 0; ct < K::CT; ++ct)
 #pragma unroll
           for (int g = 0; g < K::RG; ++g)
-            acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xb[B][g][ks], acc[g][ct], 0, 0, 0);
+            acc[g][ct] = mfma_16x16x32_bf16(wf[ks][ct], xb[B][g][ks], acc[g][ct]);
     };
     int o[NB];
     static_for<0, NB - 1>([&](auto J) {

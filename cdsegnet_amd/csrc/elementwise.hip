@@ -8,8 +8,10 @@ namespace {
 __device__ __forceinline__ float4 load4(const void* p, int dtype, long idx /* element index, %4==0 */) {
   if (dtype == CDSEG_F32) return *reinterpret_cast<const float4*>((const float*)p + idx);
   const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)p + idx);
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                     __uint_as_float(u.y & 0xffff0000u));
+  float4 r;
+  unpack_bf16x2(u.x, r.x, r.y);
+  unpack_bf16x2(u.y, r.z, r.w);
+  return r;
 }
 
 __device__ __forceinline__ void store4(void* p, int dtype, long idx, float4 v) {

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_16x16x32_bf16(a[i], b[j], acc[i][j]);
       }
     } else {
       // per 32-wide k block: k-slot g of MFMA step (h, ss) holds k = 16*h + 4*g + ss (same map for A and W)
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_16x16x32_bf16(a[i], b[j], acc[i][j]);
     }
   }
   __syncthreads();  // all fragment reads done: the stages become the C tile

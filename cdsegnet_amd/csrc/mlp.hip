@@ -104,7 +104,7 @@ __global__ __launch_bounds__(4 * BM) void mlp_fused_kernel(MlpP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < TN2; ++t) acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc2[i][t], 0, 0, 0);
+        for (int t = 0; t < TN2; ++t) acc2[i][t] = mfma_16x16x32_bf16(a[i], b[t], acc2[i][t]);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(4 * BM) void mlp_fused_kernel(MlpP p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int t = 0; t < TN1; ++t)
-          acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc1[i][t], 0, 0, 0);
+          acc1[i][t] = mfma_16x16x32_bf16(a[i], b[t], acc1[i][t]);
     }
     // bias + GELU + bf16 -> Hs in A-operand layout.  MFMA C layout: col = lane & 15, row = 4 (lane >> 4) + r
 #pragma unroll
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(4 * BM) void mlp_fused_kernel(MlpP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < TN2; ++t) acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc2[i][t], 0, 0, 0);
+        for (int t = 0; t < TN2; ++t) acc2[i][t] = mfma_16x16x32_bf16(a[i], b[t], acc2[i][t]);
     }
     __syncthreads();  // W1s / W2s / Hs are rewritten by the next hidden tile (or become the C tile)
   }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(4 * BM) void cpe_head_fused_kernel(HeadP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+        for (int t = 0; t < TN; ++t) acc[i][t] = mfma_16x16x32_bf16(a[i], b[t], acc[i][t]);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -175,9 +175,7 @@ __global__ __launch_bounds__(STEM_WAVES * 64) void stem5_kernel(StemP p) {
               const uint32_t wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
-                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-                acc[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, xs[kp]), __builtin_bit_cast(bf2, wv[j]), acc[j],
-                                                        false);
+                acc[j] = dot2_bf16(xs[kp], wv[j], acc[j]);
               }
             }
           }

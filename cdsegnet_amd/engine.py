@@ -25,7 +25,7 @@ import threading
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import CdsegError
 
 CURVES = ("z", "z-trans", "hilbert", "hilbert-trans")
@@ -158,11 +158,17 @@ class State:
 
 
 class Engine:
-    def __init__(self, model, precision="bf16"):
-        if precision not in ("bf16", "bf16+head", "fp32"):
+    PRECISIONS = ("bf16", "bf16+head", "fp16", "fp16+head", "fp32")
+
+    def __init__(self, model, precision="bf16", variant=None):
+        """precision: the 16-bit trunk type ("bf16*": bfloat16, "fp16*": IEEE half - the library is built once for each,
+        csrc/common.h) with "+head" = seg heads in exact fp32, or "fp32" (exact-fp32 MFMA everywhere).
+        variant: which build an fp32 engine calls (the fp32 twin of a half engine stays inside the half build)."""
+        if precision not in self.PRECISIONS:
             raise ValueError(precision)
         self.model, self.precision = model, precision
-        self.T = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.variant = variant or ("f16" if precision.startswith("fp16") else "bf16")
+        self.T = torch.float32 if precision == "fp32" else ops.LP_DTYPES[self.variant]
         self.device = None
         self.w = None
         self.rng_offset = 0
@@ -181,13 +187,17 @@ class Engine:
         # stages of a bf16 forward that run through the exact-fp32 twin engine instead (keys: n_emb, c_emb, n_enc0..4,
         # c_enc0..2, x, n_dec3..0, c_dec1..0, n_head, c_head).  The error budget of the bf16 mode is measured with it
         # (tools/bf16_budget.py); precision "bf16+head" is hi = {"n_head"}.
-        self.hi = frozenset(("n_head", "c_head")) if precision == "bf16+head" else frozenset()
+        self.hi = frozenset(("n_head", "c_head")) if precision.endswith("+head") else frozenset()
         self._twin = None
 
     # ------------------------------------------------------------------ weights
     def prepare(self, device):
         if self.w is not None and self.device == device:
             return
+        with _lib.use(self.variant):
+            self._prepare(device)
+
+    def _prepare(self, device):
         self.device = device
         T = self.T
         w = {}
@@ -360,7 +370,7 @@ class Engine:
         if key not in self.hi or self.T == torch.float32:
             return self
         if self._twin is None:
-            self._twin = Engine(self.model, "fp32")
+            self._twin = Engine(self.model, "fp32", variant=self.variant)
             self._twin.use_native_blocks = self.use_native_blocks
         self._twin.prepare(self.device)
         return self._twin
@@ -860,7 +870,8 @@ class Engine:
     def inference(self, input_dict, noise_level=None, draws=None):
         """Single-step inference (ref: default.py:371-422)."""
         try:
-            return self._inference(input_dict, noise_level, draws)
+            with _lib.use(self.variant):
+                return self._inference(input_dict, noise_level, draws)
         finally:
             if hasattr(ops, "unbind_stream"):
                 ops.unbind_stream()
@@ -868,7 +879,8 @@ class Engine:
     def inference_ddim(self, input_dict, step=1, mode="avg", noise_level=None, draws=None):
         """Multi-step inference MSAI (mode="avg") / MSFI ("final") (ref: default.py:278-369)."""
         try:
-            return self._inference_ddim(input_dict, step, mode, noise_level, draws)
+            with _lib.use(self.variant):
+                return self._inference_ddim(input_dict, step, mode, noise_level, draws)
         finally:
             if hasattr(ops, "unbind_stream"):
                 ops.unbind_stream()

@@ -405,7 +405,9 @@ class DefaultSegmentorV2(nn.Module):
         if T_dim != -1:
             self.t_emb_table = calc_t_emb_table(T, T_dim)  # (T, T_dim) host table, uploaded on first use
         # engine knobs (not part of the reference API)
-        self.precision = "bf16"        # "bf16" (MFMA bf16, fp32 accumulate/residual) | "fp32" (exact-fp32 MFMA)
+        # "fp16+head" (default) | "fp16" | "bf16+head" | "bf16": 16-bit MFMA operands / activations (IEEE half or bfloat16),
+        # fp32 accumulation and residual stream, "+head" = seg heads in exact fp32 | "fp32": exact-fp32 MFMA everywhere
+        self.precision = "fp16+head"
         self._lanes = {}
         self.noise_source = "torch_cpu"  # "torch_cpu" replays the reference's CPU-generator draws | "device"
         # noise_level jitter: "torch_cpu" = the CPU-run reference's draw order (golden vectors) | "device" = device

@@ -15,7 +15,28 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_SWISH, BF16, F32, GemmArgs, check
 
 __all__ = ["ACT_NONE", "ACT_GELU", "ACT_SWISH", "F32", "BF16"]
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+LP_DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16}  # the 16-bit type of each build of the library
+
+
+class _Dtypes:
+    """torch dtype -> ABI dtype code.  A 16-bit tensor must be of the ACTIVE build's 16-bit type (`_lib.use`): the ABI
+    code CDSEG_BF16 means "the build's 16-bit type", handing half bits to the bfloat16 build would compute garbage."""
+
+    def __getitem__(self, dtype):
+        if dtype == torch.float32:
+            return F32
+        if dtype == LP_DTYPES[_lib.active()]:
+            return BF16
+        raise _lib.CdsegError(f"{dtype} tensors do not belong to the active build of the library ({_lib.active()})")
+
+
+_DT = _Dtypes()
+
+
+def is_lp(dtype):
+    return dtype in (torch.bfloat16, torch.float16)
+
+
 _WS = {}
 
 
@@ -502,7 +523,7 @@ FUSED_MLP_CHANNELS = (32, 64, 128)
 def mlp_fused_ok(h, hidden):
     """The fused MLP kernel covers bf16 with C = 32 / 64 / 128 and the standard 4x hidden width."""
     c = h.shape[1]
-    return (h.dtype == torch.bfloat16 and c in FUSED_MLP_CHANNELS and hidden == 4 * c and
+    return (is_lp(h.dtype) and c in FUSED_MLP_CHANNELS and hidden == 4 * c and
             c <= 128)
 
 
@@ -517,7 +538,7 @@ def mlp_fused(h, w1, b1, w2, b2, x, xc=None):
 
 def cpe_head_fused_ok(y):
     """cpe linear + LN + residual + LN1 + qkv in one launch: bf16, C = 32 / 64."""
-    return y.dtype == torch.bfloat16 and y.shape[1] in (32, 64)
+    return is_lp(y.dtype) and y.shape[1] in (32, 64)
 
 
 def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
@@ -533,7 +554,7 @@ def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
 def attn_tail_fused_ok(o, hidden):
     """proj + LayerNorm + MLP in one launch: bf16, C = 32 / 64."""
     c = o.shape[1]
-    return o.dtype == torch.bfloat16 and c in (32, 64) and hidden == 4 * c
+    return is_lp(o.dtype) and c in (32, 64) and hidden == 4 * c
 
 
 def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5):
@@ -548,7 +569,7 @@ def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5)
 
 def block_rr_ok(channels, dtype):
     """Register-resident Block head / tail kernels (csrc/blockrr.hip): bf16, C = 32 / 64."""
-    return dtype == torch.bfloat16 and channels in (32, 64)
+    return is_lp(dtype) and channels in (32, 64)
 
 
 def block_rr_head_on():
@@ -619,7 +640,7 @@ def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start
 
 def stem5_ok(cout, dtype):
     """The map-free stem kernel (csrc/stem.hip) covers the shipped stems: 32 output channels, bf16."""
-    return cout == 32 and dtype == torch.bfloat16
+    return cout == 32 and is_lp(dtype)
 
 
 def child_info(zcode_sorted, seg_start, m):
@@ -633,7 +654,7 @@ def child_info(zcode_sorted, seg_start, m):
 def stem5_pack(w):
     """(32, 125 * 8) bf16 stem weight -> LDS image of the stem kernel (built once per weight)."""
     _need_gpu(w)
-    assert w.dtype == torch.bfloat16 and tuple(w.shape) == (32, 1000)
+    assert is_lp(w.dtype) and tuple(w.shape) == (32, 1000)
     img = torch.empty(_lib.load().cdseg_stem5_wimg_bytes(), dtype=torch.uint8, device=w.device)
     check(_lib.load().cdseg_stem5_pack(_ptr(w), _ptr(img), _stream()), "stem5_pack")
     return img
@@ -651,7 +672,7 @@ def stem5(x8, wimg, scale, shift, grid, cluster, parent_nbr3, cinfo, depth, out,
 def subm_conv3_ok(x):
     """The weight-stationary live-list conv (csrc/conv.hip) covers the wide bf16 stages: C = 32 / 64."""
     n = x.shape[0]  # (32-bit buffer offsets inside the kernel: larger inputs take the gathered GEMM)
-    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (32, 64) and x.stride(0) == x.shape[1] and
+    return (is_lp(x.dtype) and x.dim() == 2 and x.shape[1] in (32, 64) and x.stride(0) == x.shape[1] and
             n * 27 * 4 < 2 ** 31 and n * x.shape[1] * 2 < 2 ** 31 - 65536)
 
 

@@ -13,6 +13,13 @@ ACT_NONE, ACT_GELU, ACT_SWISH = 0, 1, 2
 F32, BF16 = 0, 1
 
 
+LP_DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def is_lp(dtype):
+    return dtype in (torch.bfloat16, torch.float16)
+
+
 def grid_max(grid):
     return grid.max().reshape(1).to(torch.int64)
 

@@ -15,12 +15,32 @@ import cdsegnet_amd.models  # noqa: F401  (registers the two model names)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib():
-    if not os.path.exists(_lib.LIB_PATH):
+@pytest.fixture(scope="module", params=_lib.VARIANTS)
+def lib(request):
+    """Both builds of the library: bfloat16 and IEEE half as the 16-bit type (same sources, same ABI)."""
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.LIB_PATH_F16)):
         from cdsegnet_amd.build import build_library
         build_library()
-    return _lib.load()
+    return _lib.load(request.param)
+
+
+def test_library_variant_routing_is_per_thread_and_checked():
+    import threading
+    from cdsegnet_amd import ops
+    assert _lib.active() == "bf16"
+    seen = {}
+    with _lib.use("f16"):
+        assert _lib.active() == "f16"
+        assert ops._DT[torch.float16] == _lib.BF16 and ops._DT[torch.float32] == _lib.F32
+        with pytest.raises(_lib.CdsegError):  # bfloat16 bits handed to the half build
+            ops._DT[torch.bfloat16]
+        t = threading.Thread(target=lambda: seen.setdefault("other", _lib.active()))
+        t.start(); t.join()
+    assert seen["other"] == "bf16" and _lib.active() == "bf16"
+    with pytest.raises(_lib.CdsegError):
+        ops._DT[torch.float16]
+    with pytest.raises(ValueError):
+        _lib.use("fp8")
 
 
 def test_library_exports_every_declared_symbol(lib):

@@ -76,19 +76,25 @@ def test_mini_fp32_matches_reference_golden(name):
     assert agree > 0.999
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", E2E)
-def test_mini_bf16_close_to_reference_golden(name):
+def test_mini_bf16_close_to_reference_golden(name, precision):
     fx = load_fixture(name + ".npz")
     cfg, sd = fixture_cfg(fx), fixture_state_dict(fx)
     nl = float(fx["noise_level"]) if "noise_level" in fx.files else None
-    model = build(cfg, sd, "bf16", enable_flash=False)
+    model = build(cfg, sd, precision, enable_flash=False)
     logits = run(model, fixture_input(fx), fixture_draws(fx), nl)
-    err, agree = report(f"{name} bf16 vs reference", logits, fx["logits"])
+    err, agree = report(f"{name} {precision} vs reference", logits, fx["logits"])
     assert np.isfinite(logits).all()
-    # measured (round 2): 1.0e-2 .. 1.6e-2 / 99.1 .. 100 %; bounds = measured + ~2x margin so that a regression shows.
-    # bf16 operand rounding through ~20 blocks; logits are O(1); random-init logits have small class margins
-    assert err < 0.04
-    assert agree > 0.985
+    if precision == "bf16":
+        # measured (round 2): 1.0e-2 .. 1.6e-2 / 99.1 .. 100 %; bounds = measured + ~2x margin so that a regression shows.
+        # bf16 operand rounding through ~20 blocks; logits are O(1); random-init logits have small class margins
+        assert err < 0.04
+        assert agree > 0.985
+    else:
+        # IEEE half trunk (11-bit mantissa, the reference's own attention dtype): 8x less rounding per operand
+        assert err < 0.008
+        assert agree > 0.995
 
 
 def test_seeded_default_draws_replay_the_reference():
@@ -108,7 +114,7 @@ def test_seeded_default_draws_replay_the_reference():
     assert err < 1e-3
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_native_block_executor_equals_binding_sequence(precision):
     """The C++ Block executor (cdseg_block_forward) issues the same kernels as the per-op binding path."""
     fx = load_fixture("full_e2e_8k.npz")
@@ -124,7 +130,7 @@ def test_native_block_executor_equals_binding_sequence(precision):
 
 
 @pytest.mark.parametrize("name", ["mini_ddim_avg2", "mini_ddim_final1"])
-@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16", 0.05)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16", 0.05), ("fp16", 0.01)])
 def test_inference_ddim_matches_reference_golden(name, precision, tol):
     """SURVEY.md 8f row 2 (MSAI / MSFI, default.py:278-369): c-decoder + c-head + DDIM update on device,
     step-invariant plan built once."""
@@ -311,6 +317,10 @@ def test_full_size_properties_120k(full_model):
     d = run(full_model, inp, draws)
     err, agree = report("120k bf16 vs fp32 (HIP both)", d, a)
     assert np.isfinite(d).all() and err < 0.08 and agree > 0.98  # measured 3.1e-2 / 99.1 %
+    full_model.precision = "fp16+head"
+    e = run(full_model, inp, draws)
+    err, agree = report("120k fp16+head vs fp32 (HIP both)", e, a)
+    assert np.isfinite(e).all() and err < 0.012 and agree > 0.997
 
 
 def test_full_size_robustness_properties_120k(full_model):
@@ -462,7 +472,7 @@ def test_testtime_pipeline_with_tta_vs_oracle():
     assert err < 1e-4 and agree > 0.999
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16+head"])
 def test_inference_many_equals_scene_by_scene(precision):
     """Scenes in flight on several HIP streams (inference_many) give bit-identical logits to one inference call
     per scene (same kernels, same draw order), including scenes of different sizes sharing a lane."""
@@ -623,6 +633,9 @@ def test_mixed_precision_stages_and_fp32_head():
     e_head, a_head = report("bf16+head vs reference", head, fx["logits"])
     assert e_head < 0.04 and a_head > 0.985
     assert float(np.abs(head - pure).max()) < 0.02  # one bf16 rounding of a 16..64-wide feature row times the head weights
+    half = run(build(cfg, sd, "fp16+head", enable_flash=False), fixture_input(fx), fixture_draws(fx))
+    e_half, a_half = report("fp16+head vs reference", half, fx["logits"])
+    assert e_half < 0.008 and a_half > 0.995 and e_half < e_head
     # a single fp32 stage in the middle of a bf16 forward (dtype hand-over in both directions, skip features included)
     model = build(cfg, sd, "bf16", enable_flash=False)
     model.engine().hi = frozenset(["n_enc2", "n_dec1"])

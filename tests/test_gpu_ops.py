@@ -23,6 +23,28 @@ def ops():
     return _ops
 
 
+_CUR = {"lp": torch.bfloat16}
+
+
+def LP():
+    return _CUR["lp"]
+
+
+@pytest.fixture(autouse=True)
+def _library_variant(request):
+    """Tests parametrised with dtype=float16 or lp="f16" run against the IEEE-half build of the library."""
+    from cdsegnet_amd import _lib
+    params = getattr(getattr(request.node, "callspec", None), "params", {})
+    variant = "f16" if (params.get("dtype") == torch.float16 or params.get("lp") == "f16") else "bf16"
+    _CUR["lp"] = {"bf16": torch.bfloat16, "f16": torch.float16}[variant]
+    with _lib.use(variant):
+        yield
+    _CUR["lp"] = torch.bfloat16
+
+
+LPS = pytest.mark.parametrize("lp", ["bf16", "f16"])
+
+
 def dev(x, dtype=None):
     t = torch.as_tensor(x)
     if dtype is not None:
@@ -151,10 +173,12 @@ def test_pad_plan_vs_reference_golden(ops, name, K):
 
 # ------------------------------------------------------------------ GEMM
 def _bf16_round(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    """Round to the 16-bit type of the library build under test (bfloat16, or IEEE half for the `float16` / lp="f16"
+    parametrisations: the same sources compiled with -DCDSEG_LP_F16, cdsegnet_amd/libcdseg_hip_f16.so)."""
+    return x.to(LP()).to(torch.float32)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(1000, 96, 32), (777, 20, 64), (4096, 128, 128), (300, 512, 512), (65, 2048, 512),
                                    (130, 40, 16), (5000, 64, 2048)])
 def test_gemm_plain(ops, dtype, M, N, K):
@@ -163,7 +187,7 @@ def test_gemm_plain(ops, dtype, M, N, K):
     W = torch.randn(N, K, generator=g) / K ** 0.5
     b = torch.randn(N, generator=g)
     res = torch.randn(M, N, generator=g)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         A, W = _bf16_round(A), _bf16_round(W)
     ref = A.double() @ W.double().t() + b.double()
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
@@ -172,7 +196,7 @@ def test_gemm_plain(ops, dtype, M, N, K):
     report(f"gemm {dtype} {M}x{N}x{K}", max_err=err)
     assert err < (2e-5 * K ** 0.5 + 1e-5)  # fp32 accumulation of exactly-representable products
     # GELU + residual + second (bf16) copy, asymmetric on purpose (catches transposed C layouts)
-    out2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out2 = torch.empty(M, N, dtype=LP(), device="cuda")
     ops.gemm(dev(A, dtype), dev(W, dtype), out, bias=dev(b), act=ops.ACT_GELU, res=dev(res), out2=out2)
     ref2 = F.gelu(ref.float()).double() + res.double()
     err2 = (out.cpu().double() - ref2).abs().max().item()
@@ -180,13 +204,13 @@ def test_gemm_plain(ops, dtype, M, N, K):
     assert (out2.float().cpu() - ref2.float()).abs().max().item() < 0.02 * ref2.abs().max().item() + 1e-2
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_epilogue_bn_gather_add_scatter(ops, dtype):
     g = torch.Generator().manual_seed(3)
     M, N, K, Mc = 1500, 64, 128, 400
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) / K ** 0.5
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         A, W = _bf16_round(A), _bf16_round(W)
     b, sc, sh = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
     child = torch.randn(Mc, N, generator=g)
@@ -204,7 +228,7 @@ def test_gemm_epilogue_bn_gather_add_scatter(ops, dtype):
     assert (out2.float().cpu() - pre).abs().max().item() < tol2 * (1 + pre.abs().max().item())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("name,C", [("room1500", 32), ("batch2", 64), ("lidar5000", 16), ("room1500", 128),
                                     ("room1500", 256), ("lidar8", 512)])  # C >= 256: the 256-row deep-stage tiles
 def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
@@ -216,7 +240,7 @@ def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
     x = torch.randn(n, C, generator=g)
     w = torch.randn(C, 3, 3, 3, C, generator=g) / (27 * C) ** 0.5
     b = torch.randn(C, generator=g)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         x, w = _bf16_round(x), _bf16_round(w)
     ref = OM.subm_conv3d(x, nbr.cpu().numpy().astype(np.int64), w, b)
     out = torch.empty(n, C, dtype=torch.float32, device="cuda")
@@ -226,9 +250,10 @@ def test_sparse_conv_gemm_vs_oracle(ops, dtype, name, C):
     assert err < 2e-4
 
 
+@LPS
 @pytest.mark.parametrize("name,C", [("room1500", 32), ("batch2", 64), ("lidar5000", 32), ("lidar8", 64), ("tiny64", 32),
                                     ("rand16", 64)])
-def test_subm_conv3_weight_stationary_vs_oracle(ops, name, C):
+def test_subm_conv3_weight_stationary_vs_oracle(ops, lp, name, C):
     """csrc/conv.hip (W resident in LDS, gathered rows straight into MFMA fragments, C = 32 / 64 bf16) against the
     oracle's subm_conv3d on bf16-rounded operands, and against the gathered-A GEMM it replaces (same inputs; different
     summation order only).  Row counts that are not a multiple of the 256-row block, rows with no neighbour but
@@ -242,12 +267,12 @@ def test_subm_conv3_weight_stationary_vs_oracle(ops, name, C):
     w = _bf16_round(torch.randn(C, 3, 3, 3, C, generator=g) / (27 * C) ** 0.5)
     b = torch.randn(C, generator=g)
     ref = OM.subm_conv3d(x, nbr.t().cpu().numpy().astype(np.int64), w, b)
-    xd, wd = dev(x, torch.bfloat16), dev(w.reshape(C, -1), torch.bfloat16)
+    xd, wd = dev(x, LP()), dev(w.reshape(C, -1), LP())
     assert ops.subm_conv3_ok(xd)
     img = ops.subm_conv3_pack(wd)
-    out = torch.full((n, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out = torch.full((n, C), float("nan"), dtype=LP(), device="cuda")
     ops.subm_conv3(xd, img, dev(b), nbr, out)
-    old = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
+    old = torch.empty(n, C, dtype=LP(), device="cuda")
     ops.gemm(xd, wd, old, bias=dev(b), nbr=nbr, nbr_kmajor=True, kvol=27)
     err = (out.float().cpu() - ref).abs().max().item()
     err_old = (old.float().cpu() - ref).abs().max().item()
@@ -257,7 +282,8 @@ def test_subm_conv3_weight_stationary_vs_oracle(ops, name, C):
     assert torch.isfinite(out.float()).all()
 
 
-def test_subm_conv3_large_random_map(ops):
+@LPS
+def test_subm_conv3_large_random_map(ops, lp):
     """120k-row scene map, both widths, and bias = None; compares with the gathered-A GEMM on the same bf16 operands
     (fp32 accumulation in both: equal up to summation order, then one bf16 rounding)."""
     from cdsegnet_amd import synth
@@ -271,9 +297,9 @@ def test_subm_conv3_large_random_map(ops):
     n = len(grid)
     for C in (32, 64):
         g = torch.Generator().manual_seed(C)
-        x = torch.randn(n, C, generator=g).cuda().to(torch.bfloat16)
-        w = (torch.randn(C, 27 * C, generator=g) / (27 * C) ** 0.5).cuda().to(torch.bfloat16)
-        out = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
+        x = torch.randn(n, C, generator=g).cuda().to(LP())
+        w = (torch.randn(C, 27 * C, generator=g) / (27 * C) ** 0.5).cuda().to(LP())
+        out = torch.empty(n, C, dtype=LP(), device="cuda")
         ops.subm_conv3(x, ops.subm_conv3_pack(w), None, nbr, out)
         old = torch.empty(n, C, dtype=torch.float32, device="cuda")
         ops.gemm(x, w, old, nbr=nbr, nbr_kmajor=True, kvol=27)
@@ -285,8 +311,9 @@ def test_subm_conv3_large_random_map(ops):
         assert torch.equal(out, out2)  # deterministic
 
 
+@LPS
 @pytest.mark.parametrize("C", [32, 64])
-def test_subm_conv3_strided_rows(ops, C):
+def test_subm_conv3_strided_rows(ops, lp, C):
     """Input and output as column slices of wider buffers (row stride 2C: a power-of-two byte stride, as the ABI asks);
     the untouched halves keep their contents."""
     fx = load_fixture("serialization_lidar5000.npz")
@@ -294,19 +321,19 @@ def test_subm_conv3_strided_rows(ops, C):
     n = len(p)
     nbr = ops.nbr_table(zs, g0, b0, depth, 3, True)
     g = torch.Generator().manual_seed(7 * C)
-    xw = torch.randn(n, 2 * C, generator=g).cuda().to(torch.bfloat16)
-    w = (torch.randn(C, 27 * C, generator=g) / (27 * C) ** 0.5).cuda().to(torch.bfloat16)
+    xw = torch.randn(n, 2 * C, generator=g).cuda().to(LP())
+    w = (torch.randn(C, 27 * C, generator=g) / (27 * C) ** 0.5).cuda().to(LP())
     b = torch.randn(C, generator=g).cuda()
     img = ops.subm_conv3_pack(w)
-    dense = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
+    dense = torch.empty(n, C, dtype=LP(), device="cuda")
     ops.subm_conv3(xw[:, C:].contiguous(), img, b, nbr, dense)
-    yw = torch.full((n, 2 * C), 3.0, dtype=torch.bfloat16, device="cuda")
+    yw = torch.full((n, 2 * C), 3.0, dtype=LP(), device="cuda")
     ops.subm_conv3(xw[:, C:], img, b, nbr, yw[:, :C])
     assert torch.equal(yw[:, :C], dense)
-    assert torch.equal(yw[:, C:], torch.full((n, C), 3.0, dtype=torch.bfloat16, device="cuda"))
+    assert torch.equal(yw[:, C:], torch.full((n, C), 3.0, dtype=LP(), device="cuda"))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(1000, 32, 32), (4097, 64, 64), (130, 128, 128), (70, 16, 16), (515, 48, 48),
                                    # rows over several column tiles: finished by the last block of the row tile
                                    (3364, 256, 256), (778, 512, 512), (300, 384, 384), (20000, 256, 256),
@@ -318,7 +345,7 @@ def test_gemm_fused_layernorm_epilogue(ops, dtype, M, N, K):
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) / K ** 0.5
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         A, W = _bf16_round(A), _bf16_round(W)
     b, res, cb = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(N, generator=g)
     g1, b1 = torch.randn(N, generator=g), torch.randn(N, generator=g)
@@ -346,7 +373,7 @@ def test_gemm_fused_layernorm_epilogue(ops, dtype, M, N, K):
     assert torch.equal(x3, x2) and torch.equal(h3, h)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(448, 512, 2048), (832, 1536, 512), (100, 256, 4096), (3392, 256, 256)])
 def test_gemm_split_k(ops, dtype, M, N, K):
     """Few output tiles + long K -> the split-K path (partials in the workspace, finished by the last block)."""
@@ -354,7 +381,7 @@ def test_gemm_split_k(ops, dtype, M, N, K):
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) / K ** 0.5
     b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         A, W = _bf16_round(A), _bf16_round(W)
     ref = F.gelu((A.double() @ W.double().t() + b.double()).float()).double() + res.double()
     out = dev(res)
@@ -368,7 +395,7 @@ def test_gemm_split_k(ops, dtype, M, N, K):
     assert torch.equal(again, out), "split-K must be deterministic"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_sparse_conv_split_k_deep_stage(ops, dtype):
     """Stage-4-like conv: a few hundred points, C = 512 (K = 27 * 512)."""
     fx = load_fixture("serialization_lidar5000.npz")
@@ -382,7 +409,7 @@ def test_sparse_conv_split_k_deep_stage(ops, dtype):
     x = torch.randn(m, C, generator=g)
     w = torch.randn(C, 27, C, generator=g) / (27 * C) ** 0.5
     b = torch.randn(C, generator=g)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         x, w = _bf16_round(x), _bf16_round(w)
     ref = OM.subm_conv3d(x, nbr.cpu().numpy().astype(np.int64), w.reshape(C, 3, 3, 3, C), b)
     out = torch.empty(m, C, dtype=torch.float32, device="cuda")
@@ -392,7 +419,7 @@ def test_sparse_conv_split_k_deep_stage(ops, dtype):
     assert err < 5e-4
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("name,cin,cout", [("room1500", 6, 32), ("lidar5000", 4, 16), ("batch2", 6, 64)])
 def test_stem_as_gathered_gemm_vs_oracle(ops, dtype, name, cin, cout):
     """The engine's stem: input rows gathered/padded to 8 channels, k=5 conv (125 offsets) on the MFMA GEMM,
@@ -405,7 +432,7 @@ def test_stem_as_gathered_gemm_vs_oracle(ops, dtype, name, cin, cout):
     x = torch.randn(n, cin, generator=g)  # caller order
     w = torch.randn(cout, 5, 5, 5, cin, generator=g) / (125 * cin) ** 0.5
     sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         x, w = _bf16_round(x), _bf16_round(w)
     xp = x[torch.from_numpy(p)]
     ref = F.gelu(OM.subm_conv3d(xp, nbr.cpu().numpy().astype(np.int64), w, None) * sc + sh)
@@ -422,8 +449,9 @@ def test_stem_as_gathered_gemm_vs_oracle(ops, dtype, name, cin, cout):
     assert err < 1e-4
 
 
+@LPS
 @pytest.mark.parametrize("name,cin", [("room1500", 6), ("lidar5000", 4), ("batch2", 6), ("lidar8", 4), ("rand16", 6), ("tiny64", 6)])
-def test_stem5_map_free_vs_oracle(ops, name, cin):
+def test_stem5_map_free_vs_oracle(ops, lp, name, cin):
     """csrc/stem.hip: the k = 5 stem WITHOUT a 125-offset kernel map (neighbours enumerated through the parent level's
     3x3x3 map + per-parent octant masks), bf16 operands / fp32 accumulation, folded BN + GELU, against (a) the oracle's
     subm_conv3d on the explicit 5x5x5 map with the same bf16-rounded operands and (b) the gathered-A GEMM path it
@@ -444,12 +472,12 @@ def test_stem5_map_free_vs_oracle(ops, name, cin):
     sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
     xp = x[torch.from_numpy(p)]
     ref = F.gelu(OM.subm_conv3d(xp, nbr5.cpu().numpy().astype(np.int64), w, None) * sc + sh)
-    a = ops.gather_pad_cast(dev(x), perm0, 8, torch.bfloat16)
+    a = ops.gather_pad_cast(dev(x), perm0, 8, LP())
     wp = torch.zeros(32, 125, 8)
     wp[:, :, :cin] = w.reshape(32, 125, cin)
-    wd = dev(wp.reshape(32, -1), torch.bfloat16)
+    wd = dev(wp.reshape(32, -1), LP())
     out = torch.full((n, 32), float("nan"), dtype=torch.float32, device="cuda")
-    out2 = torch.empty(n, 32, dtype=torch.bfloat16, device="cuda")
+    out2 = torch.empty(n, 32, dtype=LP(), device="cuda")
     ops.stem5(a, ops.stem5_pack(wd), dev(sc), dev(sh), g0, cluster, pn3, cinfo, depth, out, out2)
     old = torch.empty(n, 32, dtype=torch.float32, device="cuda")
     ops.gemm(a, wd, old, scale=dev(sc), shift=dev(sh), act=ops.ACT_GELU, nbr=nbr5, kvol=125)
@@ -460,8 +488,9 @@ def test_stem5_map_free_vs_oracle(ops, name, cin):
 
 
 # ------------------------------------------------------------------ LayerNorm / pooling reduce / small ops
+@LPS
 @pytest.mark.parametrize("C", [16, 32, 48, 64, 128, 256, 512, 2048])
-def test_layernorm(ops, C):
+def test_layernorm(ops, lp, C):
     g = torch.Generator().manual_seed(C)
     M = 1237
     x = torch.randn(M, C, generator=g) * 3 + 1
@@ -474,13 +503,13 @@ def test_layernorm(ops, C):
     xr = dev(res)
     ops.layernorm(dev(x), dev(gm), dev(bt), xr, res=xr, colbias=dev(cb))  # in place on the residual
     assert (xr.cpu() - (ref + res + cb)).abs().max().item() < 2e-5
-    ob = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
-    ops.layernorm(dev(x, torch.bfloat16), dev(gm), dev(bt), ob)
+    ob = torch.empty(M, C, dtype=LP(), device="cuda")
+    ops.layernorm(dev(x, LP()), dev(gm), dev(bt), ob)
     refb = F.layer_norm(_bf16_round(x), (C,), gm, bt, 1e-5)
     assert (ob.float().cpu() - refb).abs().max().item() < 0.02 * (1 + refb.abs().max().item())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_segment_max_and_mean(ops, dtype):
     g = torch.Generator().manual_seed(1)
     m, C = 700, 64
@@ -488,13 +517,13 @@ def test_segment_max_and_mean(ops, dtype):
     seg = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)])
     n = int(seg[-1])
     y = torch.randn(n, C, generator=g)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         y = _bf16_round(y)
     sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g)  # negative scales too: max must come first
     cluster = np.repeat(np.arange(m), counts.numpy())
     ref = F.gelu(OM.segment_max(y, cluster, m) * sc + sh)
     out = torch.empty(m, C, dtype=torch.float32, device="cuda")
-    out2 = torch.empty(m, C, dtype=torch.bfloat16, device="cuda")
+    out2 = torch.empty(m, C, dtype=LP(), device="cuda")
     ops.segment_max(dev(y, dtype), dev(seg.int()), m, dev(sc), dev(sh), ops.ACT_GELU, out, out2)
     assert (out.cpu() - ref).abs().max().item() < 1e-5
     assert (out2.float().cpu() - ref).abs().max().item() < 0.01 * (1 + ref.abs().max().item())
@@ -519,7 +548,8 @@ def test_timestep_embedding_chain(ops):
     assert (v.cpu() - ref).abs().max().item() < 1e-5
 
 
-def test_randn_cast_axpy_gather(ops):
+@LPS
+def test_randn_cast_axpy_gather(ops, lp):
     z = ops.randn((1 << 20,), 1234, 0, torch.device("cuda")).cpu()
     assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
     assert abs((z ** 4).mean().item() - 3) < 0.05
@@ -527,7 +557,7 @@ def test_randn_cast_axpy_gather(ops):
     assert (z == z2).float().mean().item() < 1e-3
     assert torch.equal(ops.randn((1 << 20,), 1234, 0, torch.device("cuda")).cpu(), z)
     x = torch.randn(1000, 7)
-    assert torch.equal(ops.cast(dev(x), torch.bfloat16).cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast(dev(x), LP()).cpu(), x.to(LP()))
     assert torch.allclose(ops.axpy(dev(x), dev(x), 0.5).cpu(), 1.5 * x)
     idx = torch.randint(0, 1000, (333,)).int()
     x8 = torch.randn(1000, 8)
@@ -544,7 +574,7 @@ def _attention_case(ops, dtype, lens_pts, H, K, seed, cross=False):
     n = int(offset[-1])
     qkv = torch.randn(n, 3 * C, generator=g)
     qkv[:, :C] *= 2.0  # sharper softmax
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         qkv = _bf16_round(qkv)
     # a random "serialized order" that keeps batch elements contiguous
     order = np.concatenate([s + torch.randperm(int(c), generator=g).numpy() for s, c in
@@ -585,18 +615,20 @@ def test_attention_fp32_vs_oracle(ops, lens, H, K):
     assert err < 2e-5 * (1 + mag)  # exact-fp32 MFMA; differences = summation order + exp2 vs exp
 
 
+@LPS
 @pytest.mark.parametrize("lens,H,K", [([2500], 2, 1024), ([1024], 4, 1024), ([991], 32, 1024), ([26], 4, 1024),
                                       ([1500, 1100], 2, 1024), ([700, 500, 3000], 1, 1024), ([10], 1, 4),
                                       ([100, 37], 2, 16), ([1025], 8, 1024), ([33], 2, 1024)])
-def test_attention_bf16_vs_oracle(ops, lens, H, K):
-    err, mag = _attention_case(ops, torch.bfloat16, lens, H, K, seed=sum(lens) + H)
+def test_attention_bf16_vs_oracle(ops, lp, lens, H, K):
+    err, mag = _attention_case(ops, LP(), lens, H, K, seed=sum(lens) + H)
     report(f"attn bf16 lens={lens} H={H} K={K}", max_err=err, ref_max=mag)
     # inputs are bf16-exact; P is rounded to bf16 (2^-9 relative) and the output to bf16
     assert err < 0.02 * (1 + mag)
 
 
-def test_cross_attention_vs_oracle(ops):
-    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 0.02)):
+@LPS
+def test_cross_attention_vs_oracle(ops, lp):
+    for dtype, tol in ((torch.float32, 2e-5), (LP(), 0.02)):
         err, mag = _attention_case(ops, dtype, [991], 32, 1024, seed=7, cross=True)
         assert err < tol * (1 + mag)
         err, mag = _attention_case(ops, dtype, [1300, 1200], 4, 1024, seed=8, cross=True)
@@ -805,7 +837,8 @@ def test_batched_plan_kernels_equal_single_calls(ops, name):
         assert torch.equal(g, g1) and torch.equal(w, w1)
 
 
-def test_attention_bf16_loose_score_bound_falls_back_to_exact_max(ops):
+@LPS
+def test_attention_bf16_loose_score_bound_falls_back_to_exact_max(ops, lp):
     """The bf16 kernel takes m_i = |q_i| max_j |k_j| (Cauchy-Schwarz) instead of the row max; rows where that bound is
     more than 2^60 above the scores are redone with the exact max.  Build exactly that: huge, nearly orthogonal q / k."""
     g = torch.Generator().manual_seed(3)
@@ -830,8 +863,8 @@ def test_attention_bf16_loose_score_bound_falls_back_to_exact_max(ops):
     offs_pad = dev(np.array([0, 2048], dtype=np.int32))
     gq, wq = ops.pad_plan(dev(order.astype(np.int32)), offs, offs_pad, 1024, 2048)
     ps = dev(np.array([0, 1024, 2048], dtype=np.int32))
-    out = torch.empty(n, C, dtype=torch.bfloat16, device="cuda")
-    ops.attention(dev(q, torch.bfloat16), dev(k, torch.bfloat16), dev(v, torch.bfloat16), gq, gq, wq, ps, H, 1024, 0.25, out)
+    out = torch.empty(n, C, dtype=LP(), device="cuda")
+    ops.attention(dev(q, LP()), dev(k, LP()), dev(v, LP()), gq, gq, wq, ps, H, 1024, 0.25, out)
     got = out.float().cpu()[t_order]
     want = torch.cat([ref[:1024], ref[1024 + (2048 - n):]])
     assert torch.isfinite(got).all()
@@ -875,9 +908,10 @@ def test_kernel_map_from_parent_equals_search(ops, name):
             assert torch.equal(got, want), (ksize, kmajor, "info")
 
 
+@LPS
 @pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 32), (70, 64), (120000, 32), (4097, 128), (14293, 128),
                                  (65536 + 77, 128)])  # >= 64 k rows at C = 128: the 128-row workgroups
-def test_mlp_fused_vs_two_gemms_and_fp64(ops, M, C):
+def test_mlp_fused_vs_two_gemms_and_fp64(ops, lp, M, C):
     """cdseg_mlp_fused (hidden activation kept in LDS) against the two-GEMM form and an fp64 reference that rounds
     the hidden activation to bf16 at the same place (ptv3.py:299-322, :423-427)."""
     g = torch.Generator().manual_seed(M + C)
@@ -888,7 +922,7 @@ def test_mlp_fused_vs_two_gemms_and_fp64(ops, M, C):
     x0 = torch.randn(M, C, generator=g)
     u = _bf16_round(F.gelu((h.double() @ w1.double().t() + b1.double()).float()))
     ref = x0.double() + u.double() @ w2.double().t() + b2.double()
-    bf = torch.bfloat16
+    bf = LP()
     x = dev(x0)
     xc = torch.empty(M, C, dtype=bf, device="cuda")
     assert ops.mlp_fused_ok(dev(h, bf), 4 * C)
@@ -908,12 +942,13 @@ def test_mlp_fused_vs_two_gemms_and_fp64(ops, M, C):
     assert d.max().item() < 1e-2 and d.mean().item() < 2e-6
 
 
+@LPS
 @pytest.mark.parametrize("M,C", [(1000, 32), (4097, 64), (64, 64), (120000, 32)])
-def test_attn_tail_fused_equals_proj_ln_mlp_sequence(ops, M, C):
+def test_attn_tail_fused_equals_proj_ln_mlp_sequence(ops, lp, M, C):
     """cdseg_attn_tail_fused == proj GEMM (+ residual, LN2 in its epilogue) followed by the fused MLP, bit for bit:
     same MFMA products, same row-wise LayerNorm arithmetic (ptv3.py:416-427)."""
     g = torch.Generator().manual_seed(M * 3 + C)
-    bf = torch.bfloat16
+    bf = LP()
     o = dev(_bf16_round(torch.randn(M, C, generator=g)), bf)
     wp = dev(_bf16_round(torch.randn(C, C, generator=g) / C ** 0.5), bf)
     w1 = dev(_bf16_round(torch.randn(4 * C, C, generator=g) / C ** 0.5), bf)
@@ -939,13 +974,14 @@ def test_attn_tail_fused_equals_proj_ln_mlp_sequence(ops, M, C):
     assert (xa.cpu() - ref).abs().max().item() < 3e-2
 
 
+@LPS
 @pytest.mark.parametrize("M,C,tb", [(1000, 32, True), (4097, 64, False), (64, 64, True), (120000, 32, False),
                                     (70001, 64, True)])  # >= 64 k rows: the 128-row workgroups, ragged last tile
-def test_cpe_head_fused_equals_linear_ln_qkv_sequence(ops, M, C, tb):
+def test_cpe_head_fused_equals_linear_ln_qkv_sequence(ops, lp, M, C, tb):
     """cdseg_cpe_head_fused == cpe linear GEMM (LN_cpe + residual + t bias + LN1 in its epilogue) followed by the qkv
     GEMM, bit for bit (ptv3.py:401-414)."""
     g = torch.Generator().manual_seed(M * 5 + C)
-    bf = torch.bfloat16
+    bf = LP()
     y = dev(_bf16_round(torch.randn(M, C, generator=g)), bf)
     wl = dev(_bf16_round(torch.randn(C, C, generator=g) / C ** 0.5), bf)
     wq = dev(_bf16_round(torch.randn(3 * C, C, generator=g) / C ** 0.5), bf)
@@ -966,15 +1002,16 @@ def test_cpe_head_fused_equals_linear_ln_qkv_sequence(ops, M, C, tb):
     assert torch.equal(xa, xb) and torch.equal(qa, qb)
 
 
+@LPS
 @pytest.mark.parametrize("M,C,tb", [(1000, 32, True), (4097, 64, False), (64, 64, True), (31, 32, False), (120000, 32, False),
                                     (120001, 64, True)])
-def test_block_rr_head_and_tail_vs_fused_kernels(ops, M, C, tb):
+def test_block_rr_head_and_tail_vs_fused_kernels(ops, lp, M, C, tb):
     """csrc/blockrr.hip (weights resident in LDS, activations in registers, transposed MFMA products, permuted channel
     ownership) against the 64-row-tile fused kernels they replace and against plain torch with the same bf16 rounding
     points (ptv3.py:401-427).  Same products and rounding points; the fp32 summation order inside a dot product differs,
     so the comparison is within a few fp32 ulps of the row norm, plus isolated bf16 boundary flips."""
     g = torch.Generator().manual_seed(M * 7 + C)
-    bf = torch.bfloat16
+    bf = LP()
     rnd = lambda *sh, s=1.0: _bf16_round(torch.randn(*sh, generator=g) * s)  # noqa: E731
     y, o = dev(rnd(M, C), bf), dev(rnd(M, C), bf)
     wl, wq, wp = dev(rnd(C, C, s=C ** -0.5), bf), dev(rnd(3 * C, C, s=C ** -0.5), bf), dev(rnd(C, C, s=C ** -0.5), bf)

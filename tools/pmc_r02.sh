@@ -1,4 +1,6 @@
-# rocprofv3 --pmc passes for round 2 (one counter set per run; never combined with trace domains).
+# rocprofv3 --pmc passes (one counter set per run; never combined with trace domains).  The last lines of each block are the
+# tool's own timing output UNDER the profiler: the duration the counters of that pass belong to (PMC passes run the kernel
+# 1.05-4x slower than unprofiled; the unprofiled duration is in the bench line / the A/B files).
 # usage: bash tools/pmc_r02.sh <tag> <kernel substring> <cmd...>   -> gpurun_out/pmc_<tag>.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -27,7 +29,7 @@ for k, d in acc.items():
     for c, v in d.items():
         print(f"{name} | {k} | {c} | per launch {v / cnt[(k, c)]:.0f} | launches {cnt[(k, c)]}")
 PY
-  grep -h "conv level\|attention n=" /tmp/pmc_$name.log | tail -2 >> $out
+  grep -h "conv level\|attention\[" /tmp/pmc_$name.log | tail -2 >> $out
 }
 CMD=("$@")
 run ${tag}A "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES"
