@@ -97,6 +97,12 @@ constexpr int SMEM_F32 = KS_BYTES_F32 + 16 * VT_STRIDE_F32;
 //    (= head dims) in lanes 0..31 of each half wave, so lane groups 0 / 2 (head dims 0..15 of k-slot halves 0 / 1)
 //    read V and lane groups 1 / 3 (MFMA rows 16..31) read a constant "ones page": row 16 comes out as all ones, so
 //    row 16 of O^T is the softmax denominator, accumulated from the SAME bf16-rounded probabilities as the numerator.
+#ifndef ATTN_FIRST_STATIC
+#define ATTN_FIRST_STATIC 1
+#endif
+#ifndef ATTN_PRIO_OUTSIDE
+#define ATTN_PRIO_OUTSIDE 1
+#endif
 constexpr int ATTN_THREADS = 512;  // 8 waves: 2 per SIMD per block, 2 blocks per CU (LDS 66 KB each)
 constexpr int ATTN_WAVES = ATTN_THREADS / 64;
 constexpr int KV_STAGE = 1024 * 32;  // K (or V) of one patch-head
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
   if (!decode_block(p, patch, head, qslice)) return;
 #ifdef CDSEG_ATTN_TIMING
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long t_loop = 0;
+  unsigned long long t_loop = 0, t_first = 0, t_epi = 0, n_tiles = 0;
 #endif
   ATTN_STAMP(t0);
   // the staging is a few hundred instructions of a young block next to the key loops of an older one: at the default
@@ -207,6 +213,10 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
       unsigned i = 0;
       if (lane == 0) i = atomicAdd(s_next, 1u);
       i = __builtin_amdgcn_readfirstlane(i);
+      if (ATTN_FIRST_STATIC && p.qsplit == 1) {  // tiles 4w are pre-assigned (below): hand out the others, in order
+        const int t = (int)(i + i / 3u + 1u);
+        return t < nqt ? t : -1;
+      }
       const int base = (qslice + (int)(i >> 3) * p.qsplit) * ATTN_WAVES;
       if (base >= nqt) return -1;
       const int t = base + (int)(i & 7);
@@ -218,6 +228,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     return *reinterpret_cast<const uint4*>((const bf16_t*)p.q + (long)g * p.ldq + head * 16 + h * 8);
   };
 
+  int qt_first = -1;
+  uint4 q_first = make_uint4(0, 0, 0, 0);
   // ---- stage K and V by LDS-DMA.  Wave w moves the 32-key pieces w, w + 8, ..: lane -> (key = lane / 2, 16-B half).
   {
     const int kip = lane >> 1, hs = lane & 1;
@@ -255,6 +267,15 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
         dma16(vsrc[i], lds_base + KV_STAGE + pc * 1024);
       }
     }
+    // the wave's FIRST query tile is fixed (tile 4 w: its rows are the first 32 of the indices just loaded) and its
+    // query rows are fetched here, next to the K / V DMAs: claimed and fetched after the barrier, they were an exposed
+    // index -> row load chain issued at key-loop priority behind the older waves (in-kernel stamps: 14.5 % of a wave's
+    // life between the barrier and its first key loop)
+    if (ATTN_FIRST_STATIC && p.qsplit == 1 && 4 * wave < nqt) {
+      qt_first = 4 * wave;
+      const int g = __shfl(gq[0], lane & 31, 64);
+      q_first = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + (long)g * p.ldq + head * 16 + h * 8);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) s_qidx[wave * 128 + i * 64 + lane] = gq[i];
     for (int w = tid; w < ONES_BYTES / 8; w += ATTN_THREADS)
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     if (lane == 0) s_kn2[wave] = kn2;
     __syncthreads();  // everybody's DMA has landed, the ones page and the norms are written
   }
-  __builtin_amdgcn_s_setprio(0);
+  if (!ATTN_PRIO_OUTSIDE) __builtin_amdgcn_s_setprio(0);
   ATTN_STAMP(t1);
   float kmax2;
   {
@@ -308,8 +329,12 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
   const bool tail = (nkt << 5) != L;
   const int nfull = tail ? nkt - 1 : nkt;  // key tiles that need no masking
 
-  int qt = claim();
-  uint4 q_cur = load_qrow(qt);
+  int qt = qt_first;
+  uint4 q_cur = q_first;
+  if (qt < 0) {
+    qt = claim();
+    q_cur = load_qrow(qt);
+  }
   while (qt >= 0) {
     // Q' = Q * (softmax scale * log2 e), rounded to bf16 once: scores come out of the MFMA in exp2 units (consumed
     // BEFORE the next loads are issued: the compiler's wait for q_cur then has nothing younger in the queue)
@@ -365,11 +390,18 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     // any magnitude (fp32 / bf16 share the exponent range, the denominator comes from the same rounded values).
     float qn2 = sq8_bf16(__builtin_bit_cast(uint4, qf));
     qn2 += __shfl_xor(qn2, 32, 64);
+    // everything outside the key loops (prologue, normalise + store, the next tile's set-up) runs at raised priority:
+    // it is a few hundred instructions that otherwise queue behind the older waves' key loops on the same SIMD
+    if (ATTN_PRIO_OUTSIDE) __builtin_amdgcn_s_setprio(0);
     ATTN_STAMP(tl0);
     f32x16_t o = exp_pv_pass(sqrtf(qn2 * kmax2) * 1.0005f);
+    if (ATTN_PRIO_OUTSIDE) __builtin_amdgcn_s_setprio(2);
 #ifdef CDSEG_ATTN_TIMING
     asm volatile("" :: "v"(o[0]), "v"(o[8]));
-    t_loop += __builtin_readcyclecounter() - tl0;
+    const unsigned long long tl1 = __builtin_readcyclecounter();
+    t_loop += tl1 - tl0;
+    if (n_tiles == 0) t_first = tl0 - t1;
+    ++n_tiles;
 #endif
     // rows whose bound is looser than 2^60 (the largest term could sink towards the denormal range) are redone
     // with the exact row max; wave-uniform branch, never taken for ordinary logits
@@ -405,12 +437,17 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     }
     qt = qt_nxt;
     q_cur = q_nxt;
+#ifdef CDSEG_ATTN_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (timing builds: the stores and the next rows inside the stamp)
+    t_epi += __builtin_readcyclecounter() - tl1;
+#endif
   }
 #ifdef CDSEG_ATTN_TIMING
   if (lane == 0 && blockIdx.x < 4096) {
     unsigned long long* d = g_attn_t + ((size_t)blockIdx.x * 8 + wave) * 8;
     d[0] = rt0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = t1 - t0; d[3] = t_loop;
     d[4] = __builtin_readcyclecounter() - t0;
+    d[5] = t_first; d[6] = t_epi; d[7] = n_tiles;
   }
 #endif
 }

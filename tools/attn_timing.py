@@ -63,6 +63,11 @@ print(f"clock held (wave cycles / wave wall time): {life_cyc.sum() / (life_us.su
 print(f"wave life: mean {life_cyc.mean():.0f} cycles = {life_us.mean():.1f} us (p5 {np.percentile(life_us, 5):.1f}, p95 {np.percentile(life_us, 95):.1f})")
 print(f"  staging (block form: entry -> barrier; persistent form: stage a patch-head two ahead + its DMAs + norms, publisher wave): mean {t[:, :, 2].mean():.0f} cycles = {100 * t[:, :, 2].sum() / life_cyc.sum():.1f} % of wave life")
 print(f"  key loops:                  mean {t[:, :, 3].mean():.0f} cycles = {100 * t[:, :, 3].sum() / life_cyc.sum():.1f} % of wave life")
+if form == 0:
+    nt = np.maximum(t[:, :, 7], 1)
+    print(f"  barrier -> first key loop (first tile claim + query rows): mean {t[:, :, 5].mean():.0f} cycles = {100 * t[:, :, 5].sum() / life_cyc.sum():.1f} % of wave life")
+    print(f"  after a key loop -> next (loose check, normalise, store, next rows; stamped WITH a vmcnt(0)): mean {(t[:, :, 6] / nt).mean():.0f} cycles per tile, "
+          f"{100 * t[:, :, 6].sum() / life_cyc.sum():.1f} % of wave life; query tiles per wave: mean {t[:, :, 7].mean():.2f}, min {t[:, :, 7].min():.0f}, max {t[:, :, 7].max():.0f}")
 if form == 1:
     print(f"  spinning for an unpublished stage: {100 * t[:, :, 6].sum() / life_cyc.sum():.1f} % of wave life; "
           f"tasks (32-query tiles) per wave: mean {t[:, :, 5].mean():.1f}, min {t[:, :, 5].min():.0f}, max {t[:, :, 5].max():.0f}")
