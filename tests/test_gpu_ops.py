@@ -204,6 +204,25 @@ def test_gemm_plain(ops, dtype, M, N, K):
     assert (out2.float().cpu() - ref2.float()).abs().max().item() < 0.02 * ref2.abs().max().item() + 1e-2
 
 
+@LPS
+def test_gemm_16bit_outputs_saturate_in_the_half_build(ops, lp):
+    """IEEE half ends at 65504: the half build clamps on conversion (an outlier activation of a trained checkpoint must
+    not turn the rest of the forward into inf / NaN); the bfloat16 build has fp32's range and stores the value."""
+    M, N, K = 256, 128, 64
+    A = torch.full((M, K), 300.0)
+    W = torch.full((N, K), 300.0)
+    W[::2] *= -1
+    out = torch.empty(M, N, dtype=LP(), device="cuda")
+    ops.gemm(dev(A, LP()), dev(W, LP()), out)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    want = 300.0 * 300.0 * K
+    if lp == "f16":
+        assert torch.equal(got[:, 1::2], torch.full((M, N // 2), 65504.0)) and torch.equal(got[:, ::2], torch.full((M, N // 2), -65504.0))
+    else:
+        assert (got[:, 1::2] - want).abs().max() <= want * 2 ** -8 and (got[:, ::2] + want).abs().max() <= want * 2 ** -8
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_epilogue_bn_gather_add_scatter(ops, dtype):
     g = torch.Generator().manual_seed(3)
