@@ -13,7 +13,9 @@
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *  - every function is asynchronous on `stream`, returns CDSEG_OK (0) or a negative
  *    CDSEG_ERR_* code, and never allocates (callers own all buffers and workspaces);
- *  - dtypes: CDSEG_F32 = float32, CDSEG_BF16 = bfloat16 (raw uint16 bits);
+ *  - dtypes: CDSEG_F32 = float32, CDSEG_BF16 = the build's 16-bit type as raw uint16 bits: bfloat16 in libcdseg_hip.so,
+ *    IEEE half in libcdseg_hip_f16.so (the same sources compiled with -DCDSEG_LP_F16; float -> half conversions saturate
+ *    at +-65504).  Same entry points, same signatures: a caller picks the library that matches its tensors' dtype;
  *  - index arrays are int32 unless stated; codes are int64 (non-negative).
  *  - attention head dimension is 16 (every stage of every shipped config: C/H = 16).
  */
