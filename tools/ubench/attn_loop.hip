@@ -26,7 +26,8 @@ constexpr int SMEM = 2 * KV + 2048 + 64;
 //          16 = C operand of QK is the inline constant 0            32 = three key tiles in flight
 //          64 = one key tile in flight
 template <int VAR>
-__device__ __forceinline__ void pv(const f32x16_t& s, unsigned va, f32x16_t& o, const bf16x8_t& cv, f32x16_t& decoy) {
+__device__ __forceinline__ void pv(const f32x16_t& s, unsigned va, f32x16_t& o, const bf16x8_t& cv, f32x16_t& decoy,
+                                   f32x16_t* o_mf1 = nullptr /* 512: the second PV MFMA of the tile accumulates here */) {
   float pr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -54,7 +55,8 @@ __device__ __forceinline__ void pv(const f32x16_t& s, unsigned va, f32x16_t& o, 
       asm volatile("" : "+v"(pf.v));
     }
     if (VAR & 8) __builtin_amdgcn_s_setprio(1);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o, 0, 0, 0);
+    if ((VAR & 512) && mf == 1) *o_mf1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, *o_mf1, 0, 0, 0);
+    else o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o, 0, 0, 0);
     if (VAR & 8) __builtin_amdgcn_s_setprio(0);
   }
 }
@@ -70,19 +72,24 @@ __device__ __forceinline__ f32x16_t qk(const char* kp, bf16x8_t qf, const f32x16
   return r;
 }
 
-template <int VAR>
-__global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink, int qtiles, float seed) {
+// THREADS x BPC: block size and blocks per CU (every block has its own K / V image in LDS); DYN: the block's waves claim
+// their query tiles from an LDS counter (qtiles = tiles of the whole BLOCK) like the kernel does, instead of qtiles each
+template <int VAR, int THREADS = 1024, int BPC = 1, bool DYN = false>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS / 256 * BPC, THREADS / 256 * BPC)))
+void k(unsigned long long* out, float* sink, int qtiles, float seed) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // K, V: small random bf16 values; ones page
-  for (int i = tid; i < 2 * KV / 4; i += 1024) {
+  __shared__ unsigned s_next;
+  if (tid == 0) s_next = 0u;
+  for (int i = tid; i < 2 * KV / 4; i += THREADS) {
     unsigned h = (i * 2654435761u) ^ (blockIdx.x * 40503u);
     h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
     const unsigned a = 0x3c00u + (h & 0x1ffu) | ((h >> 9) & 1u) << 15, b = 0x3c00u + ((h >> 10) & 0x1ffu) | ((h >> 19) & 1u) << 15;
     reinterpret_cast<unsigned*>(smem)[i] = a | (b << 16);
   }
-  for (int w = tid; w < 2048 / 8; w += 1024) *reinterpret_cast<uint2*>(smem + 2 * KV + w * 8) = make_uint2(0x3F80u, 0u);
+  for (int w = tid; w < 2048 / 8; w += THREADS) *reinterpret_cast<uint2*>(smem + 2 * KV + w * 8) = make_uint2(0x3F80u, 0u);
   __syncthreads();
   const int ql = lane & 31, h = lane >> 5;
   const char* k_lane = smem + ql * 32 + ((h ^ ((ql >> 3) & 1)) << 4);
@@ -99,8 +106,15 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink, 
   for (int i = 0; i < 16; ++i) decoy[i] = -1.f - 0.01f * (float)((lane + i) & 15);
   float total = 0.f;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int qt = 0; qt < qtiles; ++qt) {
-    f32x16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int qt = 0;; ++qt) {
+    if (DYN) {
+      unsigned i = 0;
+      if (lane == 0) i = atomicAdd(&s_next, 1u);
+      if ((int)__builtin_amdgcn_readfirstlane(i) >= qtiles) break;
+    } else if (qt >= qtiles) {
+      break;
+    }
+    f32x16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;
     const char* kp = k_lane;
     unsigned va = va0;
     if (VAR & 32) {
@@ -126,14 +140,15 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink, 
     } else if (VAR & 64) {
       for (int kt = 0; kt < 32; ++kt) { const f32x16_t s = qk<VAR>(kp, qf, negm, cv); pv<VAR>(s, va, acc, cv, decoy); kp += 1024; va += vstep; }
     } else {
+      // 256: the two tiles in flight accumulate into different registers; 512: the two PV MFMAs of a tile do
       for (int kt = 0; kt < 32; kt += 2) {
         const f32x16_t sa = qk<VAR>(kp, qf, negm, cv), sb = qk<VAR>(kp + 1024, qf, negm, cv);
-        pv<VAR>(sa, va, acc, cv, decoy);
-        pv<VAR>(sb, va + 1024, acc, cv, decoy);
+        pv<VAR>(sa, va, acc, cv, decoy, &acc2);
+        pv<VAR>(sb, va + 1024, (VAR & 256) ? acc2 : acc, cv, decoy, &acc2);
         kp += 2048; va += 2 * vstep;
       }
     }
-    total += acc[0] + acc[8];
+    total += acc[0] + acc[8] + acc2[0] + acc2[8];
     qf[0] = (short)(qf[0] ^ (qt & 1));
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
@@ -141,30 +156,48 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink, 
   if (lane == 0) out[blockIdx.x * 16 + wave] = t1 - t0;
 }
 
-template <int VAR>
+template <int VAR, int THREADS = 1024, int BPC = 1, bool DYN = false>
 void run(const char* name) {
+  constexpr int WPS = THREADS / 256 * BPC;  // waves per SIMD
   unsigned long long* d; float* sink;
-  hipMalloc(&d, 256 * 16 * sizeof(unsigned long long)); hipMalloc(&sink, 64);
-  hipFuncSetAttribute((const void*)k<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-  const int qtiles = 64;  // 64 query tiles x 32 key tiles per wave (~0.5 ms: the clock settles)
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<VAR>, dim3(256), dim3(1024), SMEM, 0, d, sink, qtiles, 8.0f);
+  hipMalloc(&d, 256 * BPC * 16 * sizeof(unsigned long long)); hipMalloc(&sink, 64);
+  hipMemset(d, 0, 256 * BPC * 16 * sizeof(unsigned long long));
+  auto fn = k<VAR, THREADS, BPC, DYN>;
+  hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  // static: 64 query tiles x 32 key tiles per wave; dynamic: the same total per block, claimed tile by tile
+  const int per_wave = 64 * 4 / WPS;  // equal work per SIMD whatever the wave count
+  const int qtiles = DYN ? per_wave * (THREADS / 64) : per_wave;
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fn, dim3(256 * BPC), dim3(THREADS), SMEM, 0, d, sink, qtiles, 8.0f);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k<VAR>, dim3(256), dim3(1024), SMEM, 0, d, sink, qtiles, 8.0f);
+  hipLaunchKernelGGL(fn, dim3(256 * BPC), dim3(THREADS), SMEM, 0, d, sink, qtiles, 8.0f);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  std::vector<unsigned long long> hbuf(256 * 16);
+  std::vector<unsigned long long> hbuf(256 * BPC * 16);
   hipMemcpy(hbuf.data(), d, hbuf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  double mean = 0, mx = 0; for (auto v : hbuf) { mean += (double)v; mx = v > mx ? (double)v : mx; }
-  mean /= hbuf.size();
-  const double tiles = qtiles * 32.0;
-  printf("%-58s mean wave %6.1f, slowest wave %6.1f cyc/tile/SIMD (the launch runs at the slowest), %6.2f ns, %4.2f GHz\n", name,
-         mean / tiles / 4, mx / tiles / 4, ms * 1e6 / tiles / 4, mx / (ms * 1e6));
+  double mean = 0, mx = 0; int n = 0;
+  for (auto v : hbuf) if (v) { mean += (double)v; mx = v > mx ? (double)v : mx; ++n; }
+  mean /= n;
+  const double tiles_simd = per_wave * 32.0 * WPS;  // tiles one SIMD processes in the launch
+  printf("%-58s %d waves/SIMD: launch %6.2f ns per tile and SIMD = %6.1f cycles at the %4.2f GHz held; mean wave done at %3.0f %% of the launch\n", name,
+         WPS, ms * 1e6 / tiles_simd, mx / tiles_simd, mx / (ms * 1e6), 100.0 * mean / mx);
   hipFree(d); hipFree(sink);
 }
 
 int main() {
-  printf("key loop of attn_bf16_*_kernel, 4 waves per SIMD on every SIMD; cyc/tile/SIMD = mean wave cycles per 32x32 tile / 4\n");
+  printf("key loop of attn_bf16_kernel on every SIMD of the chip, equal work per SIMD in every row\n");
+  printf("-- more waves per SIMD (blocks per CU x block size), tiles claimed dynamically like in the kernel\n");
+  run<0, 1024, 1, true>("2 tiles in flight, 16 waves x 1 block, dynamic");
+  run<0, 512, 2, true>("2 tiles in flight, 8 waves x 2 blocks, dynamic");
+  run<64, 512, 2, true>("1 tile in flight, 8 waves x 2 blocks, dynamic");
+  run<64, 768, 2, true>("1 tile in flight, 12 waves x 2 blocks (80 VGPRs), dynamic");
+  run<0, 768, 2, true>("2 tiles in flight, 12 waves x 2 blocks (80 VGPRs), dynamic");
+  run<64, 1024, 2, true>("1 tile in flight, 16 waves x 2 blocks (64 VGPRs), dynamic");
+  run<32, 512, 2, true>("3 tiles in flight, 8 waves x 2 blocks, dynamic");
+  run<256, 512, 2, true>("2 tiles in flight, one PV accumulator per tile, 8 x 2, dynamic");
+  run<512, 512, 2, true>("2 tiles in flight, one PV accumulator per MFMA of a tile, 8 x 2, dynamic");
+  run<0, 512, 2, true>("2 tiles in flight, 8 waves x 2 blocks, dynamic (again)");
+  printf("-- static equal work per wave (round 3's table: the launch ends with the slowest wave)\n");
   run<0>("real loop (2 tiles in flight)");
   run<1>("  no LDS reads");
   run<2>("  exps decoupled from the QK MFMA");

@@ -68,6 +68,17 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters, flo
       MFMA(acc1); EXP(5); EXP(6); EXP(7); EXP(8); EXP(9); CVTP(2); CVTP(3); CVTP(4);
       MFMA(acc2); EXP(10); EXP(11); EXP(12); EXP(13); EXP(14); EXP(15); CVTP(5); CVTP(6); CVTP(7);
     }
+    if (KIND == 20) {  // the SAME instructions as 19 in the order the compiler emits them for the key loop: MFMAs back to back
+      MFMA(acc0); MFMA(acc1); MFMA(acc2);
+      EXP(0); EXP(1); EXP(2); EXP(3); EXP(4); EXP(5); EXP(6); EXP(7); EXP(8); EXP(9); EXP(10); EXP(11); EXP(12); EXP(13); EXP(14); EXP(15);
+      CVTP(0); CVTP(1); CVTP(2); CVTP(3); CVTP(4); CVTP(5); CVTP(6); CVTP(7);
+    }
+    if (KIND == 21) {  // two tiles per iteration, grouped like the real loop body: 2 QK MFMAs, 32 exp, 16 packs, 4 PV MFMAs
+      MFMA(acc0); MFMA(acc1);
+      for (int r = 0; r < 2; ++r) { EXP(0); EXP(1); EXP(2); EXP(3); EXP(4); EXP(5); EXP(6); EXP(7); EXP(8); EXP(9); EXP(10); EXP(11); EXP(12); EXP(13); EXP(14); EXP(15); }
+      for (int r = 0; r < 2; ++r) { CVTP(0); CVTP(1); CVTP(2); CVTP(3); CVTP(4); CVTP(5); CVTP(6); CVTP(7); }
+      MFMA(acc2); MFMA(acc0); MFMA(acc1); MFMA(acc2);
+    }
     if (KIND == 7) {  // 10 exps on the transcendental unit, 6 scores by a 7-op polynomial on the plain VALU
 #define P7(i) FMA(i); FMA((i + 1) & 15); FMA((i + 2) & 15); FMA((i + 3) & 15); FMA((i + 4) & 15); FMA((i + 5) & 15); FMA((i + 6) & 15)
       MFMA(acc0); EXP(0); P7(0); EXP(1); P7(1); EXP(2); EXP(3); PERM(0); PERM(1);
@@ -190,6 +201,8 @@ int main() {
   run<5>("3 mfma + 16 exp");
   run<6>("3 mfma + 16 exp + 8 perm (round-2 tile)");
   run<19>("3 mfma + 16 exp + 8 cvt_pk (round-3 tile)");
+  run<20>("the same, MFMAs back to back, then exps, then packs");
+  run<21>("two tiles grouped like the real loop (per TWO tiles)");
   run<8>("3 mfma + 64 fma");
   run<7>("3 mfma + 10 exp + 42 fma + 8 perm (hybrid)");
   run<10>("3 mfma + 8 exp + 56 fma + 8 perm (hybrid)");
