@@ -180,7 +180,17 @@ def secondary_roofline(iso):
     ns_ach = iso["attn_ms"] * 1e6 / (tiles / 1024.0)  # per tile and SIMD (1024 SIMDs)
     out = {"bound": "valu+transcendental issue", "tiles_per_forward": tiles, "floor_cycles_per_tile_simd": floor_cyc,
            "ns_per_tile_achieved": ns_ach, "source": "profiles/r03_ubench_pipes.txt ('3 mfma + 16 exp + 8 cvt_pk', W = 4)"}
+    try:  # the kernel's own key loop run alone with continuously claimed tiles (tools/ubench/attn_loop.hip): what the loop's
+        #   dependent chain QK -> exp -> pack -> PV costs a SIMD in steady state, without staging, launch ramp or epilogues
+        lt = open(os.path.join(ROOT, "profiles", "r03_ubench_attn_loop.txt")).read()
+        m = re.search(r"2 tiles in flight, 8 waves x 2 blocks, dynamic\s+4 waves/SIMD: launch\s+[0-9.]+ ns per tile and SIMD =\s+([0-9.]+) cycles", lt)
+        out["key_loop_alone_cycles_per_tile_simd"] = float(m.group(1))
+        out["key_loop_source"] = "profiles/r03_ubench_attn_loop.txt ('2 tiles in flight, 8 waves x 2 blocks, dynamic')"
+    except Exception:  # noqa: BLE001
+        pass
     if clock:
+        if "key_loop_alone_cycles_per_tile_simd" in out:
+            out["frac_of_own_key_loop"] = out["key_loop_alone_cycles_per_tile_simd"] / (ns_ach * clock)
         out.update({"kernel_clock_ghz": clock, "ns_per_tile_floor": floor_cyc / clock, "cycles_per_tile_achieved": ns_ach * clock,
                     "frac": floor_cyc / (ns_ach * clock), "clock_source": "profiles/r03_attention_clock.json (GRBM_GUI_ACTIVE / duration, offline rocprofv3 --pmc pass)"})
     else:
