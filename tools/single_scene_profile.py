@@ -12,7 +12,7 @@ cfg = configs.cdsegnet_config("scannet")
 model = build_model(cfg)
 model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
 model = model.cuda().eval()
-model.precision, model.noise_source = "bf16", "device"
+model.noise_source = "device"  # (precision: the default, fp16+head)
 sc = synth.room_scene(0, 120000)
 inp = {k: torch.as_tensor(sc[k]).cuda() for k in ("coord", "grid_coord", "feat", "offset")}
 inp["offset_host"] = [int(v) for v in sc["offset"]]
