@@ -1,4 +1,5 @@
-// Training path, first slice: the backward of a Block's tail down to qkv, exact fp32.
+// Training path, first slices: the backward of a PTv3 Block (attention core, LayerNorm, GELU; weight / bias gradients of
+// the Linears and of the submanifold conv), exact fp32.
 //
 // ref: pointcept/models/default.py:424-493 (training forward), engines/train.py:216-271 (loss.backward()); what
 //      autograd differentiates here: point_transformer_v3m1_base.py:246-296 (SerializedAttention core),
@@ -230,6 +231,65 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __rest
   dx[i] = dy[i] * (cdf + t * pdf);
 }
 
+// ---- weight gradient of a Linear / of one kernel offset of a submanifold conv:
+//        dW[n][k] += sum_m dY[m][n] * X[row(m)][k],   row(m) = xidx ? xidx[m] (-1: no neighbour, skipped) : m
+//      (+ db[n] += sum_m dY[m][n]).   ref: what autograd does for nn.Linear (ptv3.py:399-428) and spconv.SubMConv3d
+//      (ptv3.py:356-362) weights; dW = dY^T X is a GEMM whose reduction runs over the ROWS (10^5 .. 10^6), so the rows are
+//      split over blockIdx.z and the partial tiles are added with fp32 atomics (summation order not fixed: ~1e-7 relative).
+//      v_mfma_f32_16x16x4_f32 straight from global memory: A[i][kk] = dY[m0 + kk][n0 + i], B[kk][j] = X[row(m0 + kk)][k0 + j]
+//      (lane = i + 16 kk); a block is 4 waves = a 64 (n) x 64 (k) tile of dW.  Not tuned (first slice).
+struct WgradP {
+  const float* dy; const float* x; const int32_t* xidx; float* dw; float* db;
+  long M, rows_per_split;
+  int N, K, lddy, ldx, lddw;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 64 + wave * 16, k0 = blockIdx.y * 64;
+  if (n0 >= p.N) return;
+  const long m_begin = (long)blockIdx.z * p.rows_per_split;
+  const long m_end = min(p.M, m_begin + p.rows_per_split);
+  f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  bool kt_ok[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) kt_ok[t] = k0 + 16 * t < p.K;
+#pragma unroll 4
+  for (long m0 = m_begin; m0 < m_end; m0 += 4) {
+    const long m = m0 + kq;
+    float a = 0.f, b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < m_end) {
+      a = p.dy[m * p.lddy + n0 + i16];
+      const long row = p.xidx ? (long)p.xidx[m] : m;
+      if (row >= 0) {
+        const float* xr = p.x + row * p.ldx + k0 + i16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (kt_ok[t]) b[t] = xr[16 * t];
+      }
+    }
+    bsum += a;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+  }
+  // D[i][j]: lane holds j = lane & 15, i = 4 (lane >> 4) + r
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (!kt_ok[t]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (long)(n0 + 4 * kq + r) * p.lddw + k0 + 16 * t + i16, acc[t][r]);
+  }
+  if (p.db && blockIdx.y == 0) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 16) atomicAdd(p.db + n0 + lane, bsum);
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cdseg_attention_bwd_ws_bytes(long num_slots, int num_heads) {
@@ -270,6 +330,25 @@ extern "C" int cdseg_layernorm_bwd(const float* x, int ldx, const float* gamma, 
 extern "C" int cdseg_gelu_bwd(const float* u, const float* dy, float* dx, long n, void* stream) {
   if (n <= 0) return CDSEG_OK;
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, u, dy, dx, n);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+extern "C" int cdseg_linear_wgrad(const float* x, int ldx, const int32_t* xidx, const float* dy, int lddy, long m, int k, int n,
+                                  float* dw, int lddw, float* db, void* stream) {
+  if (m <= 0 || n <= 0 || k <= 0) return CDSEG_OK;
+  if ((n & 15) || (k & 15)) return CDSEG_ERR_UNSUPPORTED;
+  WgradP p;
+  p.dy = dy; p.x = x; p.xidx = xidx; p.dw = dw; p.db = db; p.M = m; p.N = n; p.K = k; p.lddy = lddy; p.ldx = ldx; p.lddw = lddw;
+  const int tiles = cdiv(n, 64) * cdiv(k, 64);
+  long splits = (2048 + tiles - 1) / tiles;  // ~8 blocks per CU
+  const long max_splits = (m + 255) / 256;   // at least 256 rows per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.rows_per_split = ((m + splits - 1) / splits + 3) & ~3L;
+  splits = (m + p.rows_per_split - 1) / p.rows_per_split;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(k, 64), (unsigned)splits), dim3(256), 0,
+                     (hipStream_t)stream, p);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

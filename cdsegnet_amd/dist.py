@@ -7,6 +7,9 @@ independent units - one process per GPU, no data-path collective.  The only traf
   * per eval:  all-reduce of the per-class intersection / union / target counters
                (replaces gloo gather_object of pickled records, ref: engines/test.py:374,
                utils/comm.py:169).
+  * training (first slices, cdsegnet_amd.train): `GradBucketer` - bucketed mean all-reduce of the parameter gradients,
+               launched bucket by bucket while the backward is still producing the earlier layers' gradients
+               (replaces DistributedDataParallel's reducer, ref: pointcept/engines/train.py:142-160, defaults.py:38).
 `torch.distributed` backend "nccl" is RCCL on ROCm (xGMI); "gloo" is used by the CPU tests.
 """
 import torch
@@ -135,3 +138,64 @@ def metrics(counts):
 
 def miou(counts):
     return metrics(counts)["mIoU"]
+
+
+class GradBucketer:
+    """Data-parallel gradient averaging for the training path: gradients are handed over in the order the backward
+    produces them (last layer first), packed into flat fp32 buckets, and every full bucket is all-reduced right away
+    (`async_op`: on RCCL the collective runs on its own stream next to the remaining backward kernels).  `finish()` waits,
+    divides by the world size and returns {name: averaged gradient (a view into its bucket)}.
+
+    Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce moves 2 (N-1)/N of the bucket per
+    GPU over ONE link pair per step - 64 MB keeps a step at ~0.1 ms of wire time against ~20 us of launch + sync latency
+    per ring step (the 101 M-parameter model is 406 MB of fp32 gradients: 7 buckets); DistributedDataParallel's 25 MB
+    default is sized for NVLink-switch latencies."""
+
+    def __init__(self, bucket_bytes=64 << 20, group=None):
+        self.cap = max(4, int(bucket_bytes)) // 4
+        self.group = group
+        self.cur, self.cur_fill = [], 0
+        self.pending = []  # (flat, [(name, shape, offset, numel)], work)
+        self.world = dist.get_world_size(group) if is_dist() else 1
+
+    def _flush(self):
+        if not self.cur:
+            return
+        dev = self.cur[0][1].device
+        flat = torch.empty(self.cur_fill, dtype=torch.float32, device=dev)
+        meta, off = [], 0
+        for name, g in self.cur:
+            k = g.numel()
+            flat[off:off + k].copy_(g.reshape(-1))
+            meta.append((name, tuple(g.shape), off, k))
+            off += k
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+        self.pending.append((flat, meta, work))
+        self.cur, self.cur_fill = [], 0
+
+    def add(self, name, grad):
+        if grad.dtype != torch.float32:
+            raise TypeError(f"{name}: gradients are reduced in fp32, got {grad.dtype}")
+        if self.cur and self.cur_fill + grad.numel() > self.cap:
+            self._flush()
+        self.cur.append((name, grad))
+        self.cur_fill += grad.numel()
+        if self.cur_fill >= self.cap:
+            self._flush()
+
+    def finish(self):
+        self._flush()
+        out = {}
+        for flat, meta, work in self.pending:
+            if work is not None:
+                work.wait()
+            if self.world > 1:
+                flat.div_(self.world)
+            for name, shape, off, k in meta:
+                if name in out:
+                    raise KeyError(f"gradient {name} handed over twice")
+                out[name] = flat[off:off + k].view(shape)
+        n_buckets = len(self.pending)
+        self.pending = []
+        self.buckets_reduced = n_buckets
+        return out

@@ -959,3 +959,16 @@ def gelu_bwd(u, dy):
     dx = torch.empty_like(u)
     check(_lib.load().cdseg_gelu_bwd(_ptr(u), _ptr(dy), _ptr(dx), u.numel(), _stream()), "gelu_bwd")
     return dx
+
+
+def linear_wgrad(x, dy, dw, db=None, xidx=None):
+    """dw (N, K view, any row stride) += dy^T x[xidx or arange] and db (N) += column sums of dy; fp32 (cdseg_linear_wgrad).
+    xidx (M) int32 with -1 = no row: one kernel offset of a submanifold conv."""
+    _need_gpu(x, dy, dw)
+    assert x.dtype == dy.dtype == dw.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
+    m, n = dy.shape
+    k = x.shape[1]
+    assert tuple(dw.shape) == (n, k) and (xidx is None or (xidx.dtype == torch.int32 and xidx.numel() == m))
+    check(_lib.load().cdseg_linear_wgrad(_ptr(x), x.stride(0), _ptr(xidx), _ptr(dy), dy.stride(0), m, k, n, _ptr(dw),
+                                         dw.stride(0), _ptr(db), _stream()), "linear_wgrad")
+    return dw

@@ -424,7 +424,14 @@ int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, 
  *   receive no output gradient but still act as keys.  num_slots = patch_start[num_patches]; num_tiles = sum over patches
  *   of ceil(L / 64).  ws: cdseg_attention_bwd_ws_bytes.  dtype: CDSEG_F32 only so far.
  * cdseg_layernorm_bwd: dx (=, or += when accumulate) for y = LayerNorm(x) * gamma + beta; optional dgamma / dbeta (+=).
- * cdseg_gelu_bwd: dx = dy * d/du GELU(u) on the pre-activation u (erf form, torch.nn.GELU()). */
+ * cdseg_gelu_bwd: dx = dy * d/du GELU(u) on the pre-activation u (erf form, torch.nn.GELU()).
+ * cdseg_linear_wgrad: dw[n][k] += sum_m dy[m][n] * x[row(m)][k] and (db != NULL) db[n] += sum_m dy[m][n], fp32; row(m) = m,
+ *   or xidx[m] with -1 = skip: ONE kernel offset of a submanifold conv (xidx = that offset's row of the offset-major kernel
+ *   map, dw = the offset's (Cout, Cin) slice of the (Cout, 27, Cin) weight, lddw = 27 * Cin; ref: spconv.SubMConv3d weight
+ *   gradient, ptv3.py:356-362).  n, k multiples of 16.  Accumulates (the caller zeroes dw / db); partial sums are added
+ *   with fp32 atomics (summation order not fixed).  The DATA gradient of a Linear / of the conv needs no entry point of
+ *   its own: it is cdseg_gemm on the transposed weight / on the mirrored, transposed kernel (W'[ci][o][co] = W[co][26-o][ci])
+ *   with the same kernel map. */
 size_t cdseg_attention_bwd_ws_bytes(long num_slots, int num_heads);
 int cdseg_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const int32_t* q_gidx,
                         const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
@@ -433,6 +440,8 @@ int cdseg_attention_bwd(const void* q, const void* k, const void* v, int ldq, in
 int cdseg_layernorm_bwd(const float* x, int ldx, const float* gamma, float eps, const float* dy, int lddy, float* dx, int lddx,
                         int accumulate, float* dgamma, float* dbeta, long m, int c, void* stream);
 int cdseg_gelu_bwd(const float* u, const float* dy, float* dx, long n, void* stream);
+int cdseg_linear_wgrad(const float* x, int ldx, const int32_t* xidx, const float* dy, int lddy, long m, int k, int n, float* dw,
+                       int lddw, float* db, void* stream);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,8 @@ def frozen(tag, make):
     path = os.path.join(OUT, f"{tag}.npz")
     if os.path.exists(path) and not REGEN_INPUTS:
         with np.load(path, allow_pickle=False) as f:
+            if "coord" not in f.files:  # (a fixture that does not carry its scene: regenerate it)
+                return make()
             sc = {k: f[k] for k in ("coord", "grid_coord", "feat", "offset")}
         sc["segment"] = np.zeros(len(sc["coord"]), dtype=np.int64)
         return sc
@@ -499,12 +501,17 @@ def gen_train(ref):
         (y * g).sum().backward()
     for h in hooks:
         h.remove()
-    fx = dict(x0=cap["x0"].numpy(), dy=g.numpy(), y=y.detach().numpy(), d_qkv=cap["qkv"].grad.numpy(),
+    fx = dict(coord=scene["coord"], grid_coord=scene["grid_coord"], feat=scene["feat"], offset=scene["offset"],
+              x0=cap["x0"].numpy(), dy=g.numpy(), y=y.detach().numpy(), d_qkv=cap["qkv"].grad.numpy(),
               order=cap["order"].numpy().astype(np.int64), inverse=cap["inverse"].numpy().astype(np.int64),
               cu=cap["cu"].numpy().astype(np.int64), num_heads=np.int64(blk.attn.num_heads), prefix=np.array(pre))
     for k, v in sd.items():
         if k.startswith(pre + ".") and (".norm" in k or ".attn." in k or ".mlp." in k):
             fx["sd." + k] = v.numpy()
+    # the reference's own parameter gradients of the tail (second slice: weight / bias / LayerNorm-affine gradients)
+    for k, p_ in model.named_parameters():
+        if k.startswith(pre + ".") and (".norm" in k or ".attn." in k or ".mlp." in k) and p_.grad is not None:
+            fx["g." + k] = p_.grad.detach().numpy()
     save_fixture(os.path.join(OUT, "train_block_tail.npz"), **fx)
     print("train_block_tail", fx["x0"].shape, "slots", fx["order"].shape, "patches", len(fx["cu"]) - 1,
           "|d_qkv|", float(np.abs(fx["d_qkv"]).mean()))

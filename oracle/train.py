@@ -34,3 +34,18 @@ def block_tail_qkv_grad(sd, pre, x0, order, inverse, cu, H, dy):
     y, qkv = block_tail(sd, pre, x0, order, inverse, cu, H)
     (y * torch.as_tensor(dy, dtype=torch.float32)).sum().backward()
     return y.detach(), qkv.grad.detach()
+
+
+def block_full_grads(sd, pre, x_in, nbr, order, inverse, cu, H, dy):
+    """The WHOLE Block (ptv3.py:399-428 in eval mode: CPE conv -> Linear -> LayerNorm, attention, MLP) under autograd:
+    returns (y, d x_in, {parameter key: gradient}) for <y, dy>.  nbr: (N, 27) kernel map (oracle.model.subm_neighbors).
+    The sparse conv is the oracle's restatement (spconv is not importable on CPU: parity of its arithmetic is unpinned,
+    DESIGN.md 2) - everything behind it is pinned by the reference fixture of the tail."""
+    x_in = torch.as_tensor(x_in, dtype=torch.float32).clone().requires_grad_(True)
+    sd = {k: torch.as_tensor(v).clone().requires_grad_(True) for k, v in sd.items()}
+    w = sd[pre + ".cpe.0.weight"]
+    yc = OM.subm_conv3d(x_in, np.asarray(nbr), w, sd.get(pre + ".cpe.0.bias"))
+    x0 = x_in + OM.layernorm(OM.linear(yc, sd, pre + ".cpe.1"), sd, pre + ".cpe.2")
+    y, _ = block_tail(sd, pre, x0, order, inverse, cu, H)
+    (y * torch.as_tensor(dy, dtype=torch.float32)).sum().backward()
+    return y.detach(), x_in.grad.detach(), {k: v.grad.detach() for k, v in sd.items() if v.grad is not None}

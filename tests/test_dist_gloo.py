@@ -148,3 +148,36 @@ def test_low_precision_broadcast_rounds_only_what_the_engine_casts(tmp_path):
     for frag in (".attn.qkv.weight", ".cpe.0.weight", ".mlp.0.fc1.weight", ".stem.conv.weight", ".down.proj.weight"):
         hit = [k for k in names if k.endswith(frag)]
         assert hit and all(cdist.engine_casts(k, ref[k]) for k in hit), frag
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        shapes = {"head.w": (20, 64), "dec.fc2.w": (64, 256), "dec.fc2.b": (64,), "enc.conv.w": (32, 27 * 32), "emb.b": (32,),
+                  "big.w": (300, 100)}
+        grads = {k: torch.randn(*sh, generator=g) for k, sh in shapes.items()}
+        b = cdist.GradBucketer(bucket_bytes=64 * 1024)  # small buckets: several flushes, one tensor larger than a bucket
+        for k in shapes:  # the order a backward would hand them over
+            b.add(k, grads[k])
+        out = b.finish()
+        torch.save({"out": {k: v.clone() for k, v in out.items()}, "mine": grads, "buckets": b.buckets_reduced},
+                   os.path.join(out_dir, f"grads{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucketer_two_ranks_gloo(tmp_path):
+    """Bucketed gradient all-reduce of the training path: both ranks end with the mean, tensor by tensor."""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"grads{r}.pt")) for r in (0, 1))
+    assert r0["buckets"] >= 3
+    for k in r0["mine"]:
+        mean = (r0["mine"][k] + r1["mine"][k]) / 2
+        assert r0["out"][k].shape == mean.shape
+        assert torch.allclose(r0["out"][k], mean, atol=1e-6) and torch.equal(r0["out"][k], r1["out"][k])
+    one = cdist.GradBucketer()  # no process group: pass-through
+    one.add("w", torch.ones(3, 3))
+    assert torch.equal(one.finish()["w"], torch.ones(3, 3))

@@ -57,6 +57,36 @@ def test_block_tail_backward_matches_the_reference_autograd():
     assert eg < 1e-4 * max(1.0, float(np.abs(fx["d_qkv"]).max()))  # in fact at fp32 round-off
 
 
+def test_block_tail_parameter_gradients_match_the_reference_autograd():
+    """Second slice: weight / bias / LayerNorm-affine gradients of the tail's twelve parameter tensors against the
+    gradients the REFERENCE's autograd left on its own parameters (fixture keys g.*)."""
+    fx = load_fixture("train_block_tail.npz")
+    pre = str(fx["prefix"])
+    sd = {k[3:]: fx[k] for k in fx.files if k.startswith("sd.")}
+    dev = torch.device("cuda")
+    w = _weights(sd, pre, dev)
+    gidx, widx = _slot_plan(fx["order"], fx["inverse"], dev)
+    cu = fx["cu"]
+    ps = torch.as_tensor(np.asarray(cu), dtype=torch.int32).to(dev)
+    H = int(fx["num_heads"])
+    C = fx["x0"].shape[1]
+    t = train.block_tail_forward(w, "B", torch.as_tensor(fx["x0"], dtype=torch.float32).to(dev).contiguous(), gidx, widx, ps,
+                                 [int(v) for v in cu], H, int(np.diff(cu).max()), (C // H) ** -0.5)
+    out = train.block_tail_backward(w, "B", t, torch.as_tensor(fx["dy"], dtype=torch.float32).to(dev).contiguous(), param_grads=True)
+    torch.cuda.synchronize()
+    names = {"B.norm1.g": ".norm1.0.weight", "B.norm1.b": ".norm1.0.bias", "B.qkv.w": ".attn.qkv.weight", "B.qkv.b": ".attn.qkv.bias",
+             "B.proj.w": ".attn.proj.weight", "B.proj.b": ".attn.proj.bias", "B.norm2.g": ".norm2.0.weight", "B.norm2.b": ".norm2.0.bias",
+             "B.fc1.w": ".mlp.0.fc1.weight", "B.fc1.b": ".mlp.0.fc1.bias", "B.fc2.w": ".mlp.0.fc2.weight", "B.fc2.b": ".mlp.0.fc2.bias"}
+    assert set(out["grads"]) == set(names)
+    worst = 0.0
+    for mine, ref in names.items():
+        r = fx["g." + pre + ref]
+        e = float(np.abs(out["grads"][mine].cpu().numpy() - r).max()) / max(1.0, float(np.abs(r).max()))
+        worst = max(worst, e)
+        assert e < 1e-3, (mine, e)
+    print(f"[measure] tail parameter gradients vs reference autograd: worst rel err {worst:.3e} over 12 tensors")
+
+
 @pytest.mark.parametrize("lens,H", [([700], 2), ([1024, 1024, 300], 4), ([64, 1, 130], 8)])
 def test_block_tail_backward_vs_oracle(lens, H):
     """Ragged patches (incl. a 1-slot patch), more heads, slots that repeat rows (padding duplicates)."""
@@ -108,3 +138,93 @@ def test_layernorm_and_gelu_backward_kernels():
     ur = u.clone().requires_grad_(True)
     torch.nn.functional.gelu(ur).sum().backward()
     assert float((du.cpu() - ur.grad).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ second slice: the whole Block
+def test_linear_wgrad_kernel_plain_and_gathered():
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 5003, 48, 96
+    x, dy = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g)
+    idx = torch.randint(-1, M, (M,), generator=g).to(torch.int32)
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    wide = torch.zeros(N, 3 * K, device=dev)  # a strided (N, K) slice of a wider matrix, like one conv offset
+    ops.bind_stream()
+    try:
+        ops.linear_wgrad(x.to(dev), dy.to(dev), dw, db)
+        ops.linear_wgrad(x.to(dev), dy.to(dev), wide[:, K:2 * K], None, xidx=idx.to(dev))
+    finally:
+        ops.unbind_stream()
+    ref = dy.double().t() @ x.double()
+    assert float((dw.cpu().double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+    assert float((db.cpu().double() - dy.double().sum(0)).abs().max()) < 1e-3 * float(dy.double().sum(0).abs().max())
+    m = idx >= 0
+    refg = dy[m].double().t() @ x[idx[m].long()].double()
+    assert float((wide[:, K:2 * K].cpu().double() - refg).abs().max()) < 1e-3 * float(refg.abs().max())
+    assert float(wide[:, :K].abs().max()) == 0.0 and float(wide[:, 2 * K:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("npts,H", [(900, 2), (2300, 4)])
+def test_whole_block_backward_vs_oracle(npts, H):
+    """CPE conv + Linear + LayerNorm + attention + MLP of one Block: gradient of the input and of every parameter against
+    torch autograd on the oracle restatement (real kernel map of a synthetic scene, real padded patch plan)."""
+    from cdsegnet_amd import synth
+    from oracle import model as OM
+    from oracle import serialization as S
+    rng = np.random.default_rng(npts + H)
+    sc = synth.room_scene(7, npts)
+    grid = np.asarray(sc["grid_coord"], dtype=np.int64)
+    n = len(grid)
+    C = 16 * H
+    nbr = OM.subm_neighbors(grid, np.zeros(n, dtype=np.int64), 3)  # (n, 27)
+    K = 1024
+    offset = np.array([n])
+    pad, unpad, cu = S.padding_plan(offset, K)
+    perm = rng.permutation(n)  # any serialization order
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    order, inverse = perm[pad], unpad[inv]
+    pre = "blk"
+    sd = {}
+    for k, shape in ((".cpe.0.weight", (C, 3, 3, 3, C)), (".cpe.0.bias", (C,)), (".cpe.1.weight", (C, C)), (".cpe.1.bias", (C,)),
+                     (".cpe.2.weight", (C,)), (".cpe.2.bias", (C,)),
+                     (".norm1.0.weight", (C,)), (".norm1.0.bias", (C,)), (".attn.qkv.weight", (3 * C, C)), (".attn.qkv.bias", (3 * C,)),
+                     (".attn.proj.weight", (C, C)), (".attn.proj.bias", (C,)), (".norm2.0.weight", (C,)), (".norm2.0.bias", (C,)),
+                     (".mlp.0.fc1.weight", (4 * C, C)), (".mlp.0.fc1.bias", (4 * C,)), (".mlp.0.fc2.weight", (C, 4 * C)),
+                     (".mlp.0.fc2.bias", (C,))):
+        scale = {1: 0.1, 2: 0.3, 5: 0.3 / 27 ** 0.5}[len(shape)]
+        sd[pre + k] = (rng.standard_normal(shape) * scale + (1.0 if k.endswith(".weight") and len(shape) == 1 else 0.0)).astype(np.float32)
+    x_in = rng.standard_normal((n, C)).astype(np.float32)
+    dy = rng.standard_normal((n, C)).astype(np.float32)
+    ry, rdx, rg = OT.block_full_grads(sd, pre, x_in, nbr, order, inverse, cu, H, dy)
+
+    dev = torch.device("cuda")
+    w = _weights(sd, pre, dev)
+    f = lambda k: torch.as_tensor(sd[pre + k], dtype=torch.float32).to(dev).contiguous()  # noqa: E731
+    w.update({"B.cpe0.w": f(".cpe.0.weight").reshape(C, -1).contiguous(), "B.cpe0.b": f(".cpe.0.bias"), "B.cpe1.w": f(".cpe.1.weight"),
+              "B.cpe1.b": f(".cpe.1.bias"), "B.cpe2.g": f(".cpe.2.weight"), "B.cpe2.b": f(".cpe.2.bias")})
+    gidx, widx = _slot_plan(order, inverse, dev)
+    ps = torch.as_tensor(np.asarray(cu), dtype=torch.int32).to(dev)
+    nbr_k = torch.as_tensor(nbr.T.astype(np.int32)).contiguous().to(dev)
+    tape = train.block_forward(w, "B", torch.as_tensor(x_in).to(dev), nbr_k, gidx, widx, ps, [int(v) for v in cu], H,
+                               int(np.diff(cu).max()), (C // H) ** -0.5)
+    dx, dxc, grads = train.block_backward(w, "B", tape, torch.as_tensor(dy).to(dev))
+    torch.cuda.synchronize()
+    assert dxc is None
+    ey = float(np.abs(tape["tail"].y.cpu().numpy() - ry.numpy()).max())
+    ex = float(np.abs(dx.cpu().numpy() - rdx.numpy()).max()) / max(1.0, float(rdx.abs().max()))
+    names = {"B.cpe0.w": ".cpe.0.weight", "B.cpe0.b": ".cpe.0.bias", "B.cpe1.w": ".cpe.1.weight", "B.cpe1.b": ".cpe.1.bias",
+             "B.cpe2.g": ".cpe.2.weight", "B.cpe2.b": ".cpe.2.bias", "B.norm1.g": ".norm1.0.weight", "B.norm1.b": ".norm1.0.bias",
+             "B.qkv.w": ".attn.qkv.weight", "B.qkv.b": ".attn.qkv.bias", "B.proj.w": ".attn.proj.weight", "B.proj.b": ".attn.proj.bias",
+             "B.norm2.g": ".norm2.0.weight", "B.norm2.b": ".norm2.0.bias", "B.fc1.w": ".mlp.0.fc1.weight", "B.fc1.b": ".mlp.0.fc1.bias",
+             "B.fc2.w": ".mlp.0.fc2.weight", "B.fc2.b": ".mlp.0.fc2.bias"}
+    assert set(grads) == set(names)
+    worst = 0.0
+    for mine, ref in names.items():
+        r = rg[pre + ref].reshape(grads[mine].shape)
+        e = float((grads[mine].cpu() - r).abs().max()) / max(1.0, float(r.abs().max()))
+        worst = max(worst, e)
+        assert e < 1e-3, (mine, e)
+    print(f"[measure] whole Block backward vs oracle autograd n={n} H={H}: forward {ey:.3e}, d_x_in rel {ex:.3e}, "
+          f"worst parameter gradient rel {worst:.3e} (18 tensors incl. the 27-offset conv kernel)")
+    assert ey < 1e-3 and ex < 1e-3

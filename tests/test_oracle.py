@@ -284,3 +284,15 @@ def test_train_oracle_matches_the_reference_autograd():
     y, g = OT.block_tail_qkv_grad(sd, pre, fx["x0"], fx["order"], fx["inverse"], fx["cu"], int(fx["num_heads"]), fx["dy"])
     assert float(np.abs(y.numpy() - fx["y"]).max()) < 1e-5
     assert float(np.abs(g.numpy() - fx["d_qkv"]).max()) < 1e-6
+    # second slice: the oracle's parameter gradients against the ones the reference's autograd left on its parameters
+    sdt = {k: torch.as_tensor(v).clone().requires_grad_(True) for k, v in sd.items()}
+    x0 = torch.as_tensor(fx["x0"], dtype=torch.float32)
+    yy, _ = OT.block_tail(sdt, pre, x0, fx["order"], fx["inverse"], fx["cu"], int(fx["num_heads"]))
+    (yy * torch.as_tensor(fx["dy"])).sum().backward()
+    checked = 0
+    for k in fx.files:
+        if k.startswith("g."):
+            r = fx[k]
+            assert float(np.abs(sdt[k[2:]].grad.numpy() - r).max()) < 1e-5 * max(1.0, float(np.abs(r).max())), k
+            checked += 1
+    assert checked == 12
