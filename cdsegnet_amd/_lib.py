@@ -145,6 +145,8 @@ SIGNATURES = {
     "cdseg_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                     c_void_p, c_long, c_int, c_void_p]),
     "cdseg_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "cdseg_conv_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p]),
     "cdseg_linear_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_int, c_void_p,
                                    c_void_p]),
     "cdseg_prof_enable": (c_int, [c_int]),

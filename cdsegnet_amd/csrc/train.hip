@@ -240,8 +240,9 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __rest
 //      (lane = i + 16 kk); a block is 4 waves = a 64 (n) x 64 (k) tile of dW.  Not tuned (first slice).
 struct WgradP {
   const float* dy; const float* x; const int32_t* xidx; float* dw; float* db;
-  long M, rows_per_split;
+  long M, rows_per_split, idx_stride;  // idx_stride: elements between the index rows of consecutive offsets (conv form)
   int N, K, lddy, ldx, lddw;
+  int splits, dw_off_stride;           // blockIdx.z = offset * splits + split; offset o adds o * dw_off_stride to dw
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
@@ -249,8 +250,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
   const int i16 = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * 64 + wave * 16, k0 = blockIdx.y * 64;
   if (n0 >= p.N) return;
-  const long m_begin = (long)blockIdx.z * p.rows_per_split;
+  const int off = blockIdx.z / p.splits;  // kernel offset (conv form; 0 for a Linear)
+  const long m_begin = (long)(blockIdx.z - off * p.splits) * p.rows_per_split;
   const long m_end = min(p.M, m_begin + p.rows_per_split);
+  const int32_t* xidx = p.xidx ? p.xidx + off * p.idx_stride : nullptr;
+  float* dw = p.dw + (long)off * p.dw_off_stride;
   f32x4_t acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     float a = 0.f, b[4] = {0.f, 0.f, 0.f, 0.f};
     if (m < m_end) {
       a = p.dy[m * p.lddy + n0 + i16];
-      const long row = p.xidx ? (long)p.xidx[m] : m;
+      const long row = xidx ? (long)xidx[m] : m;
       if (row >= 0) {
         const float* xr = p.x + row * p.ldx + k0 + i16;
 #pragma unroll
@@ -281,9 +285,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
   for (int t = 0; t < 4; ++t) {
     if (!kt_ok[t]) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (long)(n0 + 4 * kq + r) * p.lddw + k0 + 16 * t + i16, acc[t][r]);
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + (long)(n0 + 4 * kq + r) * p.lddw + k0 + 16 * t + i16, acc[t][r]);
   }
-  if (p.db && blockIdx.y == 0) {
+  if (p.db && blockIdx.y == 0 && off == 0) {
     bsum += __shfl_xor(bsum, 16, 64);
     bsum += __shfl_xor(bsum, 32, 64);
     if (lane < 16) atomicAdd(p.db + n0 + lane, bsum);
@@ -334,21 +338,37 @@ extern "C" int cdseg_gelu_bwd(const float* u, const float* dy, float* dx, long n
   return CDSEG_OK;
 }
 
+static int launch_wgrad(WgradP p, int noff, hipStream_t stream) {
+  const int tiles = cdiv(p.N, 64) * cdiv(p.K, 64) * noff;
+  long splits = (2048 + tiles - 1) / tiles;     // ~8 blocks per CU
+  const long max_splits = (p.M + 1023) / 1024;  // at least 1024 rows per block: 4096 atomics per tile
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.rows_per_split = ((p.M + splits - 1) / splits + 3) & ~3L;
+  splits = (p.M + p.rows_per_split - 1) / p.rows_per_split;
+  p.splits = (int)splits;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.K, 64), (unsigned)(splits * noff)), dim3(256), 0,
+                     stream, p);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
 extern "C" int cdseg_linear_wgrad(const float* x, int ldx, const int32_t* xidx, const float* dy, int lddy, long m, int k, int n,
                                   float* dw, int lddw, float* db, void* stream) {
   if (m <= 0 || n <= 0 || k <= 0) return CDSEG_OK;
   if ((n & 15) || (k & 15)) return CDSEG_ERR_UNSUPPORTED;
   WgradP p;
   p.dy = dy; p.x = x; p.xidx = xidx; p.dw = dw; p.db = db; p.M = m; p.N = n; p.K = k; p.lddy = lddy; p.ldx = ldx; p.lddw = lddw;
-  const int tiles = cdiv(n, 64) * cdiv(k, 64);
-  long splits = (2048 + tiles - 1) / tiles;  // ~8 blocks per CU
-  const long max_splits = (m + 255) / 256;   // at least 256 rows per block
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  p.rows_per_split = ((m + splits - 1) / splits + 3) & ~3L;
-  splits = (m + p.rows_per_split - 1) / p.rows_per_split;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(k, 64), (unsigned)splits), dim3(256), 0,
-                     (hipStream_t)stream, p);
-  CDSEG_CHECK_LAUNCH();
-  return CDSEG_OK;
+  p.idx_stride = 0; p.dw_off_stride = 0;
+  return launch_wgrad(p, 1, (hipStream_t)stream);
+}
+
+extern "C" int cdseg_conv_wgrad(const float* x, int ldx, const int32_t* nbr_kmajor, int kvol, const float* dy, int lddy, long m,
+                                int cin, int cout, float* dw, float* db, void* stream) {
+  if (m <= 0 || kvol <= 0) return CDSEG_OK;
+  if ((cin & 15) || (cout & 15)) return CDSEG_ERR_UNSUPPORTED;
+  WgradP p;
+  p.dy = dy; p.x = x; p.xidx = nbr_kmajor; p.dw = dw; p.db = db; p.M = m; p.N = cout; p.K = cin; p.lddy = lddy; p.ldx = ldx;
+  p.lddw = kvol * cin; p.idx_stride = m; p.dw_off_stride = cin;
+  return launch_wgrad(p, kvol, (hipStream_t)stream);
 }

@@ -972,3 +972,16 @@ def linear_wgrad(x, dy, dw, db=None, xidx=None):
     check(_lib.load().cdseg_linear_wgrad(_ptr(x), x.stride(0), _ptr(xidx), _ptr(dy), dy.stride(0), m, k, n, _ptr(dw),
                                          dw.stride(0), _ptr(db), _stream()), "linear_wgrad")
     return dw
+
+
+def conv_wgrad(x, nbr_kmajor, dy, dw3, db=None):
+    """dw3 (Cout, kvol, Cin) += the weight gradient of a submanifold conv over all kernel offsets (one launch), db += the
+    bias gradient; nbr_kmajor (kvol, M) int32 offset-major kernel map.  fp32 (cdseg_conv_wgrad)."""
+    _need_gpu(x, dy, dw3)
+    kvol, m = nbr_kmajor.shape
+    cout, kv, cin = dw3.shape
+    assert kv == kvol and dw3.is_contiguous() and x.dtype == dy.dtype == dw3.dtype == torch.float32
+    assert nbr_kmajor.dtype == torch.int32 and nbr_kmajor.is_contiguous() and dy.shape == (m, cout) and x.shape[1] == cin
+    check(_lib.load().cdseg_conv_wgrad(_ptr(x), x.stride(0), _ptr(nbr_kmajor), kvol, _ptr(dy), dy.stride(0), m, cin, cout,
+                                       _ptr(dw3), _ptr(db), _stream()), "conv_wgrad")
+    return dw3

@@ -179,8 +179,7 @@ def block_backward(w, pre, tape, dy):
         dbc = torch.zeros_like(w[pre + ".cpe0.b"]) if w.get(pre + ".cpe0.b") is not None else None
         dw3 = dwc.view(cout, 27, cin)
         nbr = tape["nbr"]
-        for o in range(27):  # one gathered dY^T X per kernel offset
-            ops.linear_wgrad(tape["x_conv"], dyc, dw3[:, o, :], dbc if o == 13 else None, xidx=nbr[o])
+        ops.conv_wgrad(tape["x_conv"], nbr, dyc, dw3, dbc)  # 27 gathered dY^T X in one launch
         grads[pre + ".cpe0.w"] = dwc
         if dbc is not None:
             grads[pre + ".cpe0.b"] = dbc

@@ -442,6 +442,10 @@ int cdseg_layernorm_bwd(const float* x, int ldx, const float* gamma, float eps, 
 int cdseg_gelu_bwd(const float* u, const float* dy, float* dx, long n, void* stream);
 int cdseg_linear_wgrad(const float* x, int ldx, const int32_t* xidx, const float* dy, int lddy, long m, int k, int n, float* dw,
                        int lddw, float* db, void* stream);
+/* all kvol offsets of a submanifold conv in one launch: dw (cout, kvol, cin) += ..., db (cout) += column sums of dy;
+ * nbr_kmajor: the (kvol, m) offset-major kernel map */
+int cdseg_conv_wgrad(const float* x, int ldx, const int32_t* nbr_kmajor, int kvol, const float* dy, int lddy, long m, int cin,
+                     int cout, float* dw, float* db, void* stream);
 
 #ifdef __cplusplus
 }
