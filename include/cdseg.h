@@ -333,7 +333,7 @@ int cdseg_subm_conv3(const void* x, int ldx, const void* wimg, const float* bias
  * ref: ptv3.py:633-663 (Embedding: SubMConv3d(c_in -> 32, k = 5, bias = False) + BatchNorm1d(eps 1e-3) + GELU).
  * The <= 125 neighbours of a point are enumerated through the next coarser level (27 parent cells x <= 8 children);
  * bf16 operands, fp32 accumulation (csrc/stem.hip).  x8 (n, 8) bf16 rows in physical order (channels zero-padded),
- * wimg = cdseg_stem5_pack image of the (32, 125 * 8) bf16 weight, scale / shift = folded BatchNorm, grid (n, 3),
+ * wimg = cdseg_stem5_pack image (MFMA fragment order, cdseg_stem5_wimg_bytes) of the (32, 125 * 8) 16-bit weight, scale / shift = folded BatchNorm, grid (n, 3),
  * cluster (n) parent of every point, parent_nbr3 (27, m) offset-major 3x3x3 map of the parent level,
  * child_info (m) from cdseg_child_info(fine z-codes, children runs).  out (n, 32) fp32, out2 (n, 32) bf16 or NULL. */
 int cdseg_child_info(const int64_t* zcode_sorted, const int32_t* seg_start, long m, int64_t* info, void* stream);

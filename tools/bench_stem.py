@@ -4,6 +4,9 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cdsegnet_amd import _lib
+if os.environ.get("CDSEG_AB_LIB"):  # A/B runs against another build of the library (tools only)
+    _lib.LIB_PATH = os.path.abspath(os.environ["CDSEG_AB_LIB"])
 from cdsegnet_amd import ops, synth
 from tools.bench_gemm import time_op
 
