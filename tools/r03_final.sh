@@ -8,6 +8,11 @@ mkdir -p gpurun_out
 tail -3 gpurun_out/r03f_tests.log
 grep "\[measure\]" gpurun_out/r03f_tests.log | sed 's/^\.*//' > gpurun_out/r03f_parity_measured.txt; wc -l gpurun_out/r03f_parity_measured.txt
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/r03f_smoke.log 2>&1; tail -4 gpurun_out/r03f_smoke.log
+# HBM traffic of the attention kernel over bench.py's own forwards (separate --pmc passes), read by the bench line below
+bash tools/pmc_bench_traffic.sh $GRAFT_REPO_ROOT/gpurun_out/r03f_attention_traffic.json > gpurun_out/r03f_pmc.log 2>&1
+tail -6 gpurun_out/r03f_pmc.log
+cp gpurun_out/r03f_attention_traffic.json profiles/r03_attention_traffic.json
+cd $GRAFT_REPO_ROOT
 ( timeout 600 python bench.py ) > gpurun_out/r03f_bench.json 2> gpurun_out/r03f_bench.err
 cat gpurun_out/r03f_bench.json
 cd /tmp && export TMPDIR=/tmp
