@@ -690,3 +690,29 @@ def test_model_variants_full_width_vs_oracle(variant):
     err, agree = report(f"scannet/{variant} full width fp32 vs oracle", logits, ref)
     assert logits.shape == (n, cfg["num_classes"])
     assert err < 1e-3 and agree > 0.999
+
+
+@pytest.mark.parametrize("gain", [2.0, 3.0])
+def test_half_trunk_survives_large_activations(gain):
+    """The default precision keeps activations in IEEE half (|x| <= 65504).  Random-init weights give O(1) activations; a
+    trained checkpoint can be rougher, so every Linear / conv weight of the mini model is scaled by `gain` (pre-LayerNorm
+    sums, MLP hiddens, attention logits and the residual stream grow with it: at x3 the logits are ~370 instead of ~0.4)
+    and the half trunk must stay finite and stay closer to the exact-fp32 path than the bfloat16 trunk does.
+    (At x10 - logits of 1e8 - the 16-bit shadow of the residual stream passes 65504 and SATURATES: finite, but wrong; a
+    checkpoint like that needs precision "bf16+head".  DESIGN.md 2.)"""
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = fixture_cfg(fx), dict(fixture_state_dict(fx))
+    for k in list(sd):
+        v = sd[k]
+        if k.endswith(".weight") and v.dim() >= 2 and "seg_head" not in k:
+            sd[k] = v * gain
+    inp, draws = fixture_input(fx), fixture_draws(fx)
+    ref = run(build(cfg, sd, "fp32", enable_flash=False), inp, draws)
+    half = run(build(cfg, sd, "fp16+head", enable_flash=False), inp, draws)
+    bf = run(build(cfg, sd, "bf16+head", enable_flash=False), inp, draws)
+    assert np.isfinite(ref).all() and np.isfinite(half).all() and np.isfinite(bf).all()
+    scale = float(np.abs(ref).mean())
+    e_half, a_half = report(f"weights x{gain}: fp16+head vs fp32 (mean |logit| {scale:.2f})", half, ref)
+    e_bf, a_bf = report(f"weights x{gain}: bf16+head vs fp32", bf, ref)
+    assert e_half < e_bf and a_half >= a_bf
+    assert e_half < 0.02 * max(1.0, float(np.abs(ref).max()))
