@@ -5,187 +5,257 @@
 //      autograd differentiates here: point_transformer_v3m1_base.py:246-296 (SerializedAttention core),
 //      :399-428 (Block: x += proj(attn); x += fc2(GELU(fc1(LN(x))))).
 //
-// These are the fp32 kernels of the 1e-3 parity mode's backward: straightforward VALU code (one thread per query / per
-// key, K / V / Q tiles through LDS), written to pin the arithmetic and the index plumbing (slot plan, padding
-// duplicates) against the reference's autograd.  The MFMA recompute-P form of attn_bf16_kernel's backward is the next
-// step.
+// These are the fp32 kernels of the 1e-3 parity mode's backward, written to pin the arithmetic and the index plumbing
+// (slot plan, padding duplicates) against the reference's autograd.  The attention core and the weight gradients run on
+// the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); LayerNorm / GELU are row kernels.  The 16-bit recompute-P form of
+// attn_bf16_kernel's backward (what an AMP training step would run) is the next step.
 #include "common.h"
 
 namespace {
 
-constexpr int TB = 64;   // slots per block (one wave)
-constexpr int HD = 16;   // head dim
+constexpr int HD = 16;       // head dim
+constexpr int BW_WAVES = 16;  // waves per block of the attention backward kernels (1 block per CU: the LDS holds K + V or Q + dO)
+constexpr int BW_MAXL = 1024;
 
 struct AttnBwdP {
   const float* q; const float* k; const float* v; const float* dout;
   const int32_t* q_gidx; const int32_t* kv_gidx; const int32_t* widx; const int32_t* patch_start;
   float* dq; float* dk; float* dv;
-  float* stats;  // (slot, head, {m, l, D})
+  float* stats;  // (slot, head, {m (log2 units of the prescaled scores), 1 / l, D})
   int ldq, ldk, ldv, lddo, lddq, lddk, lddv;
   int num_heads;
   float scale;
 };
 
-// block -> (patch, head, tile of 64 slots); grid.x = total tiles (host: prefix over patches), looked up by binary search
-__device__ __forceinline__ bool locate(const int32_t* patch_start, int num_patches, int tile, int& patch, int& t0) {
-  // tiles are laid out patch by patch: tile index -> patch via the cumulative tile counts recomputed on the fly
-  int acc = 0;
-  for (int p = 0; p < num_patches; ++p) {
-    const int L = patch_start[p + 1] - patch_start[p];
-    const int nt = (L + TB - 1) / TB;
-    if (tile < acc + nt) { patch = p; t0 = (tile - acc) * TB; return true; }
-    acc += nt;
-  }
-  return false;
+// The attention backward on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), exact fp32 like the parity mode's forward
+// (attn_f32_kernel).  With s_ij = scale q_i.k_j, P = softmax_j(s), dP_ij = dO_i.v_j, D_i = sum_j P_ij dP_ij,
+// dS = P o (dP - D):   dQ = scale dS K,   dK = scale dS^T Q,   dV = P^T dO.
+// One block = one (patch, head); two kernels, each in the orientation that needs no transposition:
+//   q kernel  (K, V of the patch-head in LDS; a wave owns 16-query tiles): S^T = K Q^T and dP^T = V dO^T come out of the
+//             MFMA with a query per lane column and 4 keys per lane - sweep 1 keeps the running (max, sum, sum P dP) of
+//             the online softmax and leaves (m, 1 / l, D) per query, sweep 2 recomputes them and feeds dS^T STRAIGHT from
+//             the accumulator registers into dQ^T += K^T dS^T (MFMA t takes k-slot kq <-> key 4 kq + t, which is register
+//             t of lane group kq: no permute);
+//   kv kernel (Q', dO and the statistics in LDS; a wave owns 16-key tiles): S = Q' K^T, dP = dO V^T with a key per lane
+//             column, then dV^T += dO^T P and dK^T += Q'^T dS the same way.
+// Q is prescaled by scale * log2(e) so that P = exp2(s' - m'); 20 + 16 MFMAs per 16 x 16 (query, key) tile.
+// LDS rows are 16 floats; the four 16-byte chunks of a row are XOR-swizzled with (row >> 1) & 3 (conflict-free float4
+// operand reads, like attn_f32_kernel's K image).
+__device__ __forceinline__ int bw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
+__device__ __forceinline__ float bw_elem(const char* base, int row, int d) {
+  return *reinterpret_cast<const float*>(base + bw_off(row, d >> 2) + (d & 3) * 4);
 }
 
-// ---- pass over the QUERIES of a tile: softmax statistics, D_i = sum_j P_ij (dO_i . V_j), then dQ_i
-__global__ __launch_bounds__(TB) void attn_bwd_q_kernel(AttnBwdP p, int num_patches) {
-  __shared__ float Ks[TB][HD + 1], Vs[TB][HD + 1];
-  int patch, t0;
-  if (!locate(p.patch_start, num_patches, blockIdx.x, patch, t0)) return;
-  const int head = blockIdx.y;
+__global__ __launch_bounds__(BW_WAVES * 64) void attn_bwd_q_mfma_kernel(AttnBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + BW_MAXL * 64;
+  const int patch = blockIdx.x, head = blockIdx.y;
   const int ps = p.patch_start[patch], L = p.patch_start[patch + 1] - ps;
-  const int lane = threadIdx.x;
-  const int slot = t0 + lane;
-  const bool valid = slot < L;
-  float q[HD], g[HD];
+  const int nt = (L + 15) >> 4, Lp = nt << 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int s = tid; s < Lp; s += BW_WAVES * 64) {
+    float4 kk[4], vv[4];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) { q[d] = 0.f; g[d] = 0.f; }
-  long qrow = -1;
-  if (valid) {
-    qrow = p.q_gidx[ps + slot];
-    const float* qp = p.q + qrow * p.ldq + head * HD;
+    for (int c = 0; c < 4; ++c) kk[c] = vv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < L) {
+      const long r = p.kv_gidx[ps + s];
+      const float4* kp = reinterpret_cast<const float4*>(p.k + r * p.ldk + head * HD);
+      const float4* vp = reinterpret_cast<const float4*>(p.v + r * p.ldv + head * HD);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) q[d] = qp[d] * p.scale;
-    const int w = p.widx[ps + slot];  // the slot's output row; padding duplicates have none: dO = 0
-    if (w >= 0) {
-      const float* gp = p.dout + (long)w * p.lddo + head * HD;
+      for (int c = 0; c < 4; ++c) { kk[c] = kp[c]; vv[c] = vp[c]; }
+    }
 #pragma unroll
-      for (int d = 0; d < HD; ++d) g[d] = gp[d];
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<float4*>(Ks + bw_off(s, c)) = kk[c];
+      *reinterpret_cast<float4*>(Vs + bw_off(s, c)) = vv[c];
     }
   }
-  auto stage = [&](int k0) {
-    __syncthreads();
-    const int ks = k0 + lane;
-    if (ks < L) {
-      const long r = p.kv_gidx[ps + ks];
-      const float* kp = p.k + r * p.ldk + head * HD;
-      const float* vp = p.v + r * p.ldv + head * HD;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) { Ks[lane][d] = kp[d]; Vs[lane][d] = vp[d]; }
-    }
-    __syncthreads();
-  };
-  // pass 1: row max
-  float m = -INFINITY;
-  for (int k0 = 0; k0 < L; k0 += TB) {
-    stage(k0);
-    const int nk = min(TB, L - k0);
-    for (int j = 0; j < nk; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[j][d], s);
-      m = fmaxf(m, s);
-    }
-  }
-  // pass 2: l = sum exp(s - m), Dn = sum exp(s - m) (dO . v)
-  float l = 0.f, dn = 0.f;
-  for (int k0 = 0; k0 < L; k0 += TB) {
-    stage(k0);
-    const int nk = min(TB, L - k0);
-    for (int j = 0; j < nk; ++j) {
-      float s = 0.f, dp = 0.f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) { s = fmaf(q[d], Ks[j][d], s); dp = fmaf(g[d], Vs[j][d], dp); }
-      const float e = expf(s - m);
-      l += e;
-      dn = fmaf(e, dp, dn);
-    }
-  }
-  const float inv_l = 1.0f / l, D = dn * inv_l;
-  if (valid) {
-    float* st = p.stats + ((long)(ps + slot) * p.num_heads + head) * 3;
-    st[0] = m; st[1] = l; st[2] = D;
-  }
-  // pass 3: dQ_i = scale * sum_j P_ij (dP_ij - D_i) K_j
-  float dq[HD];
-#pragma unroll
-  for (int d = 0; d < HD; ++d) dq[d] = 0.f;
-  for (int k0 = 0; k0 < L; k0 += TB) {
-    stage(k0);
-    const int nk = min(TB, L - k0);
-    for (int j = 0; j < nk; ++j) {
-      float s = 0.f, dp = 0.f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) { s = fmaf(q[d], Ks[j][d], s); dp = fmaf(g[d], Vs[j][d], dp); }
-      const float ds = expf(s - m) * inv_l * (dp - D);
-#pragma unroll
-      for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, Ks[j][d], dq[d]);
-    }
-  }
-  if (valid) {
-    float* o = p.dq + qrow * p.lddq + head * HD;  // a point padded into two slots collects both (the gather's backward)
-#pragma unroll
-    for (int d = 0; d < HD; ++d) atomicAdd(o + d, dq[d] * p.scale);
-  }
-}
-
-// ---- pass over the KEYS of a tile: dK_j = scale * sum_i dS_ij Q_i, dV_j = sum_i P_ij dO_i
-__global__ __launch_bounds__(TB) void attn_bwd_kv_kernel(AttnBwdP p, int num_patches) {
-  __shared__ float Qs[TB][HD + 1], Gs[TB][HD + 1], Ss[TB][4];
-  int patch, t0;
-  if (!locate(p.patch_start, num_patches, blockIdx.x, patch, t0)) return;
-  const int head = blockIdx.y;
-  const int ps = p.patch_start[patch], L = p.patch_start[patch + 1] - ps;
-  const int lane = threadIdx.x;
-  const int slot = t0 + lane;
-  const bool valid = slot < L;
-  float k[HD], v[HD], dk[HD], dv[HD];
-  long krow = -1;
-#pragma unroll
-  for (int d = 0; d < HD; ++d) { k[d] = v[d] = dk[d] = dv[d] = 0.f; }
-  if (valid) {
-    krow = p.kv_gidx[ps + slot];
-    const float* kp = p.k + krow * p.ldk + head * HD;
-    const float* vp = p.v + krow * p.ldv + head * HD;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) { k[d] = kp[d]; v[d] = vp[d]; }
-  }
-  for (int q0 = 0; q0 < L; q0 += TB) {
-    __syncthreads();
-    const int qs = q0 + lane;
-    if (qs < L) {
-      const long r = p.q_gidx[ps + qs];
-      const float* qp = p.q + r * p.ldq + head * HD;
-      const int w = p.widx[ps + qs];
-#pragma unroll
-      for (int d = 0; d < HD; ++d) {
-        Qs[lane][d] = qp[d] * p.scale;
-        Gs[lane][d] = w >= 0 ? p.dout[(long)w * p.lddo + head * HD + d] : 0.f;
+  __syncthreads();
+  const int ql = lane & 15, g = lane >> 4;
+  const float c2 = p.scale * 1.44269504088896340736f;
+  for (int qt = wave; qt < nt; qt += BW_WAVES) {
+    const int qslot = qt * 16 + ql;
+    const bool valid = qslot < L;
+    long qrow = 0;
+    float qf[4] = {0.f, 0.f, 0.f, 0.f}, gf[4] = {0.f, 0.f, 0.f, 0.f};  // B operands: (query ql, head dims 4 g .. 4 g + 3)
+    if (valid) {
+      qrow = p.q_gidx[ps + qslot];
+      const float4 t = *reinterpret_cast<const float4*>(p.q + qrow * p.ldq + head * HD + 4 * g);
+      qf[0] = t.x * c2; qf[1] = t.y * c2; qf[2] = t.z * c2; qf[3] = t.w * c2;
+      const int w = p.widx[ps + qslot];  // the slot's output row; padding duplicates have none: dO = 0
+      if (w >= 0) {
+        const float4 u = *reinterpret_cast<const float4*>(p.dout + (long)w * p.lddo + head * HD + 4 * g);
+        gf[0] = u.x; gf[1] = u.y; gf[2] = u.z; gf[3] = u.w;
       }
-      const float* st = p.stats + ((long)(ps + qs) * p.num_heads + head) * 3;
-      Ss[lane][0] = st[0]; Ss[lane][1] = 1.0f / st[1]; Ss[lane][2] = st[2];
     }
-    __syncthreads();
-    const int nq = min(TB, L - q0);
-    for (int i = 0; i < nq; ++i) {
-      float s = 0.f, dp = 0.f;
+    auto tile = [&](int kt, f32x4_t& sc, f32x4_t& dp) {  // S'^T and dP^T of key tile kt: rows = keys 4 g + r, column = query ql
+      const int key = kt * 16 + ql;
+      const float4 kf = *reinterpret_cast<const float4*>(Ks + bw_off(key, g));
+      const float4 vf = *reinterpret_cast<const float4*>(Vs + bw_off(key, g));
+      const float ka[4] = {kf.x, kf.y, kf.z, kf.w}, va[4] = {vf.x, vf.y, vf.z, vf.w};
+      sc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int d = 0; d < HD; ++d) { s = fmaf(Qs[i][d], k[d], s); dp = fmaf(Gs[i][d], v[d], dp); }
-      const float pij = expf(s - Ss[i][0]) * Ss[i][1];
-      const float ds = pij * (dp - Ss[i][2]);
+      for (int t = 0; t < 4; ++t) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], qf[t], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va[t], gf[t], dp, 0, 0, 0);
+      }
 #pragma unroll
-      for (int d = 0; d < HD; ++d) { dk[d] = fmaf(ds, Qs[i][d], dk[d]); dv[d] = fmaf(pij, Gs[i][d], dv[d]); }
+      for (int r = 0; r < 4; ++r)
+        if (kt * 16 + 4 * g + r >= L) sc[r] = -INFINITY;
+    };
+    // ---- sweep 1: online (m, l, sum e dP) over the lane's keys, then across the four lane groups of the query
+    float m = -INFINITY, l = 0.f, dn = 0.f;
+    for (int kt = 0; kt < nt; ++kt) {
+      f32x4_t sc, dp;
+      tile(kt, sc, dp);
+      const float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+      const float mn = fmaxf(m, mt);
+      if (mn > -INFINITY) {
+        const float a = exp2f(m - mn);
+        l *= a; dn *= a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(sc[r] - mn);
+          l += e;
+          dn = fmaf(e, dp[r], dn);
+        }
+        m = mn;
+      }
     }
-  }
-  if (valid) {
-    float* ok = p.dk + krow * p.lddk + head * HD;
-    float* ov = p.dv + krow * p.lddv + head * HD;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { atomicAdd(ok + d, dk[d]); atomicAdd(ov + d, dv[d]); }  // Qs carries the scale already
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64), d2 = __shfl_xor(dn, off, 64);
+      const float mn = fmaxf(m, m2);
+      if (mn > -INFINITY) {
+        const float a = exp2f(m - mn), b = exp2f(m2 - mn);
+        l = l * a + l2 * b;
+        dn = dn * a + d2 * b;
+      }
+      m = mn;
+    }
+    const float il = 1.0f / l, D = dn * il;
+    if (valid && g == 0) {
+      float* st = p.stats + ((long)(ps + qslot) * p.num_heads + head) * 3;
+      st[0] = m; st[1] = il; st[2] = D;
+    }
+    // ---- sweep 2: dQ^T (rows = head dims 4 g + r, column = query ql) += K^T dS^T
+    f32x4_t dq = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nt; ++kt) {
+      f32x4_t sc, dp;
+      tile(kt, sc, dp);
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[r] = exp2f(sc[r] - m) * il * (dp[r] - D);  // (masked keys: exp2(-inf) = 0)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)  // k-slot g of MFMA t <-> key 4 g + t: A = K[key][head dim ql], B = register t
+        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(bw_elem(Ks, kt * 16 + 4 * g + t, ql), ds[t], dq, 0, 0, 0);
+    }
+    if (valid) {
+      float* o = p.dq + qrow * p.lddq + head * HD + 4 * g;  // a point padded into two slots collects both
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(o + r, dq[r] * p.scale);
+    }
   }
 }
+
+__global__ __launch_bounds__(BW_WAVES * 64) void attn_bwd_kv_mfma_kernel(AttnBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;                                                     // Q' = Q * scale * log2(e)
+  char* Gs = smem + BW_MAXL * 64;                                      // dO
+  float* sm = reinterpret_cast<float*>(smem + 2 * BW_MAXL * 64);       // m
+  float* sil = sm + BW_MAXL;                                           // 1 / l
+  float* sD = sil + BW_MAXL;                                           // D
+  const int patch = blockIdx.x, head = blockIdx.y;
+  const int ps = p.patch_start[patch], L = p.patch_start[patch + 1] - ps;
+  const int nt = (L + 15) >> 4, Lp = nt << 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float c2 = p.scale * 1.44269504088896340736f;
+  for (int s = tid; s < Lp; s += BW_WAVES * 64) {
+    float4 qq[4], gg[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qq[c] = gg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = INFINITY, il = 0.f, D = 0.f;  // slots past the end: P = exp2(0 - inf) = 0
+    if (s < L) {
+      const long r = p.q_gidx[ps + s];
+      const float4* qp = reinterpret_cast<const float4*>(p.q + r * p.ldq + head * HD);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = qp[c];
+        qq[c] = make_float4(t.x * c2, t.y * c2, t.z * c2, t.w * c2);
+      }
+      const int w = p.widx[ps + s];
+      if (w >= 0) {
+        const float4* gp = reinterpret_cast<const float4*>(p.dout + (long)w * p.lddo + head * HD);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gg[c] = gp[c];
+      }
+      const float* st = p.stats + ((long)(ps + s) * p.num_heads + head) * 3;
+      m = st[0]; il = st[1]; D = st[2];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<float4*>(Qs + bw_off(s, c)) = qq[c];
+      *reinterpret_cast<float4*>(Gs + bw_off(s, c)) = gg[c];
+    }
+    sm[s] = m; sil[s] = il; sD[s] = D;
+  }
+  __syncthreads();
+  const int kl = lane & 15, g = lane >> 4;
+  for (int kt = wave; kt < nt; kt += BW_WAVES) {
+    const int kslot = kt * 16 + kl;
+    const bool valid = kslot < L;
+    long krow = 0;
+    float kf[4] = {0.f, 0.f, 0.f, 0.f}, vf[4] = {0.f, 0.f, 0.f, 0.f};  // B operands: (key kl, head dims 4 g .. 4 g + 3)
+    if (valid) {
+      krow = p.kv_gidx[ps + kslot];
+      const float4 a = *reinterpret_cast<const float4*>(p.k + krow * p.ldk + head * HD + 4 * g);
+      const float4 b = *reinterpret_cast<const float4*>(p.v + krow * p.ldv + head * HD + 4 * g);
+      kf[0] = a.x; kf[1] = a.y; kf[2] = a.z; kf[3] = a.w;
+      vf[0] = b.x; vf[1] = b.y; vf[2] = b.z; vf[3] = b.w;
+    }
+    f32x4_t dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};  // rows = head dims 4 g + r, column = key kl
+    for (int qt = 0; qt < nt; ++qt) {
+      const int qrow = qt * 16 + kl;  // A operand row = query qt * 16 + (lane & 15)
+      const float4 qa4 = *reinterpret_cast<const float4*>(Qs + bw_off(qrow, g));
+      const float4 ga4 = *reinterpret_cast<const float4*>(Gs + bw_off(qrow, g));
+      const float qa[4] = {qa4.x, qa4.y, qa4.z, qa4.w}, ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
+      f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};  // rows = queries 4 g + r, column = key kl
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[t], kf[t], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[t], vf[t], dp, 0, 0, 0);
+      }
+      const float4 m4 = *reinterpret_cast<const float4*>(sm + qt * 16 + 4 * g);
+      const float4 i4 = *reinterpret_cast<const float4*>(sil + qt * 16 + 4 * g);
+      const float4 D4 = *reinterpret_cast<const float4*>(sD + qt * 16 + 4 * g);
+      const float ms[4] = {m4.x, m4.y, m4.z, m4.w}, is[4] = {i4.x, i4.y, i4.z, i4.w}, Ds[4] = {D4.x, D4.y, D4.z, D4.w};
+      float pr[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = exp2f(sc[r] - ms[r]) * is[r];
+        ds[r] = pr[r] * (dp[r] - Ds[r]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // k-slot g of MFMA t <-> query 4 g + t: A = dO / Q' [query][head dim kl], B = register t
+        const int qq = qt * 16 + 4 * g + t;
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(bw_elem(Gs, qq, kl), pr[t], dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(bw_elem(Qs, qq, kl), ds[t], dk, 0, 0, 0);
+      }
+    }
+    if (valid) {
+      float* ok = p.dk + krow * p.lddk + head * HD + 4 * g;
+      float* ov = p.dv + krow * p.lddv + head * HD + 4 * g;
+      const float ln2 = 0.69314718055994530942f;  // Q' carries scale * log2(e): dK = scale dS^T Q = ln 2 dS^T Q'
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { atomicAdd(ok + r, dk[r] * ln2); atomicAdd(ov + r, dv[r]); }
+    }
+  }
+}
+
+constexpr int BW_Q_LDS = 2 * BW_MAXL * 64;
+constexpr int BW_KV_LDS = 2 * BW_MAXL * 64 + 3 * BW_MAXL * 4;
 
 // ---- LayerNorm backward: dx = (1/sigma) (dyg - mean(dyg) - xhat mean(dyg xhat)), dyg = dy * gamma; one wave per row
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
@@ -315,9 +385,17 @@ extern "C" int cdseg_attention_bwd(const void* q, const void* k, const void* v, 
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.num_heads = num_heads; p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)num_tiles, (unsigned)num_heads);
-  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(TB), 0, s, p, num_patches);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(TB), 0, s, p, num_patches);
+  (void)num_tiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BW_Q_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BW_KV_LDS) != hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid((unsigned)num_patches, (unsigned)num_heads);
+  hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, grid, dim3(BW_WAVES * 64), BW_Q_LDS, s, p);
+  hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, grid, dim3(BW_WAVES * 64), BW_KV_LDS, s, p);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }
