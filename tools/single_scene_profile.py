@@ -4,6 +4,9 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.getcwd())
+from cdsegnet_amd import _lib
+if os.environ.get("CDSEG_AB_LIB"):  # A/B runs against an experimental bfloat16 build (tools only): implies bf16+head
+    _lib.LIB_PATH = os.path.abspath(os.environ["CDSEG_AB_LIB"])
 from cdsegnet_amd import configs, synth
 from cdsegnet_amd.param_init import fill_state_dict
 from cdsegnet_amd.registry import build_model
@@ -13,6 +16,8 @@ model = build_model(cfg)
 model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
 model = model.cuda().eval()
 model.noise_source = "device"  # (precision: the default, fp16+head)
+if os.environ.get("CDSEG_AB_LIB"):
+    model.precision = "bf16+head"
 sc = synth.room_scene(0, 120000)
 inp = {k: torch.as_tensor(sc[k]).cuda() for k in ("coord", "grid_coord", "feat", "offset")}
 inp["offset_host"] = [int(v) for v in sc["offset"]]
