@@ -936,6 +936,11 @@ def attention_bwd(q, k, v, q_gidx, kv_gidx, widx, patch_start, patch_start_host,
     ps = [int(x) for x in patch_start_host]
     num_patches = len(ps) - 1
     tiles = sum((ps[i + 1] - ps[i] + 63) // 64 for i in range(num_patches))
+    if num_patches and max(ps[i + 1] - ps[i] for i in range(num_patches)) > 1024:
+        raise _lib.CdsegError("attention_bwd: a patch holds at most 1024 slots (the patch-head lives in LDS, like the forward)")
+    for t, ld in ((q, q.stride(0)), (k, k.stride(0)), (v, v.stride(0)), (dout, dout.stride(0))):
+        if ld % 4 or t.data_ptr() % 16:
+            raise _lib.CdsegError("attention_bwd: rows must be 16-byte aligned (float4 operand loads)")
     lib = _lib.load()
     ws = torch.empty(max(1, lib.cdseg_attention_bwd_ws_bytes(ps[-1], int(num_heads))), dtype=torch.uint8, device=q.device)
     check(lib.cdseg_attention_bwd(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),

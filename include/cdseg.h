@@ -422,7 +422,8 @@ int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, 
  *   dv are ACCUMULATED into (+=, the caller zeroes them) at the gathered rows - a point that the padding plan put into
  *   two slots collects both (the backward of the reference's `qkv[order]` gather); slots without an output row (widx -1)
  *   receive no output gradient but still act as keys.  num_slots = patch_start[num_patches]; num_tiles = sum over patches
- *   of ceil(L / 64).  ws: cdseg_attention_bwd_ws_bytes.  dtype: CDSEG_F32 only so far.
+ *   of ceil(L / 64) (unused since the MFMA form).  L <= 1024 per patch (the patch-head lives in LDS), 16-byte aligned rows.
+ *   ws: cdseg_attention_bwd_ws_bytes.  dtype: CDSEG_F32 only so far.
  * cdseg_layernorm_bwd: dx (=, or += when accumulate) for y = LayerNorm(x) * gamma + beta; optional dgamma / dbeta (+=).
  * cdseg_gelu_bwd: dx = dy * d/du GELU(u) on the pre-activation u (erf form, torch.nn.GELU()).
  * cdseg_linear_wgrad: dw[n][k] += sum_m dy[m][n] * x[row(m)][k] and (db != NULL) db[n] += sum_m dy[m][n], fp32; row(m) = m,
