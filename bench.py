@@ -80,6 +80,9 @@ def parse():
                          "scenes-per-forward x lanes scenes (one batch per lane)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="independent forwards in flight per GPU (HIP streams); 1 = strictly one forward at a time")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling aid: no side-stream fork inside a forward (with --lanes 1 no two kernels ever overlap, so a "
+                         "rocprofv3 --kernel-trace of the run shows each kernel's own duration)")
     ap.add_argument("--shard", type=int, default=0, metavar="S",
                     help="strong-scaling mode (BASELINE config 4's shape: --dataset nuscenes --points 40000 --shard 64): ONE "
                          "global list of S mixed-size scenes, LPT-sharded over the ranks (cdsegnet_amd.dist.shard_scenes), "
@@ -403,6 +406,8 @@ def main():
         return out
 
     timer = not args.no_kernel_timer
+    if args.serial:
+        model.engine().fork_stage = None
     out = None
     if args.warmup:
         out = run(args.warmup)
@@ -422,8 +427,10 @@ def main():
 
     # ---- kernel-level pass (rank 0): the SAME forward the timed region issues (first lane's 8 collated scenes), one
     # forward at a time, HIP events around every attention / sparse-conv launch on the launch stream.  Inside the timed
-    # region three forwards share the CUs, so a launch's wall time there is not a property of the kernel; rocprofv3
-    # --kernel-trace serialises the streams the same way (profiles/).
+    # region three forwards share the CUs, so a launch's wall time there is not a property of the kernel (and the
+    # rocprofv3 --kernel-trace profile of the default run overlaps the lanes as well: profiles/r03_bench_kernel_stats.txt is for
+    # the SHARES; the trace of a one-lane run, profiles/r03_bench_lanes1_kernel_stats.txt, is the one whose average
+    # durations this pass has to agree with).
     iso = None
     eng = model.engine()
     if timer and rank == 0:
