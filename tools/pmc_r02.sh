@@ -29,7 +29,7 @@ for k, d in acc.items():
     for c, v in d.items():
         print(f"{name} | {k} | {c} | per launch {v / cnt[(k, c)]:.0f} | launches {cnt[(k, c)]}")
 PY
-  grep -h "conv level\|attention\[" /tmp/pmc_$name.log | tail -2 >> $out
+  grep -h "conv level\|attention\[\|stem5 n=" /tmp/pmc_$name.log | tail -2 >> $out
 }
 CMD=("$@")
 run ${tag}A "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES"
