@@ -117,7 +117,41 @@ void k(unsigned long long* out, float* sink, int qtiles, float seed) {
     f32x16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;
     const char* kp = k_lane;
     unsigned va = va0;
-    if (VAR & 32) {
+    if (VAR & 1024) {
+      // software-pipelined AND interleaved: the QK MFMA of tile t + 1 is issued first, then tile t's exps and packs in two
+      // halves with one PV MFMA after each half - in program order no MFMA waits for a VALU result that is not already
+      // there, and every MFMA has ~12 VALU instructions behind it to cover its 32 pipe cycles
+      // (two tiles per trip with the score registers swapping roles: no register copies)
+      auto half = [&](const f32x16_t& sc, int mf, unsigned vaddr) {
+        float pr[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pr[r] = __builtin_amdgcn_exp2f(sc[8 * mf + r]);
+        union { bf16x8_t v; uint32_t u[4]; } pf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16x2(pr[2 * j], pr[2 * j + 1]);
+        const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(vaddr + 512 * mf));
+        const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(vaddr + 512 * mf + 256));
+        const bf16x8_t vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two V^T reads
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  // 8 exps + 4 packs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // PV
+      };
+      f32x16_t sA = qk<VAR>(kp, qf, negm, cv), sB;
+      for (int kt = 0; kt < 32; kt += 2) {
+        sB = qk<VAR>(kp + 1024, qf, negm, cv);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        half(sA, 0, va);
+        half(sA, 1, va);
+        sA = qk<VAR>(kp + (kt < 30 ? 2048 : 0), qf, negm, cv);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        half(sB, 0, va + vstep);
+        half(sB, 1, va + vstep);
+        kp += 2048; va += 2 * vstep;
+      }
+    } else if (VAR & 32) {
       int kt = 0;
       for (; kt + 2 < 32; kt += 3) {
         const f32x16_t sa = qk<VAR>(kp, qf, negm, cv), sb = qk<VAR>(kp + 1024, qf, negm, cv), sc = qk<VAR>(kp + 2048, qf, negm, cv);
@@ -194,6 +228,8 @@ int main() {
   run<0, 768, 2, true>("2 tiles in flight, 12 waves x 2 blocks (80 VGPRs), dynamic");
   run<64, 1024, 2, true>("1 tile in flight, 16 waves x 2 blocks (64 VGPRs), dynamic");
   run<32, 512, 2, true>("3 tiles in flight, 8 waves x 2 blocks, dynamic");
+  run<1024, 512, 2, true>("software-pipelined + interleaved (1 tile + prefetch), 8 x 2, dynamic");
+  run<1024, 768, 2, true>("software-pipelined + interleaved, 12 waves x 2 blocks, dynamic");
   run<256, 512, 2, true>("2 tiles in flight, one PV accumulator per tile, 8 x 2, dynamic");
   run<512, 512, 2, true>("2 tiles in flight, one PV accumulator per MFMA of a tile, 8 x 2, dynamic");
   run<0, 512, 2, true>("2 tiles in flight, 8 waves x 2 blocks, dynamic (again)");
