@@ -79,6 +79,54 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters, flo
       for (int r = 0; r < 2; ++r) { CVTP(0); CVTP(1); CVTP(2); CVTP(3); CVTP(4); CVTP(5); CVTP(6); CVTP(7); }
       MFMA(acc2); MFMA(acc0); MFMA(acc1); MFMA(acc2);
     }
+    if (KIND == 22) {  // KIND 19 with the real data dependences: exps read the FIRST MFMA's result, the other two MFMAs' B operand is the packs
+#define EXPD(i) asm volatile("v_exp_f32 %0, %1" : "=v"(e[i]) : "v"(acc0[i]))
+      union { bf16x8_t v; unsigned u[4]; } pb0, pb1;
+      MFMA(acc0);
+      EXPD(0); EXPD(1); EXPD(2); EXPD(3); EXPD(4); EXPD(5); EXPD(6); EXPD(7); CVTP(0); CVTP(1); CVTP(2); CVTP(3);
+      pb0.u[0] = p[0]; pb0.u[1] = p[1]; pb0.u[2] = p[2]; pb0.u[3] = p[3];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(pb0.v));
+      EXPD(8); EXPD(9); EXPD(10); EXPD(11); EXPD(12); EXPD(13); EXPD(14); EXPD(15); CVTP(4); CVTP(5); CVTP(6); CVTP(7);
+      pb1.u[0] = p[4]; pb1.u[1] = p[5]; pb1.u[2] = p[6]; pb1.u[3] = p[7];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(pb1.v));
+    }
+    if (KIND == 25) {  // TWO tiles with their real dependences in the order the compiler emits the key loop: grouped
+      union { bf16x8_t v; unsigned u[4]; } pb0, pb1;
+      float e2[16];
+      unsigned p2[8];
+#define EXPD2(i) asm volatile("v_exp_f32 %0, %1" : "=v"(e2[i]) : "v"(acc2[i]))
+#define CVTP2(i) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p2[i]) : "v"(e2[2 * (i)]), "v"(e2[2 * (i) + 1]))
+      MFMA(acc0); MFMA(acc2);  // the two QK products
+      EXPD(0); EXPD(1); EXPD(2); EXPD(3); EXPD(4); EXPD(5); EXPD(6); EXPD(7); EXPD(8); EXPD(9); EXPD(10); EXPD(11); EXPD(12); EXPD(13); EXPD(14); EXPD(15);
+      EXPD2(0); EXPD2(1); EXPD2(2); EXPD2(3); EXPD2(4); EXPD2(5); EXPD2(6); EXPD2(7); EXPD2(8); EXPD2(9); EXPD2(10); EXPD2(11); EXPD2(12); EXPD2(13); EXPD2(14); EXPD2(15);
+      CVTP(0); CVTP(1); CVTP(2); CVTP(3); CVTP(4); CVTP(5); CVTP(6); CVTP(7);
+      CVTP2(0); CVTP2(1); CVTP2(2); CVTP2(3); CVTP2(4); CVTP2(5); CVTP2(6); CVTP2(7);
+      pb0.u[0] = p[0]; pb0.u[1] = p[1]; pb0.u[2] = p[2]; pb0.u[3] = p[3];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(pb0.v));
+      pb1.u[0] = p[4]; pb1.u[1] = p[5]; pb1.u[2] = p[6]; pb1.u[3] = p[7];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(pb1.v));
+      pb0.u[0] = p2[0]; pb0.u[1] = p2[1]; pb0.u[2] = p2[2]; pb0.u[3] = p2[3];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(pb0.v));
+      pb1.u[0] = p2[4]; pb1.u[1] = p2[5]; pb1.u[2] = p2[6]; pb1.u[3] = p2[7];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(pb1.v));
+    }
+    if (KIND == 23) {  // only the MFMA -> exp dependence
+      MFMA(acc0);
+      EXPD(0); EXPD(1); EXPD(2); EXPD(3); EXPD(4); EXPD(5); EXPD(6); EXPD(7); CVTP(0); CVTP(1); CVTP(2); CVTP(3);
+      MFMA(acc1);
+      EXPD(8); EXPD(9); EXPD(10); EXPD(11); EXPD(12); EXPD(13); EXPD(14); EXPD(15); CVTP(4); CVTP(5); CVTP(6); CVTP(7);
+      MFMA(acc2);
+    }
+    if (KIND == 24) {  // only the pack -> MFMA dependence
+      union { bf16x8_t v; unsigned u[4]; } pb0, pb1;
+      MFMA(acc0);
+      EXP(0); EXP(1); EXP(2); EXP(3); EXP(4); EXP(5); EXP(6); EXP(7); CVTP(0); CVTP(1); CVTP(2); CVTP(3);
+      pb0.u[0] = p[0]; pb0.u[1] = p[1]; pb0.u[2] = p[2]; pb0.u[3] = p[3];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(pb0.v));
+      EXP(8); EXP(9); EXP(10); EXP(11); EXP(12); EXP(13); EXP(14); EXP(15); CVTP(4); CVTP(5); CVTP(6); CVTP(7);
+      pb1.u[0] = p[4]; pb1.u[1] = p[5]; pb1.u[2] = p[6]; pb1.u[3] = p[7];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(pb1.v));
+    }
     if (KIND == 7) {  // 10 exps on the transcendental unit, 6 scores by a 7-op polynomial on the plain VALU
 #define P7(i) FMA(i); FMA((i + 1) & 15); FMA((i + 2) & 15); FMA((i + 3) & 15); FMA((i + 4) & 15); FMA((i + 5) & 15); FMA((i + 6) & 15)
       MFMA(acc0); EXP(0); P7(0); EXP(1); P7(1); EXP(2); EXP(3); PERM(0); PERM(1);
@@ -202,6 +250,10 @@ int main() {
   run<6>("3 mfma + 16 exp + 8 perm (round-2 tile)");
   run<19>("3 mfma + 16 exp + 8 cvt_pk (round-3 tile)");
   run<20>("the same, MFMAs back to back, then exps, then packs");
+  run<22>("round-3 tile with its REAL dependences (MFMA -> exp -> pack -> MFMA)");
+  run<25>("  TWO tiles, real dependences, GROUPED like the compiled key loop (per two tiles)");
+  run<23>("  only MFMA -> exp");
+  run<24>("  only pack -> MFMA");
   run<21>("two tiles grouped like the real loop (per TWO tiles)");
   run<8>("3 mfma + 64 fma");
   run<7>("3 mfma + 10 exp + 42 fma + 8 perm (hybrid)");
