@@ -19,7 +19,9 @@
 //    costs ONE v_exp_f32.  Query tiles whose bound is too loose (> 2^60) are redone with the exact row max;
 //  * the kernel is bound by the VALU / transcendental issue, not by the matrix pipe: 16 v_exp_f32 + 8
 //    v_cvt_pk_bf16_f32 per 32x32 score tile against 3 MFMAs of 32 cycles (tools/ubench/pipes.hip,
-//    profiles/r03_ubench_pipes.txt: 128 cycles per tile and SIMD at 4 waves per SIMD = half the MFMA-only rate);
+//    profiles/r03_ubench_pipes.txt: 128 cycles per tile and SIMD at 4 waves per SIMD = half the MFMA-only rate - and with
+//    both pipes busy the chip holds only ~1.5 GHz: 82-87 ns per tile in wall time, with or without the real data
+//    dependences, interleaved or grouped; the key loop alone runs at 91 ns, the whole kernel at 134-145 ns);
 //  * bf16: v_mfma_f32_32x32x16_bf16 for both products; the MFMA k-slot <-> key assignment of
 //    the PV product is chosen so the exponentiated scores feed it straight from the
 //    accumulator registers (no permute); the matching V^T operand is two ds_read_b64_tr_b16 of the row-major V;
