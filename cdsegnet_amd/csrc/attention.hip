@@ -588,7 +588,9 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
   const int tile = dtype == CDSEG_F32 ? 16 : 32;
   const int nqt = (max_len + tile - 1) / tile;
   const int ph = num_patches * num_heads;
-  int qsplit = ph >= 384 ? 1 : (ph >= 160 ? 2 : 4);
+  // (sweep at the end of round 3, tools/bench_attention.py: 202 and 224 patch-heads run 2 - 6 % faster unsplit than in two
+  // slices; 112 and fewer want 2 - 4 slices)
+  int qsplit = ph >= 192 ? 1 : (ph >= 96 ? 2 : 4);
   qsplit = cdseg_knob("CDSEG_ATTN_QSPLIT", qsplit);  // (power of two)
   const int max_split = (nqt + ATTN_WAVES - 1) / ATTN_WAVES;
   while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
