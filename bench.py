@@ -379,7 +379,7 @@ def main():
     low = args.precision != "fp32"
     variant = "f16" if args.precision.startswith("fp16") else "bf16"  # which build of the library this run calls
     T = ops.LP_DTYPES[variant] if low else torch.float32
-    _lib.use(variant).__enter__()  # this thread's direct op calls (kernel timer) go to the engine's build
+    _lib.activate(variant)  # this thread's direct op calls (kernel timer) go to the engine's build
     if world > 1:  # weights: one RCCL broadcast from rank 0 in the compute dtype (replaces the DDP-ctor broadcast)
         cdist.broadcast_model(model, src=0, weight_dtype=T if T != torch.float32 else None)
     model.precision = args.precision

@@ -191,6 +191,13 @@ class use:
         return False
 
 
+def activate(variant):
+    """Make `variant` the calling thread's build from here on (a process that runs one precision throughout, e.g. bench.py)."""
+    if variant not in VARIANTS:
+        raise ValueError(variant)
+    _tls.variant = variant
+
+
 def load(variant=None):
     """Load the HIP library (the calling thread's active build); raises CdsegError (never falls back) if it is absent."""
     v = variant or active()
