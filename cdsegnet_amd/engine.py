@@ -157,6 +157,27 @@ class State:
         self.parent = None
 
 
+class _HeadsInFp32:
+    """What `Engine._eng` hands out for the seg heads of a 16-bit engine with precision "*+head": the heads' weights in fp32
+    and the dtype hand-over (`_fit`) - not a second copy of all 101 M parameters."""
+    T = torch.float32
+
+    def __init__(self, eng):
+        bb, self.device, self.w = eng.model.backbone, eng.device, {}
+        for name in ("n_head", "c_head"):
+            mod = getattr(bb, "_" + name, None)
+            if isinstance(mod, torch.nn.Linear):
+                self.w[name + ".w"] = mod.weight.detach().to(device=eng.device, dtype=torch.float32).contiguous()
+                self.w[name + ".b"] = (mod.bias.detach().to(device=eng.device, dtype=torch.float32).contiguous()
+                                       if mod.bias is not None else None)
+
+    def prepare(self, device):
+        assert device == self.device
+
+    def _fit(self, st, exact=False):
+        return Engine._fit(self, st, exact)
+
+
 class Engine:
     PRECISIONS = ("bf16", "bf16+head", "fp16", "fp16+head", "fp32")
 
@@ -369,9 +390,13 @@ class Engine:
         """The engine that runs stage `key`: this one, or its exact-fp32 twin for the stages named in self.hi."""
         if key not in self.hi or self.T == torch.float32:
             return self
-        if self._twin is None:
-            self._twin = Engine(self.model, "fp32", variant=self.variant)
-            self._twin.use_native_blocks = self.use_native_blocks
+        heads_only = self.hi <= {"n_head", "c_head"}  # precision "*+head": the heads' weights are all that is needed in fp32
+        if self._twin is None or isinstance(self._twin, _HeadsInFp32) != heads_only or self._twin.device != self.device:
+            if heads_only:
+                self._twin = _HeadsInFp32(self)
+            else:
+                self._twin = Engine(self.model, "fp32", variant=self.variant)
+                self._twin.use_native_blocks = self.use_native_blocks
         self._twin.prepare(self.device)
         return self._twin
 
