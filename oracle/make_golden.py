@@ -517,6 +517,103 @@ def gen_train(ref):
           "|d_qkv|", float(np.abs(fx["d_qkv"]).mean()))
 
 
+def gen_train_step(ref):
+    """The reference's TRAINING forward (default.py:424-493: per-scene timestep, q_sample, both decoders, train-mode
+    BatchNorm, DropPath) with the shipped criteria (MSE + CrossEntropy + Lovasz under the GLS combination) on a batch of
+    two scenes of the mini model, and loss.backward() (engines/train.py:216-271).  Recorded: every random draw in
+    consumption order (timesteps, noise, order shuffles, DropPath masks per module), the loss and its parts, both
+    predictions, d loss / d prediction, the L2 norm of EVERY parameter gradient and a few gradients in full."""
+    from cdsegnet_amd import synth as _synth
+    cfg = configs.mini_config()
+    cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+                       dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
+                       dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
+    import pointcept.models.losses  # noqa: F401  (registers the criteria)
+    model, sd = ref_model(ref, cfg, seed=21)
+    model.train()
+    path = os.path.join(OUT, "train_step_mini.npz")
+    if os.path.exists(path) and not REGEN_INPUTS:
+        with np.load(path, allow_pickle=False) as f:
+            scene = {k: f[k] for k in ("coord", "grid_coord", "feat", "offset", "segment")}
+    else:
+        scene = _synth.collate([_synth.room_scene(71, 900), _synth.room_scene(72, 700)])
+        seg = np.asarray(scene["segment"]).astype(np.int64) % cfg["num_classes"]
+        seg[::17] = -1  # some unlabelled points (ignore_index)
+        scene = dict(coord=scene["coord"], grid_coord=scene["grid_coord"], feat=scene["feat"], offset=scene["offset"], segment=seg)
+    inp = to_torch_input(scene)
+    inp["segment"] = torch.from_numpy(np.asarray(scene["segment"]).astype(np.int64))
+    # DropPath masks by module: the stand-in draws `bernoulli_(keep)` then divides by keep
+    masks, cur = {}, [None]
+    real_bernoulli = torch.Tensor.bernoulli_
+    for name, mod in model.named_modules():
+        if type(mod).__name__ == "DropPath" and mod.drop_prob > 0.0:
+            mod.register_forward_pre_hook(lambda m, a, name=name: cur.__setitem__(0, (name, 1.0 - m.drop_prob)))
+
+    def bernoulli_(self, *a, **k):
+        r = real_bernoulli(self, *a, **k)
+        name, keep = cur[0]
+        masks.setdefault(name, []).append((r / keep).clone().numpy())
+        return r
+
+    real_randint = torch.randint
+    ts_log = []
+
+    def randint(*a, **k):
+        r = real_randint(*a, **k)
+        ts_log.append(r.clone())
+        return r
+
+    caps = {}
+    torch.manual_seed(123)
+    torch.Tensor.bernoulli_ = bernoulli_
+    torch.randint = randint
+    try:
+        with DrawRecorder() as rec:
+            hooks = [model.backbone._n_head.register_forward_hook(lambda m, a, o: (o.retain_grad(), caps.__setitem__("n_pred", o))[1]),
+                     model.backbone._c_head.register_forward_hook(lambda m, a, o: (o.retain_grad(), caps.__setitem__("c_pred", o))[1])]
+            crit = model.criteria
+            parts = []
+            real_call = type(crit).__call__
+            for c in crit.criteria:
+                c.register_forward_hook(lambda m, a, o: parts.append(float(o)))
+            out = model(inp)
+            loss = out["loss"]
+            loss.backward()
+            for h in hooks:
+                h.remove()
+    finally:
+        torch.Tensor.bernoulli_ = real_bernoulli
+        torch.randint = real_randint
+    normals = [t for k, t in rec.log if k == "normal"]
+    perms = [t for k, t in rec.log if k == "randperm"]
+    assert len(ts_log) == 1 and len(normals) == 1 and len(perms) == 8, (len(ts_log), len(normals), len(perms))
+    names = [k for k, _ in model.named_parameters()]
+    gnorm = np.array([float(p_.grad.norm()) if p_.grad is not None else -1.0 for _, p_ in model.named_parameters()], dtype=np.float64)
+    full = ["backbone._n_head.weight", "backbone._c_head.weight", "backbone._n_embedding.stem.conv.weight",
+            "backbone._n_enc.enc2.block0.attn.qkv.weight", "backbone._n_enc.enc1.down.norm.0.weight", "backbone.fc_t1.weight",
+            "backbone._tm_dec0.cross_block2.attn.kv.weight", "backbone._n_dec.dec0.up.proj.0.weight"]
+    pd = dict(model.named_parameters())
+    fx = dict(coord=scene["coord"], grid_coord=scene["grid_coord"], feat=scene["feat"], offset=scene["offset"],
+              segment=np.asarray(scene["segment"]).astype(np.int64), sd_seed=np.int64(21),
+              ts=ts_log[0].numpy(), noise=normals[0].numpy(), perms=np.stack([p_.numpy() for p_ in perms]),
+              loss=np.float64(float(loss)), loss_parts=np.array(parts, dtype=np.float64),
+              n_pred=caps["n_pred"].detach().numpy(), c_pred=caps["c_pred"].detach().numpy(),
+              d_n_pred=caps["n_pred"].grad.numpy(), d_c_pred=caps["c_pred"].grad.numpy(),
+              grad_names=np.array(names), grad_norms=gnorm)
+    mk = sorted(masks)
+    fx["mask_names"] = np.array(mk)
+    fx["mask_counts"] = np.array([len(masks[k]) for k in mk], dtype=np.int64)
+    for i, k in enumerate(mk):
+        for j, m in enumerate(masks[k]):
+            fx[f"mask.{i}.{j}"] = m.astype(np.float32)
+    for k in full:
+        if k in pd and pd[k].grad is not None:
+            fx["g." + k] = pd[k].grad.numpy()
+    save_fixture(path, **fx)
+    print("train_step_mini: loss", float(loss), "parts", parts, "points", len(scene["coord"]), "DropPath modules", len(mk),
+          "params with grad", int((gnorm >= 0).sum()), "of", len(gnorm))
+
+
 def gen_variants(ref):
     """Full-width model variants straight from the reference's OWN config files (configs/<dataset>/<variant>.py run with
     runpy): constructor hyper-parameters the inference path reads, state_dict schema (keys + shapes, hashed) and
@@ -567,7 +664,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "tta", "iou", "variants", "train"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["ser", "e2e", "cfg", "ddim", "ptv3", "gs", "tta", "iou", "variants", "train", "trainstep"]
     if "ser" in which:
         gen_serialization(ref)
     if "e2e" in which:
@@ -588,3 +685,5 @@ if __name__ == "__main__":
         gen_variants(ref)
     if "train" in which:
         gen_train(ref)
+    if "trainstep" in which:
+        gen_train_step(ref)

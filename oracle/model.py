@@ -62,10 +62,27 @@ def layernorm(x, sd, p, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
 
 
+# Training mode of the restatement (oracle/train.py::training_forward sets it; None = eval, everything above the
+# training row of SURVEY 8(f4) runs in eval).  TRAIN.masks: {DropPath module name: [mask, ...]} in call order - the
+# reference's stochastic-depth draws (timm DropPath on an (N, C) feature drops whole ROWS, ptv3.py:392-394,415,423),
+# recorded by make_golden.py; BatchNorm1d normalises with the batch statistics (torch's training-mode semantics).
+TRAIN = None
+
+
 def batchnorm_eval(x, sd, p, eps=1e-3):
-    """nn.BatchNorm1d(eps=1e-3) in eval mode (ptv3.py:1440)."""
+    """nn.BatchNorm1d(eps=1e-3) (ptv3.py:1440): running statistics in eval mode, batch statistics under TRAIN."""
+    if TRAIN is not None:
+        return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, eps)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
+
+
+def drop_path(x, name):
+    """DropPath of module `name` (identity in eval and for modules built with rate 0: they hold no masks)."""
+    if TRAIN is None:
+        return x
+    q = TRAIN.masks.get(name)
+    return x * q.pop(0) if q else x
 
 
 def swish(x):  # ptv3.py:30-31
@@ -257,10 +274,10 @@ def block(p, sd, pre, H, oi, K, with_t):
     x = x + cpe(p, x_conv, sd, pre + ".cpe")
     if with_t and "t_emb" in p:
         x = x + linear(p.t_emb, sd, pre + ".t_mlp")
-    x = x + serialized_attention(p, layernorm(x, sd, pre + ".norm1.0"), sd, pre + ".attn", H, oi, K)
+    x = x + drop_path(serialized_attention(p, layernorm(x, sd, pre + ".norm1.0"), sd, pre + ".attn", H, oi, K), pre + ".drop_path.0")
     h = layernorm(x, sd, pre + ".norm2.0")
     h = linear(F.gelu(linear(h, sd, pre + ".mlp.0.fc1")), sd, pre + ".mlp.0.fc2")
-    p.feat = x + h
+    p.feat = x + drop_path(h, pre + ".drop_path.0")
     return p
 
 
@@ -344,10 +361,10 @@ def cross_block(qp, kvp, sd, pre, H, K):
     hkv = layernorm(xkv, sd, pre + ".kv_norm1.0")
     kvp.feat = hkv  # the kv point leaves the block holding its normed feature
     a = serialized_cross_attention(qp, kvp, hq, hkv, sd, pre + ".attn", H, 0, K)
-    x = xq + 1.0 * a
+    x = xq + 1.0 * drop_path(a, pre + ".drop_path.0")
     h = layernorm(x, sd, pre + ".q_norm2.0")
     h = linear(F.gelu(linear(h, sd, pre + ".mlp.0.fc1")), sd, pre + ".mlp.0.fc2")
-    qp.feat = x + h
+    qp.feat = x + drop_path(h, pre + ".drop_path.0")
     return qp
 
 

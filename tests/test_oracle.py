@@ -296,3 +296,49 @@ def test_train_oracle_matches_the_reference_autograd():
             assert float(np.abs(sdt[k[2:]].grad.numpy() - r).max()) < 1e-5 * max(1.0, float(np.abs(r).max())), k
             checked += 1
     assert checked == 12
+
+
+def test_training_forward_oracle_matches_the_reference_train_step():
+    """oracle/train.py::training_forward (train-mode forward of default.py:424-493 + the GLS criteria) against the
+    reference's own training step on a batch of two scenes (tests/golden/train_step_mini.npz, oracle/make_golden.py
+    trainstep: random draws recorded in consumption order, DropPath masks per module): loss and its three parts, both
+    predictions, d loss / d prediction, and - by autograd over the restatement - the gradient of EVERY parameter (norms) and
+    eight gradients in full.  The anchor for the next slices of the training path."""
+    from cdsegnet_amd import configs
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    import cdsegnet_amd.models  # noqa: F401
+    from oracle import train as OT
+    fx = load_fixture("train_step_mini.npz")
+    cfg = configs.mini_config()
+    model = build_model(cfg)
+    sd = fill_state_dict(model.state_dict(), seed=int(fx["sd_seed"]))
+    names = [str(n) for n in fx["grad_names"]]
+    pset = set(names)
+    sdt = {k: (v.clone().float().requires_grad_(True) if k in pset else v.clone()) for k, v in sd.items()}
+    masks = {str(k): [fx[f"mask.{i}.{j}"] for j in range(int(fx["mask_counts"][i]))] for i, k in enumerate(fx["mask_names"])}
+    draws = dict(ts=fx["ts"], noise=fx["noise"], perms=[list(p) for p in fx["perms"]], masks=masks)
+    inp = {k: fx[k] for k in ("coord", "grid_coord", "feat", "offset", "segment")}
+    out = OT.training_forward(cfg, sdt, inp, draws, T=cfg["T"])
+    assert abs(float(out["loss"].detach()) - float(fx["loss"])) < 1e-5
+    got_parts = np.array([float(out[k].detach()) for k in ("mse", "ce", "lovasz")])
+    assert np.abs(got_parts - fx["loss_parts"]).max() < 1e-5
+    assert float((out["n_pred"].detach() - torch.as_tensor(fx["n_pred"])).abs().max()) < 1e-5
+    assert float((out["c_pred"].detach() - torch.as_tensor(fx["c_pred"])).abs().max()) < 1e-5
+    out["n_pred"].retain_grad()
+    out["c_pred"].retain_grad()
+    out["loss"].backward()
+    assert float((out["n_pred"].grad - torch.as_tensor(fx["d_n_pred"])).abs().max()) < 1e-7
+    assert float((out["c_pred"].grad - torch.as_tensor(fx["d_c_pred"])).abs().max()) < 1e-7
+    gn = np.array([float(sdt[k].grad.norm()) if sdt[k].grad is not None else -1.0 for k in names])
+    ref = fx["grad_norms"]
+    assert (gn >= 0).all() and len(gn) == 508
+    # (biases in front of a train-mode BatchNorm have an exactly-zero gradient: compare absolutely as well)
+    assert (np.abs(gn - ref) <= 1e-4 * ref + 1e-6 * ref.max()).all()
+    checked = 0
+    for k in fx.files:
+        if k.startswith("g."):
+            r = fx[k]
+            assert float((sdt[k[2:]].grad - torch.as_tensor(r)).abs().max()) <= 1e-5 * float(np.abs(r).max()), k
+            checked += 1
+    assert checked == 8
