@@ -600,6 +600,16 @@ def gen_train_step(ref):
               n_pred=caps["n_pred"].detach().numpy(), c_pred=caps["c_pred"].detach().numpy(),
               d_n_pred=caps["n_pred"].grad.numpy(), d_c_pred=caps["c_pred"].grad.numpy(),
               grad_names=np.array(names), grad_norms=gnorm)
+    # one optimizer step on those gradients, grouped like pointcept/utils/optimizer.py:20-56 with the shipped settings
+    # (configs/scannet/CDSegNet.py:143,152: AdamW lr 2e-3, weight decay 0.05; parameters with "block" in their name lr 2e-4)
+    before = {k: p_.detach().clone() for k, p_ in model.named_parameters()}
+    groups = [dict(params=[p_ for k, p_ in model.named_parameters() if "block" not in k], lr=0.002),
+              dict(params=[p_ for k, p_ in model.named_parameters() if "block" in k], lr=0.0002)]
+    opt = torch.optim.AdamW(groups, lr=0.002, weight_decay=0.05)
+    opt.step()
+    fx["step_norms"] = np.array([float((p_.detach() - before[k]).norm()) for k, p_ in model.named_parameters()], dtype=np.float64)
+    for k in ("backbone._n_head.weight", "backbone._n_enc.enc2.block0.attn.qkv.weight"):
+        fx["p1." + k] = pd[k].detach().numpy().copy()
     mk = sorted(masks)
     fx["mask_names"] = np.array(mk)
     fx["mask_counts"] = np.array([len(masks[k]) for k in mk], dtype=np.int64)

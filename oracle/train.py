@@ -123,3 +123,12 @@ def training_forward(cfg, sd, input_dict, draws, T=1000, alpha_bar=None):
         OM.TRAIN = None
     loss, (mse, ce, lov) = gls_loss(c_out, noise, n_out, seg)
     return dict(loss=loss, mse=mse, ce=ce, lovasz=lov, n_pred=n_out, c_pred=c_out, c_target=noise)
+
+
+def adamw_first_step(p, g, lr, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.AdamW's FIRST step (decoupled weight decay, bias-corrected moments): what engines/train.py:216-271 applies
+    with the shipped optimizer (configs/scannet/CDSegNet.py:143: lr 2e-3, weight decay 0.05; parameter group "block": 2e-4)."""
+    p = p * (1.0 - lr * weight_decay)
+    m_hat = ((1 - betas[0]) * g) / (1 - betas[0])
+    v_hat = ((1 - betas[1]) * g * g) / (1 - betas[1])
+    return p - lr * m_hat / (v_hat.sqrt() + eps)

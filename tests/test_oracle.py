@@ -342,3 +342,15 @@ def test_training_forward_oracle_matches_the_reference_train_step():
             assert float((sdt[k[2:]].grad - torch.as_tensor(r)).abs().max()) <= 1e-5 * float(np.abs(r).max()), k
             checked += 1
     assert checked == 8
+    # ... and the optimizer step that follows (AdamW, two learning-rate groups)
+    worst = 0.0
+    for i, k in enumerate(names):
+        if ref[i] < 1e-4 * ref.max():
+            continue  # (a gradient that is rounding noise - e.g. a bias in front of a train-mode BatchNorm - makes g / (|g| + eps) noise)
+        lr = 0.0002 if "block" in k else 0.002
+        new = OT.adamw_first_step(sd[k].float(), sdt[k].grad, lr)
+        dn = float((new - sd[k].float()).norm())
+        worst = max(worst, abs(dn - float(fx["step_norms"][i])) / max(float(fx["step_norms"][i]), 1e-12))
+        if "p1." + k in fx.files:
+            assert float((new - torch.as_tensor(fx["p1." + k])).abs().max()) < 2e-6
+    assert worst < 2e-2  # (first-step AdamW moves every element by ~lr: g / (|g| + eps) amplifies gradients of ~1e-8)
