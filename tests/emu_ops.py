@@ -530,3 +530,59 @@ def iou_counts(pred, target, num_classes, ignore_index=-1, pred_idx=None):
     hit = t[p == t]
     out[0] = torch.bincount(hit[(hit >= 0) & (hit < num_classes)], minlength=num_classes)[:num_classes]
     return out
+
+
+# ------------------------------------------------------------------ training path (cdsegnet_amd/train.py on the CPU)
+def attention_bwd(q, k, v, q_gidx, kv_gidx, widx, patch_start, patch_start_host, num_heads, scale, dout, dq, dk, dv):
+    """Autograd through the oracle's patch attention on the library's slot plan; += into dq / dk / dv like the kernel."""
+    ps = np.asarray(patch_start_host, dtype=np.int64)
+    qq, kk, vv = (t.detach().clone().float().requires_grad_(True) for t in (q, k, v))
+    o = OM._patch_attention(qq[q_gidx.long()], kk[kv_gidx.long()], vv[kv_gidx.long()], ps, num_heads, scale)
+    m = widx >= 0
+    full = torch.zeros_like(dout)
+    full = full.index_put((widx[m].long(),), o[m])
+    (full * dout).sum().backward()
+    dq += qq.grad
+    dk += kk.grad
+    dv += vv.grad
+
+
+def layernorm_bwd(x, gamma, dy, dx, accumulate=False, eps=1e-5, dgamma=None, dbeta=None):
+    xr = x.detach().clone().requires_grad_(True)
+    g = gamma.detach().clone().requires_grad_(True)
+    b = torch.zeros_like(gamma).requires_grad_(True)
+    F.layer_norm(xr, (x.shape[1],), g, b, eps).backward(dy)
+    if accumulate:
+        dx += xr.grad
+    else:
+        dx.copy_(xr.grad)
+    if dgamma is not None:
+        dgamma += g.grad
+    if dbeta is not None:
+        dbeta += b.grad
+    return dx
+
+
+def gelu_bwd(u, dy):
+    ur = u.detach().clone().requires_grad_(True)
+    F.gelu(ur).backward(dy)
+    return ur.grad
+
+
+def linear_wgrad(x, dy, dw, db=None, xidx=None):
+    if xidx is None:
+        dw += dy.t() @ x
+    else:
+        m = xidx >= 0
+        dw += dy[m].t() @ x[xidx[m].long()]
+    if db is not None:
+        db += dy.sum(0)
+    return dw
+
+
+def conv_wgrad(x, nbr_kmajor, dy, dw3, db=None):
+    for o in range(nbr_kmajor.shape[0]):
+        linear_wgrad(x, dy, dw3[:, o, :], None, xidx=nbr_kmajor[o])
+    if db is not None:
+        db += dy.sum(0)
+    return dw3

@@ -296,3 +296,59 @@ def test_engine_degenerate_scenes_vs_oracle(emulated, kind, flash):
     out = model.inference({k: torch.as_tensor(v) for k, v in inp.items()}, eval=False, draws=dict(draws))["seg_logits"].numpy()
     assert out.shape == ref.shape and np.isfinite(out).all()
     assert np.abs(out - ref).max() < 2e-4
+
+
+def test_whole_block_backward_host_chain_on_the_emulated_ops(monkeypatch):
+    """cdsegnet_amd/train.py (forward with tape + whole-Block backward: the order of the products, the transposed and the
+    mirrored conv weights, the gradient names, the slot-plan plumbing) on the PyTorch-CPU emulation of the ops, against
+    torch autograd over the oracle's Block - the CPU twin of tests/test_gpu_train.py::test_whole_block_backward_vs_oracle."""
+    import cdsegnet_amd.train as train
+    from cdsegnet_amd import synth
+    from oracle import model as OM
+    from oracle import serialization as S
+    from oracle import train as OT
+    monkeypatch.setattr(train, "ops", emu_ops)
+    rng = np.random.default_rng(5)
+    sc = synth.room_scene(9, 700)
+    grid = np.asarray(sc["grid_coord"], dtype=np.int64)
+    n, H = len(grid), 2
+    C = 16 * H
+    nbr = OM.subm_neighbors(grid, np.zeros(n, dtype=np.int64), 3)
+    pad, unpad, cu = S.padding_plan(np.array([n]), 1024)
+    perm = rng.permutation(n)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    order, inverse = perm[pad], unpad[inv]
+    pre, sd = "blk", {}
+    for k, shape in ((".cpe.0.weight", (C, 3, 3, 3, C)), (".cpe.0.bias", (C,)), (".cpe.1.weight", (C, C)), (".cpe.1.bias", (C,)),
+                     (".cpe.2.weight", (C,)), (".cpe.2.bias", (C,)), (".norm1.0.weight", (C,)), (".norm1.0.bias", (C,)),
+                     (".attn.qkv.weight", (3 * C, C)), (".attn.qkv.bias", (3 * C,)), (".attn.proj.weight", (C, C)),
+                     (".attn.proj.bias", (C,)), (".norm2.0.weight", (C,)), (".norm2.0.bias", (C,)), (".mlp.0.fc1.weight", (4 * C, C)),
+                     (".mlp.0.fc1.bias", (4 * C,)), (".mlp.0.fc2.weight", (C, 4 * C)), (".mlp.0.fc2.bias", (C,))):
+        scale = {1: 0.1, 2: 0.3, 5: 0.3 / 27 ** 0.5}[len(shape)]
+        sd[pre + k] = (rng.standard_normal(shape) * scale + (1.0 if k.endswith(".weight") and len(shape) == 1 else 0.0)).astype(np.float32)
+    x_in = rng.standard_normal((n, C)).astype(np.float32)
+    dy = rng.standard_normal((n, C)).astype(np.float32)
+    ry, rdx, rg = OT.block_full_grads(sd, pre, x_in, nbr, order, inverse, cu, H, dy)
+    f = lambda k: torch.as_tensor(sd[pre + k], dtype=torch.float32).contiguous()  # noqa: E731
+    names = {"B.cpe0.w": ".cpe.0.weight", "B.cpe0.b": ".cpe.0.bias", "B.cpe1.w": ".cpe.1.weight", "B.cpe1.b": ".cpe.1.bias",
+             "B.cpe2.g": ".cpe.2.weight", "B.cpe2.b": ".cpe.2.bias", "B.norm1.g": ".norm1.0.weight", "B.norm1.b": ".norm1.0.bias",
+             "B.qkv.w": ".attn.qkv.weight", "B.qkv.b": ".attn.qkv.bias", "B.proj.w": ".attn.proj.weight", "B.proj.b": ".attn.proj.bias",
+             "B.norm2.g": ".norm2.0.weight", "B.norm2.b": ".norm2.0.bias", "B.fc1.w": ".mlp.0.fc1.weight", "B.fc1.b": ".mlp.0.fc1.bias",
+             "B.fc2.w": ".mlp.0.fc2.weight", "B.fc2.b": ".mlp.0.fc2.bias"}
+    w = {mine: f(ref) for mine, ref in names.items()}
+    w["B.cpe0.w"] = w["B.cpe0.w"].reshape(C, -1).contiguous()
+    gidx = torch.as_tensor(order, dtype=torch.int32)
+    widx = np.full(len(order), -1, dtype=np.int32)
+    widx[inverse] = np.arange(n, dtype=np.int32)
+    ps = torch.as_tensor(np.asarray(cu), dtype=torch.int32)
+    nbr_k = torch.as_tensor(nbr.T.astype(np.int32)).contiguous()
+    tape = train.block_forward(w, "B", torch.as_tensor(x_in), nbr_k, gidx, torch.as_tensor(widx), ps, [int(v) for v in cu], H,
+                               int(np.diff(cu).max()), (C // H) ** -0.5)
+    dx, dxc, grads = train.block_backward(w, "B", tape, torch.as_tensor(dy))
+    assert dxc is None and set(grads) == set(names)
+    assert float((tape["tail"].y - ry).abs().max()) < 1e-3
+    assert float((dx - rdx).abs().max()) < 1e-3 * max(1.0, float(rdx.abs().max()))
+    for mine, ref in names.items():
+        r = rg[pre + ref].reshape(grads[mine].shape)
+        assert float((grads[mine] - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max())), mine
