@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "deep.h"
 
 namespace {
 
@@ -341,13 +342,15 @@ int rr_grid(long n, int lds_bytes) {
 }  // namespace
 
 extern "C" size_t cdseg_block_rr_img_bytes(int channels, int which) {
-  if (channels != 32 && channels != 64) return 0;
+  if (channels != 32 && channels != 64 && !deep_supported(channels)) return 0;
   return (size_t)(which == 0 ? 4 : 9) * channels * channels * 2;
 }
 
 // head image: Wl (C, C), Wqkv (3C, C);  tail image: Wp (C, C), W1 (4C, C), W2 (C, 4C).  bf16 row-major inputs.
 extern "C" int cdseg_block_rr_pack(int channels, const void* wl, const void* wqkv, void* head_img, const void* wp,
                                    const void* w1, const void* w2, void* tail_img, void* stream) {
+  // deep stages (C = 128 / 256): per-wave weight streams in consumption order (csrc/deep.hip)
+  if (deep_supported(channels)) return deep_pack(channels, wl, wqkv, head_img, wp, w1, w2, tail_img, (hipStream_t)stream);
   if (channels != 32 && channels != 64) return CDSEG_ERR_UNSUPPORTED;
   const int C = channels;
   hipStream_t s = (hipStream_t)stream;
@@ -372,9 +375,12 @@ extern "C" int cdseg_cpe_head_rr(const void* y, int ldy, const void* head_img, c
                                  int channels, void* stream) {
   if (n <= 0) return CDSEG_OK;
   if (!y || !head_img || !bl || !lnp_g || !lnp_b || !x || !ln1_g || !ln1_b || !bqkv || !qkv) return CDSEG_ERR_ARG;
-  if (channels != 32 && channels != 64) return CDSEG_ERR_UNSUPPORTED;
+  if (channels != 32 && channels != 64 && !deep_supported(channels)) return CDSEG_ERR_UNSUPPORTED;
   if ((ldy & 7) || (ldx & 3) || (ldqkv & 7) || (((uintptr_t)y | (uintptr_t)x | (uintptr_t)qkv | (uintptr_t)head_img) & 15))
     return CDSEG_ERR_ARG;
+  if (deep_supported(channels))
+    return deep_head(y, ldy, head_img, bl, lnp_g, lnp_b, x, ldx, colbias, ln1_g, ln1_b, eps, bqkv, qkv, ldqkv, n, channels,
+                     (hipStream_t)stream);
   HeadRR p;
   p.y = (const bf16_t*)y; p.wimg = (const uint4*)head_img; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.bqkv = bqkv; p.qkv = (bf16_t*)qkv;
@@ -396,9 +402,11 @@ extern "C" int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, 
                                   void* xc, int ldxc, long n, int channels, void* stream) {
   if (n <= 0) return CDSEG_OK;
   if (!o || !tail_img || !bp || !ln_g || !ln_b || !b1 || !b2 || !x) return CDSEG_ERR_ARG;
-  if (channels != 32 && channels != 64) return CDSEG_ERR_UNSUPPORTED;
+  if (channels != 32 && channels != 64 && !deep_supported(channels)) return CDSEG_ERR_UNSUPPORTED;
   if ((ldo & 7) || (ldx & 3) || (xc && (ldxc & 7)) || (((uintptr_t)o | (uintptr_t)x | (uintptr_t)xc | (uintptr_t)tail_img) & 15))
     return CDSEG_ERR_ARG;
+  if (deep_supported(channels))
+    return deep_tail(o, ldo, tail_img, bp, ln_g, ln_b, eps, b1, b2, x, ldx, xc, ldxc, n, channels, (hipStream_t)stream);
   TailRR p;
   p.o = (const bf16_t*)o; p.wimg = (const uint4*)tail_img; p.bp = bp; p.ln_g = ln_g; p.ln_b = ln_b; p.b1 = b1; p.b2 = b2;
   p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldo = ldo; p.ldx = ldx; p.ldxc = ldxc; p.eps = eps;

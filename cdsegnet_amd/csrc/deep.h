@@ -1,0 +1,13 @@
+// Deep-stage (C = 128 / 256) Block head and tail: internal entry points of csrc/deep.hip, reached through the public
+// cdseg_block_rr_pack / cdseg_cpe_head_rr / cdseg_attn_tail_rr (csrc/blockrr.hip dispatches on the channel count).
+#pragma once
+#include "common.h"
+
+bool deep_supported(int channels);
+int deep_pack(int channels, const void* wl, const void* wqkv, void* head_img, const void* wp, const void* w1, const void* w2,
+              void* tail_img, hipStream_t s);
+int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b, float* x,
+              int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
+              int ldqkv, long n, int channels, hipStream_t s);
+int deep_tail(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b, float eps,
+              const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n, int channels, hipStream_t s);

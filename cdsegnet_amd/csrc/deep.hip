@@ -1,0 +1,482 @@
+// Block head and tail of the DEEP stages (C = 128 / 256, 16-bit trunk) in one launch each (gfx950).
+//
+//   head (ref: ptv3.py:401-414)   x += LN_cpe(y Wl^T + bl) [+ t bias] ;  h = LN1(x) ;  qkv = h Wqkv^T + bqkv
+//   tail (ref: ptv3.py:416-427)   x += proj(o) ;  h = LN2(x) ;  x += fc2(GELU(fc1(h))) ;  xc = T(x)
+//
+// The wide stages (C = 32 / 64, blockrr.hip) keep every weight of the kernel in LDS and the activations in registers.
+// Here the weights are too large for that (tail: 1.2 MB at C = 256) and the rows too few to amortise a weight tile per
+// workgroup through LDS: as separate GEMM launches these products ran at 5 - 19 % of the MFMA peak (a 128 x 128 tile
+// waits ~1.7 us for every 64-deep K step of A + W, then spends 2 us in its epilogue; LayerNorm over rows wider than a
+// column tile needed a second pass).  So the roles are swapped:
+//   * the ACTIVATIONS of a BM-row tile live in LDS (16-bit, row-major, 16-byte chunks XOR-swizzled with the row so that
+//     both the MFMA B-fragment reads and the producers' 16-byte writes are bank-conflict free) for the whole chain of
+//     products - y / o, h, the hidden chunk - and never touch HBM;
+//   * the WEIGHTS stream L2 -> registers: a wave owns the same 32 output channels of every C-wide product for ALL rows
+//     of the tile (C / 32 waves per workgroup), so a weight fragment is needed by exactly one wave of the workgroup
+//     and goes straight into its MFMA A operand - no LDS staging, no barrier per K step.  The images are packed
+//     per wave in consumption order (cdseg_block_rr_pack), i.e. a wave reads ONE linear stream of 2 KB per K step
+//     through a 4-step register ring that runs across the products and their epilogues;
+//   * products are computed transposed (D^T = W X^T, v_mfma_f32_16x16x32): a lane ends up with 8 CONSECUTIVE channels
+//     of one point (the rows of the weight image are permuted accordingly), so every LDS / global access of the
+//     epilogues is 16 bytes; LayerNorm statistics are a per-lane sum, two cross-lane adds and one exchange of per-wave
+//     partial sums through LDS;
+//   * the MLP runs in hidden chunks of C units: fc1 chunk -> bias + GELU -> 16-bit -> LDS -> fc2 partial product into
+//     accumulators that were initialised with the residual row.
+// Per workgroup and weight byte the tile does BM (128) FLOP pairs instead of the 64 of a 128 x 128 GEMM tile, the
+// weight stream of all workgroups is the same sequence (L2 hits), and the launches per Block drop from 8 to 2.
+#include "deep.h"
+
+namespace {
+
+constexpr int DEEP_D = 4;  // weight ring depth in K steps (2 fragments = 8 VGPRs per step)
+
+template <int NCH>
+__device__ __forceinline__ int act_off(int row, int chunk) {  // byte offset of 16-byte chunk `chunk` of activation row `row`
+  return row * (NCH * 16) + ((chunk ^ (row & 15)) << 4);
+}
+
+__device__ __forceinline__ void lds_barrier() {  // LDS hazards only: the weight ring's global loads stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ uint4 pack8(const f32x4_t& a, const f32x4_t& b) {
+  uint4 r;
+  r.x = pack_bf16x2(a[0], a[1]); r.y = pack_bf16x2(a[2], a[3]);
+  r.z = pack_bf16x2(b[0], b[1]); r.w = pack_bf16x2(b[2], b[3]);
+  return r;
+}
+
+// BM x C tile of 16-bit rows, global -> LDS (swizzled).  Rows past the end re-read the last row (computed, never stored).
+template <int C, int BM>
+__device__ __forceinline__ void load_tile(const bf16_t* src, int ld, long m0, long n, char* buf, int tid) {
+  constexpr int NCH = C / 8, NT = 2 * C, PT = BM * NCH / NT;
+  uint4 r[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int id = i * NT + tid, row = id / NCH, c = id % NCH;
+    long m = m0 + row;
+    if (m >= n) m = n - 1;
+    r[i] = *reinterpret_cast<const uint4*>(src + m * ld + c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int id = i * NT + tid, row = id / NCH, c = id % NCH;
+    *reinterpret_cast<uint4*>(buf + act_off<NCH>(row, c)) = r[i];
+  }
+}
+
+// acc[pt][f] (channels 8 g + 4 f + r of the wave's 32, point 16 pt + p) += W X^T over K = C: KS steps of 32, the two
+// weight fragments of a step from the ring, the next ring slot requested right after.  `step0`: position of the
+// product's first step in the wave's weight stream; requests past the end re-read the last step (no branch around a
+// load: hipcc would wait vmcnt(0) there).
+template <int C, int BM>
+__device__ __forceinline__ void product(f32x4_t (&acc)[BM / 16][2], const char* bufX, uint4 (&ring)[DEEP_D][2],
+                                        const uint4* wp, int step0, int last_step, int p, int g) {
+  constexpr int KS = C / 32, NCH = C / 8, PTS = BM / 16;
+  const char* xrow = bufX + p * (NCH * 16);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, ring[s % DEEP_D][0]);
+    const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, ring[s % DEEP_D][1]);
+    const char* xs = xrow + (((4 * s + g) ^ p) << 4);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+      const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(xs + pt * 16 * (NCH * 16));
+      acc[pt][0] = mfma_16x16x32_bf16(a0, b, acc[pt][0]);
+      acc[pt][1] = mfma_16x16x32_bf16(a1, b, acc[pt][1]);
+    }
+    {
+      int nx = step0 + s + DEEP_D;
+      nx = nx < last_step ? nx : last_step;
+      ring[s % DEEP_D][0] = wp[(nx * 2 + 0) * 64];
+      ring[s % DEEP_D][1] = wp[(nx * 2 + 1) * 64];
+    }
+    // one request per step, DEEP_D steps ahead of its use: left to itself the scheduler sinks the requests towards their
+    // uses and bunches them at the end of the product (s_waitcnt vmcnt(0) right behind a request in the middle of it)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ void prime(uint4 (&ring)[DEEP_D][2], const uint4* wp, int step0) {
+#pragma unroll
+  for (int d = 0; d < DEEP_D; ++d) {
+    ring[d][0] = wp[((step0 + d) * 2 + 0) * 64];
+    ring[d][1] = wp[((step0 + d) * 2 + 1) * 64];
+  }
+}
+
+// LayerNorm statistics of the tile's rows: a row's C channels are spread over 4 lanes (g) x NW waves.
+template <int PTS, int NW>
+__device__ __forceinline__ void row_stats(const f32x4_t (&v)[PTS][2], float* st1, float* st2, int wave, int p, int g,
+                                          float inv_c, float eps, float (&mean)[PTS], float (&rstd)[PTS]) {
+  auto across = [&](float* st, int pt) {
+    float t = 0.f;
+    if constexpr (NW == 8) {
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(st + (16 * pt + p) * NW);
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(st + (16 * pt + p) * NW + 4);
+      t = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+    } else {
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(st + (16 * pt + p) * NW);
+      t = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    return t;
+  };
+#pragma unroll
+  for (int pt = 0; pt < PTS; ++pt) {
+    float s = ((v[pt][0][0] + v[pt][0][1]) + (v[pt][0][2] + v[pt][0][3])) +
+              ((v[pt][1][0] + v[pt][1][1]) + (v[pt][1][2] + v[pt][1][3]));
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (g == 0) st1[(16 * pt + p) * NW + wave] = s;
+  }
+  lds_barrier();
+#pragma unroll
+  for (int pt = 0; pt < PTS; ++pt) mean[pt] = across(st1, pt) * inv_c;
+#pragma unroll
+  for (int pt = 0; pt < PTS; ++pt) {
+    float q = 0.f;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[pt][f][r] - mean[pt];
+        q += d * d;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (g == 0) st2[(16 * pt + p) * NW + wave] = q;
+  }
+  lds_barrier();
+#pragma unroll
+  for (int pt = 0; pt < PTS; ++pt) rstd[pt] = 1.0f / sqrtf(across(st2, pt) * inv_c + eps);
+}
+
+template <int C, int BM>
+struct DeepCfg {
+  static constexpr int NW = C / 32, KS = C / 32, NT = 64 * NW;
+  static constexpr int ACT = BM * C * 2;                // one activation buffer
+  static constexpr int STAT = 2 * BM * NW * 4;          // two arrays of per-wave partial sums
+  static constexpr int HEAD_LDS = ACT + STAT + 9 * C * 4;       // bl lnp_g lnp_b colbias ln1_g ln1_b bqkv(3C)
+  static constexpr int TAIL_LDS = 2 * ACT + STAT + 8 * C * 4;   // bp ln_g ln_b b2 b1(4C)
+  static constexpr int HEAD_STEPS = 4 * KS, TAIL_STEPS = 9 * KS;
+};
+
+struct DeepHeadP {
+  const bf16_t* y; const uint4* wimg; const float* bl; const float* lnp_g; const float* lnp_b; float* x;
+  const float* colbias; const float* ln1_g; const float* ln1_b; const float* bqkv; bf16_t* qkv;
+  long n; int ldy, ldx, ldqkv; float eps;
+};
+
+template <int C, int BM>
+__global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
+  using K = DeepCfg<C, BM>;
+  constexpr int NW = K::NW, KS = K::KS, NCH = C / 8, NT = K::NT, PTS = BM / 16, S = K::HEAD_STEPS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* bufA = smem;
+  float* st1 = reinterpret_cast<float*>(smem + K::ACT);
+  float* st2 = st1 + BM * NW;
+  float* pr = st2 + BM * NW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const long m0 = (long)blockIdx.x * BM;
+  const uint4* wp = P.wimg + (size_t)wave * S * 128 + lane;
+  uint4 ring[DEEP_D][2];
+  prime(ring, wp, 0);
+  for (int c = tid; c < C; c += NT) {
+    pr[c] = P.bl[c]; pr[C + c] = P.lnp_g[c]; pr[2 * C + c] = P.lnp_b[c]; pr[3 * C + c] = P.colbias ? P.colbias[c] : 0.f;
+    pr[4 * C + c] = P.ln1_g[c]; pr[5 * C + c] = P.ln1_b[c];
+  }
+  for (int c = tid; c < 3 * C; c += NT) pr[6 * C + c] = P.bqkv[c];
+  load_tile<C, BM>(P.y, P.ldy, m0, P.n, bufA, tid);
+  const int ch0 = 32 * wave + 8 * g;  // the lane's channels: ch0 + 4 f + r
+  lds_barrier();  // tile + parameters visible
+
+  f32x4_t v[PTS][2];
+  {
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + ch0), b1 = *reinterpret_cast<const f32x4_t*>(pr + ch0 + 4);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) { v[pt][0] = b0; v[pt][1] = b1; }
+  }
+  // y Wl^T + bl.  The ring is NOT kept running across the two LayerNorms that follow (32 more live VGPRs next to the
+  // product, the residual rows and the statistics: the compiler spilled the prefetched fragments with vmcnt(0) waits
+  // inside the product); the qkv stream is primed again once the residual rows are dead
+  product<C, BM>(v, bufA, ring, wp, 0, KS - 1, p, g);
+  // residual rows: needed after the first LayerNorm's statistics, requested before them (live across the product
+  // - where the scheduler hoists them unless fenced - they cost 190 spilled VGPRs)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4_t xr[PTS][2];
+#pragma unroll
+  for (int pt = 0; pt < PTS; ++pt) {
+    long m = m0 + 16 * pt + p;
+    if (m >= P.n) m = P.n - 1;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) xr[pt][f] = *reinterpret_cast<const f32x4_t*>(P.x + m * P.ldx + ch0 + 4 * f);
+  }
+  float mean[PTS], rstd[PTS];
+  const float inv_c = 1.0f / C;
+  row_stats<PTS, NW>(v, st1, st2, wave, p, g, inv_c, P.eps, mean, rstd);
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const f32x4_t ga = *reinterpret_cast<const f32x4_t*>(pr + C + ch0 + 4 * f);
+    const f32x4_t be = *reinterpret_cast<const f32x4_t*>(pr + 2 * C + ch0 + 4 * f);
+    const f32x4_t tb = *reinterpret_cast<const f32x4_t*>(pr + 3 * C + ch0 + 4 * f);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[pt][f][r] = ((v[pt][f][r] - mean[pt]) * rstd[pt] * ga[r] + be[r]) + xr[pt][f][r] + tb[r];
+      const long m = m0 + 16 * pt + p;
+      if (m < P.n) *reinterpret_cast<f32x4_t*>(P.x + m * P.ldx + ch0 + 4 * f) = v[pt][f];
+    }
+  }
+  row_stats<PTS, NW>(v, st1, st2, wave, p, g, inv_c, P.eps, mean, rstd);
+  prime(ring, wp, KS);
+  {
+    // h = LN1(x) over the tile, in place of y (every wave is past its y reads: the statistics barriers above)
+    const f32x4_t ga0 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + ch0), ga1 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + ch0 + 4);
+    const f32x4_t be0 = *reinterpret_cast<const f32x4_t*>(pr + 5 * C + ch0), be1 = *reinterpret_cast<const f32x4_t*>(pr + 5 * C + ch0 + 4);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+      f32x4_t h0, h1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h0[r] = (v[pt][0][r] - mean[pt]) * rstd[pt] * ga0[r] + be0[r];
+        h1[r] = (v[pt][1][r] - mean[pt]) * rstd[pt] * ga1[r] + be1[r];
+      }
+      *reinterpret_cast<uint4*>(bufA + act_off<NCH>(16 * pt + p, 4 * wave + g)) = pack8(h0, h1);
+    }
+  }
+  lds_barrier();
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {  // q, k, v column blocks
+    f32x4_t a[PTS][2];
+    {
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + 6 * C + c * C + ch0);
+      const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(pr + 6 * C + c * C + ch0 + 4);
+#pragma unroll
+      for (int pt = 0; pt < PTS; ++pt) { a[pt][0] = b0; a[pt][1] = b1; }
+    }
+    int po = p;  // opaque per iteration: h is loop invariant, and its 64 fragment reads (256 VGPRs) would be hoisted
+    asm volatile("" : "+v"(po));
+    product<C, BM>(a, bufA, ring, wp, KS * (1 + c), S - 1, po, g);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+      const long m = m0 + 16 * pt + p;
+      if (m < P.n) *reinterpret_cast<uint4*>(P.qkv + m * P.ldqkv + c * C + ch0) = pack8(a[pt][0], a[pt][1]);
+    }
+  }
+}
+
+struct DeepTailP {
+  const bf16_t* o; const uint4* wimg; const float* bp; const float* ln_g; const float* ln_b; const float* b1;
+  const float* b2; float* x; bf16_t* xc;
+  long n; int ldo, ldx, ldxc; float eps;
+};
+
+template <int C, int BM>
+__global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
+  using K = DeepCfg<C, BM>;
+  constexpr int NW = K::NW, KS = K::KS, NCH = C / 8, NT = K::NT, PTS = BM / 16, S = K::TAIL_STEPS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* bufA = smem;             // o, then h
+  char* bufU = smem + K::ACT;    // hidden chunk (C units)
+  float* st1 = reinterpret_cast<float*>(smem + 2 * K::ACT);
+  float* st2 = st1 + BM * NW;
+  float* pr = st2 + BM * NW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const long m0 = (long)blockIdx.x * BM;
+  const uint4* wp = P.wimg + (size_t)wave * S * 128 + lane;
+  uint4 ring[DEEP_D][2];
+  prime(ring, wp, 0);
+  for (int c = tid; c < C; c += NT) {
+    pr[c] = P.bp[c]; pr[C + c] = P.ln_g[c]; pr[2 * C + c] = P.ln_b[c]; pr[3 * C + c] = P.b2[c];
+  }
+  for (int c = tid; c < 4 * C; c += NT) pr[4 * C + c] = P.b1[c];
+  load_tile<C, BM>(P.o, P.ldo, m0, P.n, bufA, tid);
+  const int ch0 = 32 * wave + 8 * g;
+  f32x4_t acc2[PTS][2];  // proj + bp, then x' = that + x, then x' + fc2 partial sums
+  {
+    f32x4_t xr[PTS][2];
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+      long m = m0 + 16 * pt + p;
+      if (m >= P.n) m = P.n - 1;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) xr[pt][f] = *reinterpret_cast<const f32x4_t*>(P.x + m * P.ldx + ch0 + 4 * f);
+    }
+    lds_barrier();
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + ch0), b1 = *reinterpret_cast<const f32x4_t*>(pr + ch0 + 4);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) { acc2[pt][0] = b0; acc2[pt][1] = b1; }
+    product<C, BM>(acc2, bufA, ring, wp, 0, S - 1, p, g);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) { acc2[pt][0] += xr[pt][0]; acc2[pt][1] += xr[pt][1]; }
+  }
+  {
+    float mean[PTS], rstd[PTS];
+    row_stats<PTS, NW>(acc2, st1, st2, wave, p, g, 1.0f / C, P.eps, mean, rstd);
+    const f32x4_t ga0 = *reinterpret_cast<const f32x4_t*>(pr + C + ch0), ga1 = *reinterpret_cast<const f32x4_t*>(pr + C + ch0 + 4);
+    const f32x4_t be0 = *reinterpret_cast<const f32x4_t*>(pr + 2 * C + ch0), be1 = *reinterpret_cast<const f32x4_t*>(pr + 2 * C + ch0 + 4);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+      f32x4_t h0, h1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h0[r] = (acc2[pt][0][r] - mean[pt]) * rstd[pt] * ga0[r] + be0[r];
+        h1[r] = (acc2[pt][1][r] - mean[pt]) * rstd[pt] * ga1[r] + be1[r];
+      }
+      *reinterpret_cast<uint4*>(bufA + act_off<NCH>(16 * pt + p, 4 * wave + g)) = pack8(h0, h1);
+    }
+  }
+  lds_barrier();
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {  // hidden units C j .. C j + C - 1
+    f32x4_t acc1[PTS][2];
+    {
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + j * C + ch0);
+      const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + j * C + ch0 + 4);
+#pragma unroll
+      for (int pt = 0; pt < PTS; ++pt) { acc1[pt][0] = b0; acc1[pt][1] = b1; }
+    }
+    int po = p;  // opaque per iteration: h is loop invariant (see deep_head_kernel)
+    asm volatile("" : "+v"(po));
+    product<C, BM>(acc1, bufA, ring, wp, KS * (1 + 2 * j), S - 1, po, g);
+    if (j) lds_barrier();  // every wave is done with the previous chunk's fc2 reads of bufU
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc1[pt][0][r] = gelu_erf(acc1[pt][0][r]); acc1[pt][1][r] = gelu_erf(acc1[pt][1][r]); }
+      *reinterpret_cast<uint4*>(bufU + act_off<NCH>(16 * pt + p, 4 * wave + g)) = pack8(acc1[pt][0], acc1[pt][1]);
+    }
+    lds_barrier();
+    product<C, BM>(acc2, bufU, ring, wp, KS * (2 + 2 * j), S - 1, p, g);
+  }
+  {
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + 3 * C + ch0), b1 = *reinterpret_cast<const f32x4_t*>(pr + 3 * C + ch0 + 4);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+      const long m = m0 + 16 * pt + p;
+      if (m < P.n) {
+        const f32x4_t o0 = acc2[pt][0] + b0, o1 = acc2[pt][1] + b1;
+        *reinterpret_cast<f32x4_t*>(P.x + m * P.ldx + ch0) = o0;
+        *reinterpret_cast<f32x4_t*>(P.x + m * P.ldx + ch0 + 4) = o1;
+        if (P.xc) *reinterpret_cast<uint4*>(P.xc + m * P.ldxc + ch0) = pack8(o0, o1);
+      }
+    }
+  }
+}
+
+// ---- weight images.  One product phase: KS steps x 2 fragments per wave.  16-byte unit
+// ((w * S + step0 + s) * 2 + f) * 64 + lane,  lane = 16 q + i:
+//     W[row_base + 32 w + 8 (i >> 2) + 4 f + (i & 3)][col_base + 32 s + 8 q + 0..7]
+// (MFMA A operand: lane (q, i) = row i, k slots 8 q .. 8 q + 7; output row i lands in lane group i >> 2, register i & 3)
+struct DeepPackP {
+  const bf16_t* w;
+  uint4* img;
+  int ld, C, S, step0, row_base, col_base;
+};
+
+__global__ void deep_pack_kernel(DeepPackP p) {
+  const int KS = p.C / 32, NW = p.C / 32;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= NW * KS * 128) return;
+  const int lane = u & 63, f = (u >> 6) & 1, s = (u >> 7) % KS, w = (u >> 7) / KS;
+  const int q = lane >> 4, i = lane & 15;
+  const long row = p.row_base + 32 * w + 8 * (i >> 2) + 4 * f + (i & 3);
+  const long col = p.col_base + 32 * s + 8 * q;
+  p.img[((size_t)(w * p.S + p.step0 + s) * 2 + f) * 64 + lane] = *reinterpret_cast<const uint4*>(p.w + row * p.ld + col);
+}
+
+int pack_phase(const void* w, int ld, int C, int S, int step0, int row_base, int col_base, void* img, hipStream_t s) {
+  DeepPackP p;
+  p.w = (const bf16_t*)w; p.img = (uint4*)img; p.ld = ld; p.C = C; p.S = S; p.step0 = step0; p.row_base = row_base;
+  p.col_base = col_base;
+  const int units = (C / 32) * (C / 32) * 128;
+  hipLaunchKernelGGL(deep_pack_kernel, dim3((units + 255) / 256), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? CDSEG_OK : CDSEG_ERR_LAUNCH;
+}
+
+// rows per workgroup: 128 when that still gives most CUs a workgroup, else 32 (single scenes, the deepest levels)
+inline int pick_bm(long n) { return (n + 127) / 128 >= 160 ? 128 : 32; }
+
+template <int C, int BM>
+int launch_head(const DeepHeadP& p, hipStream_t s) {
+  constexpr int lds = DeepCfg<C, BM>::HEAD_LDS;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)deep_head_kernel<C, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((deep_head_kernel<C, BM>), dim3((unsigned)((p.n + BM - 1) / BM)), dim3(2 * C), lds, s, p);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+template <int C, int BM>
+int launch_tail(const DeepTailP& p, hipStream_t s) {
+  constexpr int lds = DeepCfg<C, BM>::TAIL_LDS;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)deep_tail_kernel<C, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return CDSEG_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((deep_tail_kernel<C, BM>), dim3((unsigned)((p.n + BM - 1) / BM)), dim3(2 * C), lds, s, p);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+}  // namespace
+
+bool deep_supported(int channels) { return channels == 128 || channels == 256; }
+
+int deep_pack(int C, const void* wl, const void* wqkv, void* head_img, const void* wp, const void* w1, const void* w2,
+              void* tail_img, hipStream_t s) {
+  if (!deep_supported(C)) return CDSEG_ERR_UNSUPPORTED;
+  const int KS = C / 32;
+  int rc;
+  if (head_img) {
+    if (!wl || !wqkv) return CDSEG_ERR_ARG;
+    if ((rc = pack_phase(wl, C, C, 4 * KS, 0, 0, 0, head_img, s)) != CDSEG_OK) return rc;
+    for (int c = 0; c < 3; ++c)
+      if ((rc = pack_phase(wqkv, C, C, 4 * KS, KS * (1 + c), c * C, 0, head_img, s)) != CDSEG_OK) return rc;
+  }
+  if (tail_img) {
+    if (!wp || !w1 || !w2) return CDSEG_ERR_ARG;
+    if ((rc = pack_phase(wp, C, C, 9 * KS, 0, 0, 0, tail_img, s)) != CDSEG_OK) return rc;
+    for (int j = 0; j < 4; ++j) {
+      if ((rc = pack_phase(w1, C, C, 9 * KS, KS * (1 + 2 * j), j * C, 0, tail_img, s)) != CDSEG_OK) return rc;
+      if ((rc = pack_phase(w2, 4 * C, C, 9 * KS, KS * (2 + 2 * j), 0, j * C, tail_img, s)) != CDSEG_OK) return rc;
+    }
+  }
+  return CDSEG_OK;
+}
+
+int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b, float* x,
+              int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
+              int ldqkv, long n, int channels, hipStream_t s) {
+  DeepHeadP p;
+  p.y = (const bf16_t*)y; p.wimg = (const uint4*)head_img; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
+  p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.bqkv = bqkv; p.qkv = (bf16_t*)qkv;
+  p.n = n; p.ldy = ldy; p.ldx = ldx; p.ldqkv = ldqkv; p.eps = eps;
+  const int bm = cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
+  if (channels == 128) return bm == 128 ? launch_head<128, 128>(p, s) : launch_head<128, 32>(p, s);
+  if (channels == 256) return bm == 128 ? launch_head<256, 128>(p, s) : launch_head<256, 32>(p, s);
+  return CDSEG_ERR_UNSUPPORTED;
+}
+
+int deep_tail(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b, float eps,
+              const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n, int channels, hipStream_t s) {
+  DeepTailP p;
+  p.o = (const bf16_t*)o; p.wimg = (const uint4*)tail_img; p.bp = bp; p.ln_g = ln_g; p.ln_b = ln_b; p.b1 = b1; p.b2 = b2;
+  p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldo = ldo; p.ldx = ldx; p.ldxc = ldxc; p.eps = eps;
+  const int bm = cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
+  if (channels == 128) return bm == 128 ? launch_tail<128, 128>(p, s) : launch_tail<128, 32>(p, s);
+  if (channels == 256) return bm == 128 ? launch_tail<256, 128>(p, s) : launch_tail<256, 32>(p, s);
+  return CDSEG_ERR_UNSUPPORTED;
+}

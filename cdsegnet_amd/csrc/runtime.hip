@@ -1,5 +1,6 @@
 // Native executor for one PTv3 Block (ref: ptv3.py:399-428; big stages: conv, fused head, attention, fused tail;
-// deep stages: conv, cpe linear, qkv, attention, proj, fc1, fc2 + their second-pass kernels): issues all launches of the block
+// deep stages C = 128 / 256: conv, fused head, attention, fused tail (deep.hip); C = 512 and fp32: conv, cpe linear, qkv,
+// attention, proj, fc1, fc2 + their second-pass kernels): issues all launches of the block
 // from C++ so the Python binding pays one call instead of ~10 (the per-launch host cost of the
 // binding, ~10 us, was the step's critical path once the kernels were fast).
 #include <cstdlib>
@@ -100,7 +101,10 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
     if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
   }
   static const bool fused_head = cdseg_knob("CDSEG_FUSED_HEAD", 1) != 0;
-  const bool head = fused_head && T == CDSEG_BF16 && (C == 32 || C == 64);
+  // deep stages (C = 128 / 256) with weight-stream images: head and tail are one launch each (deep.hip)
+  static const bool deep_on = cdseg_knob("CDSEG_DEEP_FUSED", 1) != 0;
+  const bool deep = deep_on && T == CDSEG_BF16 && (C == 128 || C == 256) && d->hidden == 4 * C;
+  const bool head = (fused_head && T == CDSEG_BF16 && (C == 32 || C == 64)) || (deep && d->head_img);
   if (head && d->head_img) {
     // wide stages: weights resident in LDS, activations in registers (blockrr.hip)
     if ((rc = cdseg_cpe_head_rr(L.y, C, d->head_img, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
@@ -150,6 +154,11 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
       return rc;
   }
   static const bool fused_tail = cdseg_knob("CDSEG_FUSED_TAIL", 1) != 0 && cdseg_knob("CDSEG_FUSED_MLP", 1) != 0;
+  if (deep && d->tail_img) {
+    void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
+    return cdseg_attn_tail_rr(L.o, C, d->tail_img, (const float*)d->proj_b, (const float*)d->norm2_g, (const float*)d->norm2_b,
+                              d->ln_eps, (const float*)d->fc1_b, (const float*)d->fc2_b, (float*)io->x, C, xc, C, n, C, stream);
+  }
   if (fused_tail && T == CDSEG_BF16 && (C == 32 || C == 64) && d->hidden == 4 * C) {
     // big stages: proj + residual + LN2 + MLP in one launch; h and the hidden activation never leave the CU
     void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;

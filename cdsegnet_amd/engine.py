@@ -364,7 +364,7 @@ class Engine:
             if hasattr(ops, "block_rr_pack") and ops.block_rr_ok(mod.channels, T) and w[pre + ".fc1.w"].shape[0] == 4 * mod.channels:
                 himg, w[pre + ".tail_img"] = ops.block_rr_pack(
                     mod.channels, w[pre + ".cpe1.w"], w[pre + ".qkv.w"], w[pre + ".proj.w"], w[pre + ".fc1.w"], w[pre + ".fc2.w"])
-                if ops.block_rr_head_on():  # measured slower than the 64-row-tile fused head (memory bound either way)
+                if ops.block_rr_head_on(mod.channels):  # C = 32 / 64: slower than the 64-row-tile fused head; deep: on
                     w[pre + ".head_img"] = himg
         self.native_blocks = hasattr(ops, "block_forward") and self.use_native_blocks
         if self.native_blocks:
@@ -614,7 +614,12 @@ class Engine:
             st.xc = xc_out
             return
         qkv = self._buf(n, 3 * c, self.T)
-        if ops.cpe_head_fused_ok(st.xc):  # big stages: cpe linear + LN + residual + LN1 + qkv in one launch
+        if (pre + ".head_img") in w and not ops.cpe_head_fused_ok(st.xc):  # deep stages (C = 128 / 256): csrc/deep.hip
+            y = self._buf(n, c, self.T)
+            self._conv3(st.xc, pre + ".cpe0", lv, y)
+            ops.cpe_head_rr(y, w[pre + ".head_img"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
+                            tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.b"], qkv)
+        elif ops.cpe_head_fused_ok(st.xc):  # big stages: cpe linear + LN + residual + LN1 + qkv in one launch
             y = self._buf(n, c, self.T)
             self._conv3(st.xc, pre + ".cpe0", lv, y)
             if (pre + ".head_img") in w:
@@ -635,6 +640,11 @@ class Engine:
         ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
                       att.scale, o, work=64.0 * att.num_heads * sum_l2)
         hid = w[pre + ".fc1.w"].shape[0]
+        if (pre + ".tail_img") in w and not ops.attn_tail_fused_ok(o, hid):  # deep stages: proj + LN2 + MLP, one launch
+            st.xc = self._buf(n, c, self.T)
+            ops.attn_tail_rr(o, w[pre + ".tail_img"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
+                             w[pre + ".fc1.b"], w[pre + ".fc2.b"], st.x, st.xc)
+            return
         if ops.attn_tail_fused_ok(o, hid):  # big stages: proj + LN2 + MLP in one launch
             st.xc = self._buf(n, c, self.T)
             if (pre + ".tail_img") in w:

@@ -567,15 +567,19 @@ def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5)
     return x
 
 
+DEEP_CHANNELS = (128, 256)  # deep-stage head / tail kernels (csrc/deep.hip): weights streamed L2 -> registers
+
+
 def block_rr_ok(channels, dtype):
-    """Register-resident Block head / tail kernels (csrc/blockrr.hip): bf16, C = 32 / 64."""
-    return is_lp(dtype) and channels in (32, 64)
+    """Fused Block head / tail kernels on weight images: C = 32 / 64 (csrc/blockrr.hip: weights resident in LDS,
+    activations in registers) and C = 128 / 256 (csrc/deep.hip: activations resident in LDS, weights streamed), 16-bit."""
+    return is_lp(dtype) and (channels in (32, 64) or channels in DEEP_CHANNELS)
 
 
-def block_rr_head_on():
-    """The register-resident HEAD is off by default: the 64-row-tile fused head already streams at ~4.3 TB/s and measured
+def block_rr_head_on(channels=32):
+    """Deep stages: on.  The register-resident HEAD of the wide stages is off by default: the 64-row-tile fused head already streams at ~4.3 TB/s and measured
     5-10 % faster (tools/bench_block.py); the register-resident TAIL is 1.4-1.65x faster than its predecessor."""
-    return False
+    return channels in DEEP_CHANNELS
 
 
 def block_rr_pack(channels, wl, wqkv, wp, w1, w2):

@@ -298,12 +298,15 @@ def subm_conv3(x, wimg, bias, nbr_kmajor, out):
     return gemm(x, wimg, out, bias=bias, nbr=nbr_kmajor, nbr_kmajor=True, kvol=27)
 
 
+DEEP_CHANNELS = (128, 256)
+
+
 def block_rr_ok(channels, dtype):
-    return dtype == torch.bfloat16 and channels in (32, 64)
+    return dtype == torch.bfloat16 and (channels in (32, 64) or channels in DEEP_CHANNELS)
 
 
-def block_rr_head_on():
-    return False
+def block_rr_head_on(channels=32):
+    return channels in DEEP_CHANNELS
 
 
 def block_rr_pack(channels, wl, wqkv, wp, w1, w2):

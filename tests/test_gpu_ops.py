@@ -1115,3 +1115,72 @@ def test_tta_pipeline_device_vs_reference_fixture(ops):
         assert np.array_equal(got.astype(np.float32) if fx[f"aug{a}_frag0_coord"].dtype == np.float32 else got,
                               fx[f"aug{a}_frag0_coord"]), a
         pos += k
+
+
+# ------------------------------------------------------------------ deep-stage fused head / tail (csrc/deep.hip)
+def _deep_case(M, C, seed, with_t):
+    g = torch.Generator().manual_seed(seed)
+    bf = LP()
+    rnd = lambda *sh, s=1.0: _bf16_round(torch.randn(*sh, generator=g) * s)  # noqa: E731
+    d = dict(y=rnd(M, C), o=rnd(M, C), wl=rnd(C, C, s=C ** -0.5), wq=rnd(3 * C, C, s=C ** -0.5), wp=rnd(C, C, s=C ** -0.5),
+             w1=rnd(4 * C, C, s=C ** -0.5), w2=rnd(C, 4 * C, s=(4 * C) ** -0.5))
+    for k, n_ in (("bl", C), ("bq", 3 * C), ("bp", C), ("b1", 4 * C), ("b2", C), ("g1", C), ("e1", C), ("g2", C), ("e2", C),
+                  ("g3", C), ("e3", C)):
+        d[k] = torch.randn(n_, generator=g) * (0.3 if k[0] == "b" else 1.0)
+    d["cb"] = torch.randn(C, generator=g) if with_t else None
+    d["x0"] = torch.randn(M, C, generator=g)
+    return d, bf
+
+
+@LPS
+@pytest.mark.parametrize("M,C,tb", [(1000, 128, True), (4097, 256, False), (33, 256, True), (20480, 128, False),
+                                    (20481, 256, True), (130000, 128, True)])
+def test_deep_head_and_tail_vs_oracle_and_unfused_sequence(ops, lp, M, C, tb):
+    """csrc/deep.hip (C = 128 / 256: activations of a row tile resident in LDS, weights streamed L2 -> registers, 128- and
+    32-row workgroups, ragged last tile) against (i) the oracle's Block pieces in fp64 torch with the kernel's 16-bit
+    rounding points (oracle/model.py: cpe / block, ptv3.py:401-427) and (ii) the unfused HIP launches it replaces.  Same
+    products and rounding points; the fp32 summation order differs, so: residual stream within fp32 rounding of the row
+    norm, 16-bit outputs within isolated rounding-boundary flips."""
+    d, bf = _deep_case(M, C, M * 11 + C, tb)
+    D = lambda k, dt=None: None if d[k] is None else dev(d[k], dt)  # noqa: E731
+    assert ops.block_rr_ok(C, bf) and ops.block_rr_head_on(C)
+    himg, timg = ops.block_rr_pack(C, D("wl", bf), D("wq", bf), D("wp", bf), D("w1", bf), D("w2", bf))
+    f64 = lambda k: d[k].double()  # noqa: E731
+    # ---- head
+    xa, qa = D("x0"), torch.full((M, 3 * C), float("nan"), dtype=bf, device="cuda")
+    ops.cpe_head_rr(D("y", bf), himg, D("bl"), (D("g1"), D("e1")), xa, D("cb"), (D("g2"), D("e2")), D("bq"), qa)
+    t = f64("y") @ f64("wl").t() + f64("bl")
+    xr = f64("x0") + F.layer_norm(t, (C,), f64("g1"), f64("e1"), 1e-5) + (f64("cb") if tb else 0)
+    hr = _bf16_round(F.layer_norm(xr, (C,), f64("g2"), f64("e2"), 1e-5).float()).double()
+    qr = hr @ f64("wq").t() + f64("bq")
+    ex = (xa.cpu().double() - xr).abs().max().item()
+    eq = (qa.cpu().double() - qr).abs()
+    report(f"deep head M={M} C={C} {lp}", x_err=ex, qkv_max=eq.max().item(), qkv_mean=eq.mean().item())
+    assert ex < 2e-5 * C ** 0.5
+    assert eq.max().item() < (0.08 if lp == "bf16" else 0.012) and eq.mean().item() < (4e-3 if lp == "bf16" else 6e-4)
+    xb, hb, qb = D("x0"), torch.empty(M, C, dtype=bf, device="cuda"), torch.empty(M, 3 * C, dtype=bf, device="cuda")
+    ops.gemm(D("y", bf), D("wl", bf), xb, bias=D("bl"), ln_pre=(D("g1"), D("e1")), res=xb, colbias=D("cb"),
+             ln_post=(D("g2"), D("e2")), ln_out=hb)
+    ops.gemm(hb, D("wq", bf), qb, bias=D("bq"))
+    dq = (qa.float() - qb.float()).abs()
+    assert (xa - xb).abs().max().item() < 2e-5 * C ** 0.5
+    assert dq.max().item() < (0.08 if lp == "bf16" else 0.012) and dq.mean().item() < 2e-4
+    # ---- tail
+    xa, xca = D("x0"), torch.full((M, C), float("nan"), dtype=bf, device="cuda")
+    ops.attn_tail_rr(D("o", bf), timg, D("bp"), D("g3"), D("e3"), D("b1"), D("b2"), xa, xca)
+    x1 = f64("x0") + f64("o") @ f64("wp").t() + f64("bp")
+    h2 = _bf16_round(F.layer_norm(x1, (C,), f64("g3"), f64("e3"), 1e-5).float()).double()
+    u = _bf16_round(F.gelu(h2 @ f64("w1").t() + f64("b1")).float()).double()
+    ref = x1 + u @ f64("w2").t() + f64("b2")
+    e = (xa.cpu().double() - ref).abs()
+    report(f"deep tail M={M} C={C} {lp}", max_err=e.max().item(), mean_err=e.mean().item())
+    assert e.max().item() < (3e-2 if lp == "bf16" else 5e-3) and e.mean().item() < (4e-4 if lp == "bf16" else 6e-5)
+    assert torch.equal(xca, xa.to(bf))
+    xb, h2b, xcb = D("x0"), torch.empty(M, C, dtype=bf, device="cuda"), torch.empty(M, C, dtype=bf, device="cuda")
+    ops.gemm(D("o", bf), D("wp", bf), xb, bias=D("bp"), res=xb, ln_post=(D("g3"), D("e3")), ln_out=h2b)
+    ub = torch.empty(M, 4 * C, dtype=bf, device="cuda")
+    ops.gemm(h2b, D("w1", bf), ub, bias=D("b1"), act=ops.ACT_GELU)
+    ops.gemm(ub, D("w2", bf), xb, bias=D("b2"), res=xb, out2=xcb)
+    dd = (xa - xb).abs()
+    report(f"deep tail vs unfused M={M} C={C} {lp}", max_diff=dd.max().item(), mean_diff=dd.mean().item())
+    assert dd.max().item() < (3e-2 if lp == "bf16" else 5e-3) and dd.mean().item() < (1e-4 if lp == "bf16" else 2e-5)
