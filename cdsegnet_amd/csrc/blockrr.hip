@@ -16,7 +16,8 @@
 //     activation never exists outside registers;
 //   * the output channels are permuted inside the weight images so that a lane owns C/4 CONSECUTIVE channels of its
 //     point: every load / store of x, qkv, xc is a 16-byte access, 4 lanes cover a whole row.
-// What bounds the tail now is the erf-GELU on the VALU (128 per lane per 32 rows), not memory.
+// The erf-GELU (128 per lane per 32 rows) was half of the tail's VALU work as rcp + exp + Horner; it is the packed
+// polynomial form of common.h now (the hidden activation is rounded to 16 bits right after).
 #include <cstdlib>
 
 #include "common.h"
@@ -299,8 +300,8 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void tail_rr_kernel(TailRR p) {
           h0 = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[0][s]), hf[s], h0);
           h1 = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1[1][s]), hf[s], h1);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { h0[r] = gelu_erf(h0[r]); h1[r] = gelu_erf(h1[r]); }
+        gelu_lp4(h0);  // 16-bit result: the packed polynomial form (common.h)
+        gelu_lp4(h1);
         const bf16x8_t Hf = pack8(h0, h1);
 #pragma unroll
         for (int t = 0; t < CT; ++t)

@@ -150,6 +150,34 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x + 0.5f * fabsf(x) * erf_abs;  // 0.5 x (1 + sign(x) erf_abs)
 }
 
+// erf-form GELU where the result is rounded to the 16-bit type next (hidden activations of the MLPs): x Phi(x) with
+// Phi(x) - 1/2 = x Q(x^2), Q a degree-7 weighted least-squares fit on |x| <= 4 rescaled so that Phi(+-4) = 1 / 0 exactly
+// (the argument is clamped there).  |error| <= 6.5e-5 max(|x|, 1) (tools/fit_gelu.py) - 0.05 ulp of the half the value
+// becomes - in 12 full-rate VALU operations on two values at a time (v_pk_mul_f32 / v_pk_fma_f32), no transcendental;
+// gelu_erf above costs ~3x that and was the VALU half of the Block tails.  fp32 outputs keep gelu_erf.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_lp2(f32x2_t x) {
+  f32x2_t xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.f, 4.f);
+  xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.f, 4.f);
+  const f32x2_t t = xc * xc;
+  f32x2_t q = {-1.2454853377e-09f, -1.2454853377e-09f};
+  q = q * t + 1.0064627976e-07f;
+  q = q * t + -3.5656154246e-06f;
+  q = q * t + 7.3631240712e-05f;
+  q = q * t + -9.9749399351e-04f;
+  q = q * t + 9.4701653904e-03f;
+  q = q * t + -6.5824832133e-02f;
+  q = q * t + 3.9866018915e-01f;
+  const f32x2_t phi = xc * q + 0.5f;
+  return x * phi;
+}
+__device__ __forceinline__ void gelu_lp4(f32x4_t& v) {
+  const f32x2_t a = gelu_lp2(f32x2_t{v[0], v[1]}), b = gelu_lp2(f32x2_t{v[2], v[3]});
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+}
+__device__ __forceinline__ float gelu_lp(float x) { return gelu_lp2(f32x2_t{x, x})[0]; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -75,16 +75,25 @@ __device__ __forceinline__ void product(f32x4_t (&acc)[BM / 16][2], const char* 
                                         const uint4* wp, int step0, int last_step, int p, int g) {
   constexpr int KS = C / 32, NCH = C / 8, PTS = BM / 16;
   const char* xrow = bufX + p * (NCH * 16);
+  // the B fragments (activation rows) of step s + 1 are requested before the MFMAs of step s: with two waves per SIMD
+  // and only two fragments in flight per wave (what the scheduler chose on its own) every pair of reads was a
+  // full LDS round trip in front of four MFMAs
+  bf16x8_t b[2][PTS];
+  auto fetch = [&](int s, bf16x8_t (&dst)[PTS]) {
+    const char* xs = xrow + (((4 * s + g) ^ p) << 4);
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) dst[pt] = *reinterpret_cast<const bf16x8_t*>(xs + pt * 16 * (NCH * 16));
+  };
+  fetch(0, b[0]);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, ring[s % DEEP_D][0]);
     const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, ring[s % DEEP_D][1]);
-    const char* xs = xrow + (((4 * s + g) ^ p) << 4);
+    if (s + 1 < KS) fetch(s + 1, b[(s + 1) & 1]);
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) {
-      const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(xs + pt * 16 * (NCH * 16));
-      acc[pt][0] = mfma_16x16x32_bf16(a0, b, acc[pt][0]);
-      acc[pt][1] = mfma_16x16x32_bf16(a1, b, acc[pt][1]);
+      acc[pt][0] = mfma_16x16x32_bf16(a0, b[s & 1][pt], acc[pt][0]);
+      acc[pt][1] = mfma_16x16x32_bf16(a1, b[s & 1][pt], acc[pt][1]);
     }
     {
       int nx = step0 + s + DEEP_D;
@@ -348,8 +357,8 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
     if (j) lds_barrier();  // every wave is done with the previous chunk's fc2 reads of bufU
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { acc1[pt][0][r] = gelu_erf(acc1[pt][0][r]); acc1[pt][1][r] = gelu_erf(acc1[pt][1][r]); }
+      gelu_lp4(acc1[pt][0]);
+      gelu_lp4(acc1[pt][1]);
       *reinterpret_cast<uint4*>(bufU + act_off<NCH>(16 * pt + p, 4 * wave + g)) = pack8(acc1[pt][0], acc1[pt][1]);
     }
     lds_barrier();

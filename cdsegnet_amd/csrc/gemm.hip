@@ -190,7 +190,12 @@ __device__ __forceinline__ void epilogue8_bf16(const GemmP& g, long m, int n, fl
     a.x = a.x * c.sc0.x + c.sh0.x; a.y = a.y * c.sc0.y + c.sh0.y; a.z = a.z * c.sc0.z + c.sh0.z; a.w = a.w * c.sc0.w + c.sh0.w;
     b.x = b.x * c.sc1.x + c.sh1.x; b.y = b.y * c.sc1.y + c.sh1.y; b.z = b.z * c.sc1.z + c.sh1.z; b.w = b.w * c.sc1.w + c.sh1.w;
   }
-  if (g.act != CDSEG_ACT_NONE) {
+  if (g.act == CDSEG_ACT_GELU) {  // 16-bit output: the packed polynomial form (common.h), like the fused MLP kernels
+    f32x2_t t0 = gelu_lp2(f32x2_t{a.x, a.y}), t1 = gelu_lp2(f32x2_t{a.z, a.w});
+    a.x = t0[0]; a.y = t0[1]; a.z = t1[0]; a.w = t1[1];
+    t0 = gelu_lp2(f32x2_t{b.x, b.y}); t1 = gelu_lp2(f32x2_t{b.z, b.w});
+    b.x = t0[0]; b.y = t0[1]; b.z = t1[0]; b.w = t1[1];
+  } else if (g.act != CDSEG_ACT_NONE) {
     a.x = apply_act(a.x, g.act); a.y = apply_act(a.y, g.act); a.z = apply_act(a.z, g.act); a.w = apply_act(a.w, g.act);
     b.x = apply_act(b.x, g.act); b.y = apply_act(b.y, g.act); b.z = apply_act(b.z, g.act); b.w = apply_act(b.w, g.act);
   }
@@ -686,27 +691,35 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
 //     hipcc drains vmcnt(0) around compiler-visible LDS-DMA, and no other VMEM instruction lives in the loop.
 __device__ uint4 g_zero_page[8];  // 128 zero bytes: the source of a missing neighbour's row chunk
 
-template <int BM, bool GATHER = true>
+template <int BM, bool GATHER = true, int BN = 128, int NST = 2>
 struct DmaCfg {
-  static constexpr int WAVES = BM / 16, NT = WAVES * 64, BN = 128, BK = 64;
+  static constexpr int WAVES = BM / 16, NT = WAVES * 64, BK = 64;
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
-  static constexpr int A_PW = (BM / 8) / WAVES, W_PW = (BN / 8) / WAVES;  // DMA instructions per wave and step (2, 16 / WAVES)
-  static constexpr int STAGES = 2 * (A_BYTES + W_BYTES);
+  static constexpr int A_PW = (BM / 8) / WAVES, W_PW = (BN / 8) / WAVES;  // DMA instructions per wave and step (2, BN / 8 / WAVES)
+  static constexpr int STAGES = NST * (A_BYTES + W_BYTES);
   static constexpr int ITAB = GATHER ? BM * 27 * 4 : 0;  // the plain Linears carry no kernel-map table: with it a 128-row
   static constexpr int LDS = STAGES + ITAB + 1024;         // block took 79.6 KB of LDS and the CU held ONE block, not two
 };
 
-
-template <int BM, bool GATHER>
+// BN = 256, NST = 3 (deep sparse convs, C >= 256): the tile spans 256 output channels, so a gathered row is fetched once
+// per 256 instead of once per 128 columns (48 KB of A + W per 4.2 MFLOP step instead of 64), and TWO steps are in flight
+// behind the one being multiplied (144 KB of stages: one block per CU; these launches are bound by the L2 -> LDS fill
+// rate, which grows with the bytes in flight: profiles/r03_ubench_dma_depth.txt).
+// Sparse convs, all shapes: a (16-row group, kernel offset) pair none of whose rows has that neighbour is skipped - its
+// A rows are not fetched (they would be 16 copies of the zero page) and its MFMAs not issued.  On z-ordered points a
+// 16-row group has 17 - 24 of the 27 offsets where the 128-row tile has 23 - 27 (tools: DESIGN 4.2), i.e. 12 - 25 % of
+// the tile's matrix work and gathered bytes go away.
+template <int BM, bool GATHER, int BN = 128, int NST = 2>
 __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
 #ifdef CDSEG_GEMM_TIMING
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), tc0 = __builtin_readcyclecounter();
 #endif
-  using D = DmaCfg<BM, GATHER>;
-  constexpr int BN = 128, TN = 4;
+  using D = DmaCfg<BM, GATHER, BN, NST>;
+  constexpr int TN = BN / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tail = smem + D::STAGES + D::ITAB;
   int* live = reinterpret_cast<int*>(tail);  // [0] = count, [1..] = live offsets
+  int* glive = reinterpret_cast<int*>(tail + 256);  // per live offset: bit r = 16-row group r has a neighbour there
   unsigned long long* smask = reinterpret_cast<unsigned long long*>(tail + 640);
   int* itab = reinterpret_cast<int*>(smem + D::STAGES);  // [row][live slot]
 
@@ -764,6 +777,13 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
       itab[r * 27 + jl] = m < g.M ? g.nbr[m * g.nbr_sm + (long)live[1 + jl] * g.nbr_so] : -1;
     }
     __syncthreads();
+    for (int e = tid; e < nlive; e += D::NT) {
+      int mk = 0;
+      for (int r = 0; r < BM; ++r)
+        if (itab[r * 27 + e] >= 0) mk |= 1 << (r >> 4);
+      glive[e] = mk;
+    }
+    __syncthreads();
   }
   const int KV = nlive * g.K;
   const int nkc = KV / D::BK;  // K % 64 == 0 (launch condition)
@@ -797,8 +817,19 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
   }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   auto a_stage = [&](int st) { return lds_base + st * D::A_BYTES; };
-  auto w_stage = [&](int st) { return lds_base + 2 * D::A_BYTES + st * D::W_BYTES; };
+  auto w_stage = [&](int st) { return lds_base + NST * D::A_BYTES + st * D::W_BYTES; };
 
+  // Which of the live offsets this wave needs, as 64-bit masks over the live slots (bit jl <-> live offset jl; scalar
+  // registers, no LDS access in the K loop): m_dma - the 16-row group this wave STAGES (rows 16 wave ..) has a neighbour
+  // there; m_on0 / m_on1 - the two groups it MULTIPLIES (rows 32 wm .. / 32 wm + 16 ..) have one.
+  unsigned long long m_dma = ~0ull, m_on0 = ~0ull, m_on1 = ~0ull;
+  if (GATHER) {
+    const int gl = lane < nlive ? glive[lane] : 0;
+    m_dma = __ballot((gl >> wave) & 1);
+    m_on0 = __ballot((gl >> (2 * wm)) & 1);
+    m_on1 = __ballot((gl >> (2 * wm + 1)) & 1);
+  }
+  auto slot_of = [&](int kc) -> int { return GATHER ? ((kc * D::BK) >> kshift) : 0; };
   // gather indices of the step to be issued next (LDS reads, one step ahead of their DMA)
   int idx_n[D::A_PW];
   auto fetch_idx = [&](int kc) {
@@ -808,7 +839,8 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
       for (int i = 0; i < D::A_PW; ++i) idx_n[i] = itab[a_row[i] * 27 + jl];
     }
   };
-  auto issue = [&](int kc, int st) {
+  // issues the DMAs of step kc into stage st; returns how many instructions this wave issued
+  auto issue = [&](int kc, int st) -> int {
     const int kv = kc * D::BK;
     int cc = kv, wcol = kv;
     if (GATHER) {
@@ -817,19 +849,23 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
       wcol = live[1 + jl] * g.K + cc;
     }
 #pragma unroll
-    for (int i = 0; i < D::A_PW; ++i) {
-      const void* src;
-      if (GATHER) {
-        const int sidx = idx_n[i];
-        src = sidx >= 0 ? (const void*)((const bf16_t*)g.A + (long)sidx * g.lda + cc + a_chunk[i] * 8)
-                        : (const void*)((const char*)g_zero_page + slot * 16);
-      } else {
-        src = a_src[i] + cc;
-      }
-      dma16(src, a_stage(st) + (wave * D::A_PW + i) * 1024);
-    }
-#pragma unroll
     for (int i = 0; i < D::W_PW; ++i) dma16(w_src[i] + wcol, w_stage(st) + (wave * D::W_PW + i) * 1024);
+    const bool a_on = (m_dma >> slot_of(kc)) & 1ull;  // this wave stages rows 16 wave .. 16 wave + 15 = group `wave`
+    if (a_on) {
+#pragma unroll
+      for (int i = 0; i < D::A_PW; ++i) {
+        const void* src;
+        if (GATHER) {
+          const int sidx = idx_n[i];
+          src = sidx >= 0 ? (const void*)((const bf16_t*)g.A + (long)sidx * g.lda + cc + a_chunk[i] * 8)
+                          : (const void*)((const char*)g_zero_page + slot * 16);
+        } else {
+          src = a_src[i] + cc;
+        }
+        dma16(src, a_stage(st) + (wave * D::A_PW + i) * 1024);
+      }
+    }
+    return a_on ? D::W_PW + D::A_PW : D::W_PW;
   };
 
   f32x4_t acc[2][TN];
@@ -839,42 +875,70 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fg = lane >> 4;
 
-  if (kc0 < kc1) {
-    fetch_idx(kc0);
-    issue(kc0, 0);
-    if (kc0 + 1 < kc1) fetch_idx(kc0 + 1);
+  // prologue: NST - 1 steps in flight
+  int pending = 0;  // instructions of the youngest issued step (the only one allowed to be outstanding when NST == 3)
+#pragma unroll
+  for (int d = 0; d < NST - 1; ++d) {
+    if (kc0 + d < kc1) {
+      fetch_idx(kc0 + d);
+      pending = issue(kc0 + d, d);
+    }
   }
+  if (kc0 + NST - 1 < kc1) fetch_idx(kc0 + NST - 1);
+  int st = 0;
 #pragma unroll 1
   for (int kc = kc0; kc < kc1; ++kc) {
-    const int st = (kc - kc0) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of step kc (the only VMEM in flight) has landed
-    __builtin_amdgcn_s_barrier();                     // ... everybody's has, and nobody still reads the other stage
+    // this wave's DMA of step kc has landed: everything but the youngest step (NST == 3) may still be in flight
+    if (NST == 2 || kc + 1 >= kc1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (pending == D::W_PW) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::W_PW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::W_PW + D::A_PW) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // ... everybody's has, and nobody still reads the stage issued into next
 #ifdef CDSEG_EXPERIMENTS
     if (!(g.dbg & 2))
 #endif
-    if (kc + 1 < kc1) {
-      issue(kc + 1, st ^ 1);
-      if (kc + 2 < kc1) fetch_idx(kc + 2);
+    if (kc + NST - 1 < kc1) {
+      int sn = st + NST - 1;
+      if (sn >= NST) sn -= NST;
+      pending = issue(kc + NST - 1, sn);
+      if (kc + NST < kc1) fetch_idx(kc + NST);
     }
 #ifdef CDSEG_EXPERIMENTS
-    if (g.dbg & 1) continue;
+    if (g.dbg & 1) { if (++st == NST) st = 0; continue; }
 #endif
     const char* As = smem + st * D::A_BYTES;
-    const char* Bs = smem + 2 * D::A_BYTES + st * D::W_BYTES;
+    const char* Bs = smem + NST * D::A_BYTES + st * D::W_BYTES;
+    const int jl = slot_of(kc);
+    const bool on0 = (m_on0 >> jl) & 1ull, on1 = (m_on1 >> jl) & 1ull;
+    if (on0 || on1) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t a[2], b[TN];
+      for (int kk = 0; kk < 2; ++kk) {
+        // the fragments of a K half are requested before the branch (a dead group's A rows are stale bytes, never used)
+        bf16x8_t a[2], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off<8>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+        for (int i = 0; i < 2; ++i)
+          a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off<8>(wm * 32 + i * 16 + fr, 4 * kk + fg));
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<8>(wn * 64 + j * 16 + fr, 4 * kk + fg));
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<8>(wn * (BN / 2) + j * 16 + fr, 4 * kk + fg));
+        if (on0 && on1) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_16x16x32_bf16(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_16x16x32_bf16(a[i], b[j], acc[i][j]);
+        } else if (on0) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[0][j] = mfma_16x16x32_bf16(a[0], b[j], acc[0][j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[1][j] = mfma_16x16x32_bf16(a[1], b[j], acc[1][j]);
+        }
+      }
     }
+    if (++st == NST) st = 0;
   }
   __syncthreads();  // all fragment reads done: the stages become the C tile
 #ifdef CDSEG_EXPERIMENTS
@@ -939,8 +1003,14 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     }
   }
   const int gm = (int)((p.M + bm - 1) / bm);
+  // deep sparse convs (C >= 256): 256-column tiles on a three-stage ring, one block per CU (gemm_dma_kernel<128, true, 256, 3>)
+  bool wide = false;
+  if constexpr (GATHER && NCH == 16 && sizeof(CT) == 2) {
+    static const int wide_on = cdseg_knob("CDSEG_CONV_WIDE", 0);  // measured slower (r04): see DESIGN 4.2
+    wide = wide_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= 256 && (p.N % 256) == 0 && !ln;
+  }
   // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
-  const int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+  const int bn = wide ? 256 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
   const int gn = (p.N + bn - 1) / bn;
   // split-K when the output tiles alone cannot fill the chip (deep stages: few points, long reductions)
   int splits = 1;
@@ -952,11 +1022,17 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     int smax = (int)(nkc / 2);
     if (smax > split_max) smax = split_max;
     while (smax > 1 && (size_t)smax * p.M * p.N * sizeof(float) > ws_bytes) --smax;
-    splits = (int)((split_target + blocks - 1) / blocks);
+    if (wide) {
+      // one block per CU: as many K slices as keep the grid within one round of the chip
+      splits = (int)(256 / blocks);
+    } else {
+      splits = (int)((split_target + blocks - 1) / blocks);
+    }
     if (splits > smax) splits = smax;
     // prefer a slice count (column tiles x splits) that spreads evenly over the 8 XCDs
-    for (int c = splits; c <= smax && c < splits + 4; ++c)
-      if ((gn * c) % 8 == 0) { splits = c; break; }
+    if (!wide)
+      for (int c = splits; c <= smax && c < splits + 4; ++c)
+        if ((gn * c) % 8 == 0) { splits = c; break; }
     if (splits < 1) splits = 1;
   }
   p.fix = 0;
@@ -986,7 +1062,21 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     static const int dma_on = cdseg_knob("CDSEG_GEMM_DMA", 1);
     static const int dma_bm = cdseg_knob("CDSEG_GEMM_DMA_BM", 0);
     const bool fused_ln_here = ln && gn == 1 && splits == 1;  // complete rows in one 64-row block: stays on the old loop
-    if (dma_on && bn == 128 && (p.K % 64) == 0 && (!GATHER || (p.kshift >= 6 && p.kvol <= 27)) && !fused_ln_here &&
+    if constexpr (GATHER) {
+      if (wide && dma_on && p.kshift >= 6) {
+        launched = true;
+        using W = DmaCfg<128, true, 256, 3>;
+        static bool aw = false;
+        if (!aw) {
+          if (hipFuncSetAttribute((const void*)gemm_dma_kernel<128, true, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  W::LDS) != hipSuccess)
+            return CDSEG_ERR_LAUNCH;
+          aw = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<128, true, 256, 3>), grid, dim3(512), W::LDS, s, p);
+      }
+    }
+    if (!launched && dma_on && bn == 128 && (p.K % 64) == 0 && (!GATHER || (p.kshift >= 6 && p.kvol <= 27)) && !fused_ln_here &&
         p.M >= 128 && dma_use_bm == bm) {
       launched = true;
       (void)dma_bm;

@@ -205,12 +205,15 @@ __global__ __launch_bounds__(4 * BM) void mlp_fused_kernel(MlpP p) {
       const float bias = p.b1[HT * j + col];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
+      {
+        f32x4_t hv = acc1[i][t] + bias;
+        gelu_lp4(hv);  // 16-bit result: the packed polynomial form (common.h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wm * 32 + i * 16 + fg * 4 + r;
-          *reinterpret_cast<bf16_t*>(Hs + mlp_lds_off<NCH>(row, col >> 3) + (col & 7) * 2) =
-              f32_to_bf16(gelu_erf(acc1[i][t][r] + bias));
+          *reinterpret_cast<bf16_t*>(Hs + mlp_lds_off<NCH>(row, col >> 3) + (col & 7) * 2) = f32_to_bf16(hv[r]);
         }
+      }
     }
     __syncthreads();
 

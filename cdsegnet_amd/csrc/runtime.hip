@@ -49,6 +49,11 @@ Layout carve(const cdseg_block_desc* d, long n, void* scratch) {
   const long tiles = ((n + 63) / 64) * (((long)C + 127) / 128);
   L.ws_bytes = tiles < 256 ? (size_t)32 * n * (size_t)(3 * C > (size_t)d->hidden ? 3 * C : d->hidden) * 4
                            : (C > 128 ? (size_t)n * C * 4 : 0);
+  // the deep sparse convs (C >= 256: 128 x 256 tiles, one block per CU) split K while their grid is below 256 blocks
+  if (C >= 256 && ((n + 127) / 128) * (((long)C + 255) / 256) < 256) {
+    const size_t want = (size_t)8 * n * C * 4;
+    if (want > L.ws_bytes) L.ws_bytes = want;
+  }
   if (L.ws_bytes > SPLITK_WS_CAP) L.ws_bytes = SPLITK_WS_CAP;
   L.ws = L.ws_bytes ? c.take(L.ws_bytes) : nullptr;
   L.total = align_up(c.off, 256);

@@ -505,6 +505,10 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     if ((m + 63) >> 6) * ((a.N + 127) >> 7) < 256:  # split-K partials: only when the output has few tiles
         ws = workspace(min(32 * m * a.N * 4, 64 << 20), out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    elif nbr is not None and a.N >= 256 and ((m + 127) >> 7) * ((a.N + 255) >> 8) < 256:
+        # deep sparse convs run 128 x 256 tiles, one block per CU: split-K while that grid is below one round of the chip
+        ws = workspace(min(8 * m * a.N * 4, 64 << 20), out.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     elif a.N > 128 and (ln_pre is not None or ln_post is not None):  # rows over several column tiles
         ws = workspace(m * a.N * 4, out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()

@@ -1183,4 +1183,38 @@ def test_deep_head_and_tail_vs_oracle_and_unfused_sequence(ops, lp, M, C, tb):
     ops.gemm(ub, D("w2", bf), xb, bias=D("b2"), res=xb, out2=xcb)
     dd = (xa - xb).abs()
     report(f"deep tail vs unfused M={M} C={C} {lp}", max_diff=dd.max().item(), mean_diff=dd.mean().item())
-    assert dd.max().item() < (3e-2 if lp == "bf16" else 5e-3) and dd.mean().item() < (1e-4 if lp == "bf16" else 2e-5)
+    # (same GELU polynomial in both; hidden values on a 16-bit rounding boundary flip with the fp32 summation order)
+    assert dd.max().item() < (3e-2 if lp == "bf16" else 5e-3) and dd.mean().item() < (4e-4 if lp == "bf16" else 6e-5)
+
+
+@LPS
+@pytest.mark.parametrize("n,C", [(5000, 256), (2100, 512), (130, 256), (40000, 128), (30000, 256)])
+def test_deep_conv_group_skipping_random_map(ops, lp, n, C):
+    """The deep-stage gathered conv (gemm.hip: 16-row groups without a neighbour at an offset are neither fetched nor
+    multiplied; C >= 256: 256-column tiles on a three-stage LDS-DMA ring, split-K when the grid is small) on a random
+    offset-major kernel map with whole dead (group, offset) pairs, dead offsets and ragged last tiles, against a plain
+    fp32 torch gather + matmul per offset on the same 16-bit operands (ref: spconv.SubMConv3d call sites ptv3.py:356-362)."""
+    g = torch.Generator().manual_seed(n + C)
+    bf = LP()
+    ngrp = (n + 15) // 16
+    grp_on = torch.rand(27, ngrp, generator=g) > 0.35
+    grp_on[3] = False  # an offset nobody has
+    grp_on[:, : max(1, ngrp // 7)] &= torch.rand(27, 1, generator=g) > 0.5  # tiles with few live offsets
+    row_on = (torch.rand(27, n, generator=g) > 0.5) & grp_on.repeat_interleave(16, dim=1)[:, :n]
+    nbr = torch.where(row_on, torch.randint(0, n, (27, n), generator=g), torch.full((27, n), -1)).int()
+    x = _bf16_round(torch.randn(n, C, generator=g))
+    w = _bf16_round(torch.randn(C, 27, C, generator=g) / (13 * C) ** 0.5)
+    b = torch.randn(C, generator=g)
+    xd, wd, nd = dev(x), dev(w), dev(nbr)
+    ref = dev(b).repeat(n, 1)
+    for o in range(27):
+        idx = nd[o].long()
+        ref += torch.where((idx >= 0)[:, None], xd[idx.clamp(min=0)], torch.zeros((), device="cuda")) @ wd[:, o, :].t()
+    out = torch.full((n, C), float("nan"), dtype=bf, device="cuda")
+    ops.gemm(dev(x, bf), dev(w.reshape(C, -1), bf), out, bias=dev(b), nbr=nd, nbr_kmajor=True, kvol=27)
+    err = (out.float() - ref).abs().max().item()
+    report(f"deep conv random map n={n} C={C} {lp}", max_err=err, ref_max=ref.abs().max().item())
+    assert err < (0.04 if lp == "bf16" else 0.006)  # 16-bit rounding of outputs of magnitude ~4
+    out32 = torch.empty(n, C, dtype=torch.float32, device="cuda")
+    ops.gemm(dev(x, bf), dev(w.reshape(C, -1), bf), out32, bias=dev(b), nbr=nd, nbr_kmajor=True, kvol=27)
+    assert (out32 - ref).abs().max().item() < 2e-4
