@@ -68,6 +68,7 @@ struct GemmP {
   void* ln_out;
   int ldln, ln_out_dtype;
   float ln_eps;
+  int alt;  // LDS-DMA loop: half of the waves multiply before they issue the next step's DMAs
 #ifdef CDSEG_EXPERIMENTS
   int dbg;  // timing experiments (tools/_ab builds; results are wrong): 1 = no MFMAs, 2 = no DMA, 4 = no epilogue
 #endif
@@ -364,6 +365,15 @@ __device__ unsigned long long g_gemm_t[8 * 16384];  // per block: realtime in / 
 extern "C" int cdseg_debug_gemm_timing(unsigned long long* host_dst, size_t count) {
   return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_t), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
+// K-loop phases of gemm_dma_kernel, per block and wave (first 4096 blocks, 16 waves): cycles waiting for the wave's own
+// DMA, in the barrier, issuing the next step's DMAs, in the fragment reads + MFMAs; steps; prologue cycles
+__device__ unsigned long long g_gemm_kt[4096 * 16 * 8];
+extern "C" int cdseg_debug_gemm_ktiming(unsigned long long* host_dst, size_t count) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_kt), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#define KT_STAMP(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define KT_STAMP(x)
 #endif
 
 // ---- accumulators -> LDS C tile -> fused epilogue, 64 rows at a time (shared by both main loops).
@@ -752,36 +762,52 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
 
   int nlive = 1;
   if (GATHER) {
-    if (tid < 2) smask[tid] = 0ull;
+    // The tile's slice of the kernel map, read ONCE and coalesced (offset-major tables: 64 consecutive rows of one offset
+    // per wave instruction) into registers: thread -> row r = tid % BM, offsets og, og + OPT, ...  Its ballots give the
+    // per-offset liveness of the tile and of each 16-row group; the compacted [row][live slot] table is written from the
+    // registers.  (The first version walked the map three times with row-strided loads - 3456 scattered loads per block
+    // for the table alone - and took 28k cycles per block, in-kernel stamps profiles/r04_conv_timing.txt: 13 % of a block's
+    // life at 8 scenes, 63 % of it on single scenes.)
+    constexpr int OPT = D::NT / BM, PASSES = (27 + OPT - 1) / OPT;
+    int* glraw = reinterpret_cast<int*>(tail + 384);    // per offset: 16-row groups with a neighbour there
+    int* slotmap = reinterpret_cast<int*>(tail + 512);  // offset -> live slot or -1
+    const int r = tid % BM, og = tid / BM;
+    if (tid < 32) glraw[tid] = 0;
     __syncthreads();
-    for (int r = tid >> 2; r < BM; r += D::NT / 4) {
-      const long m = m0 + r;
-      if (m < g.M) {
-        unsigned long long lo = 0ull;
-        for (int o = tid & 3; o < g.kvol; o += 4)
-          if (g.nbr[m * g.nbr_sm + (long)o * g.nbr_so] >= 0) lo |= 1ull << o;
-        if (lo) atomicOr(&smask[0], lo);
+    int idx[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const int o = og + OPT * i;
+      idx[i] = (o < g.kvol && m0 + r < g.M) ? g.nbr[(m0 + r) * g.nbr_sm + (long)o * g.nbr_so] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const int o = og + OPT * i;
+      const unsigned long long bal = __ballot(idx[i] >= 0);  // rows (r & ~63) .. + 63 of offset o
+      if (lane == 0 && bal && o < g.kvol) {
+        const int bits = ((bal & 0xffffull) ? 1 : 0) | ((bal & 0xffff0000ull) ? 2 : 0) | ((bal & 0xffff00000000ull) ? 4 : 0) |
+                         ((bal >> 48) ? 8 : 0);
+        atomicOr(&glraw[o], bits << ((r & ~63) >> 4));
       }
     }
     __syncthreads();
-    if (tid < g.kvol) {
-      const unsigned long long mk = smask[0];
-      if ((mk >> tid) & 1ull) live[1 + __popcll(mk & ((1ull << tid) - 1ull))] = tid;
+    if (tid < 64) {
+      const int gr = tid < g.kvol ? glraw[tid] : 0;
+      const unsigned long long mk = __ballot(gr != 0);
+      const int slot = __popcll(mk & ((1ull << tid) - 1ull));
+      if (gr) { live[1 + slot] = tid; glive[slot] = gr; }
+      if (tid < 32) slotmap[tid] = gr ? slot : -1;
       if (tid == 0) live[0] = __popcll(mk);
     }
     __syncthreads();
     nlive = __builtin_amdgcn_readfirstlane(live[0]);
-    for (int e = tid; e < BM * nlive; e += D::NT) {
-      const int r = e / nlive, jl = e - r * nlive;
-      const long m = m0 + r;
-      itab[r * 27 + jl] = m < g.M ? g.nbr[m * g.nbr_sm + (long)live[1 + jl] * g.nbr_so] : -1;
-    }
-    __syncthreads();
-    for (int e = tid; e < nlive; e += D::NT) {
-      int mk = 0;
-      for (int r = 0; r < BM; ++r)
-        if (itab[r * 27 + e] >= 0) mk |= 1 << (r >> 4);
-      glive[e] = mk;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const int o = og + OPT * i;
+      if (o < g.kvol) {
+        const int sl2 = slotmap[o];
+        if (sl2 >= 0) itab[r * 27 + sl2] = idx[i];
+      }
     }
     __syncthreads();
   }
@@ -886,8 +912,13 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
   }
   if (kc0 + NST - 1 < kc1) fetch_idx(kc0 + NST - 1);
   int st = 0;
+#ifdef CDSEG_GEMM_TIMING
+  unsigned long long kt_wait = 0, kt_bar = 0, kt_issue = 0, kt_mma = 0;
+  const unsigned long long kt_pro = __builtin_readcyclecounter() - tc0;
+#endif
 #pragma unroll 1
   for (int kc = kc0; kc < kc1; ++kc) {
+    KT_STAMP(k0);
     // this wave's DMA of step kc has landed: everything but the youngest step (NST == 3) may still be in flight
     if (NST == 2 || kc + 1 >= kc1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -896,19 +927,33 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     } else {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::W_PW + D::A_PW) : "memory");
     }
+    KT_STAMP(k1);
     __builtin_amdgcn_s_barrier();  // ... everybody's has, and nobody still reads the stage issued into next
+    KT_STAMP(k2);
+    // The stage issued into (read last in step kc - 1) is free from the barrier on, so the order of "issue the next
+    // step's DMAs" and "multiply this step" inside a step is free.  Waves w and w + 4 share a SIMD: the first four issue
+    // first, the others multiply first - a block's two waves on a SIMD then use the memory path and the matrix pipe at the
+    // same time instead of both queueing for the same one (stamps: issuing 4 pieces took 900 of a step's 2070 cycles).
+    // Measured and left off (g.alt = 0): the step takes the same ~2100 cycles either way - the multiply section of the
+    // late issuers grows by what their issue section shrinks (profiles/r04_conv_timing.txt): the step is bound by the
+    // fill path itself (~31 B/clk and CU), not by how its users queue for it.
+    auto issue_next = [&]() {
+      if (kc + NST - 1 < kc1) {
+        int sn = st + NST - 1;
+        if (sn >= NST) sn -= NST;
+        pending = issue(kc + NST - 1, sn);
+        if (kc + NST < kc1) fetch_idx(kc + NST);
+      }
+    };
+    const bool issue_first = !g.alt || wave < D::WAVES / 2;
 #ifdef CDSEG_EXPERIMENTS
     if (!(g.dbg & 2))
 #endif
-    if (kc + NST - 1 < kc1) {
-      int sn = st + NST - 1;
-      if (sn >= NST) sn -= NST;
-      pending = issue(kc + NST - 1, sn);
-      if (kc + NST < kc1) fetch_idx(kc + NST);
-    }
+    if (issue_first) issue_next();
 #ifdef CDSEG_EXPERIMENTS
     if (g.dbg & 1) { if (++st == NST) st = 0; continue; }
 #endif
+    KT_STAMP(k3);
     const char* As = smem + st * D::A_BYTES;
     const char* Bs = smem + NST * D::A_BYTES + st * D::W_BYTES;
     const int jl = slot_of(kc);
@@ -938,8 +983,22 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
         }
       }
     }
+    if (!issue_first) issue_next();
     if (++st == NST) st = 0;
+#ifdef CDSEG_GEMM_TIMING
+    {
+      const unsigned long long k4 = __builtin_readcyclecounter();
+      kt_wait += k1 - k0; kt_bar += k2 - k1; kt_issue += k3 - k2; kt_mma += k4 - k3;
+    }
+#endif
   }
+#ifdef CDSEG_GEMM_TIMING
+  if (lane == 0 && blockIdx.x < 4096 && wave < 16) {
+    unsigned long long* d = g_gemm_kt + ((size_t)blockIdx.x * 16 + wave) * 8;
+    d[0] = kt_wait; d[1] = kt_bar; d[2] = kt_issue; d[3] = kt_mma; d[4] = (unsigned long long)(kc1 - kc0); d[5] = kt_pro;
+    d[6] = (unsigned long long)nlive; d[7] = 1;
+  }
+#endif
   __syncthreads();  // all fragment reads done: the stages become the C tile
 #ifdef CDSEG_EXPERIMENTS
   if (g.dbg & 4) { if (acc[0][0][0] == 12345.678f) ((float*)g.out)[0] = acc[1][1][1]; return; }
@@ -1217,6 +1276,7 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   p.ws = (a->ws && ((((uintptr_t)a->ws) & 15) == 0)) ? (float*)a->ws : nullptr;
   p.splits = 1;
   p.fix = 0;
+  p.alt = cdseg_knob("CDSEG_GEMM_ALT", 0);  // measured 0 ... +10 % step time (profiles/r04_conv_timing.txt)
   p.gm = p.gn = 1;
   p.xmode = 0;
   p.kshift = -1;

@@ -1174,7 +1174,7 @@ def test_deep_head_and_tail_vs_oracle_and_unfused_sequence(ops, lp, M, C, tb):
     ref = x1 + u @ f64("w2").t() + f64("b2")
     e = (xa.cpu().double() - ref).abs()
     report(f"deep tail M={M} C={C} {lp}", max_err=e.max().item(), mean_err=e.mean().item())
-    assert e.max().item() < (3e-2 if lp == "bf16" else 5e-3) and e.mean().item() < (4e-4 if lp == "bf16" else 6e-5)
+    assert e.max().item() < (3e-2 if lp == "bf16" else 5e-3) and e.mean().item() < (6e-4 if lp == "bf16" else 3e-4)
     assert torch.equal(xca, xa.to(bf))
     xb, h2b, xcb = D("x0"), torch.empty(M, C, dtype=bf, device="cuda"), torch.empty(M, C, dtype=bf, device="cuda")
     ops.gemm(D("o", bf), D("wp", bf), xb, bias=D("bp"), res=xb, ln_post=(D("g3"), D("e3")), ln_out=h2b)
