@@ -147,17 +147,40 @@ def cpu_baseline(cfg, sd, points, dataset, threads):
     torch.set_num_threads(threads)
     try:
         times = []
+        ref = None
         for i in range(4):
             t0 = time.time()
-            OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"])
+            ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"])
             if i:
                 times.append(time.time() - t0)
     finally:
         torch.set_num_threads(keep)
     med = float(np.median(times))
-    return dict(value=n / med, unit="points/s", cores=threads, kind="port",
-                sample=f"1 scene x {n} points (bench generator and model, fp32, PyTorch-CPU oracle), 1 warm-up + median of 3: "
-                       f"{med:.1f} s (runs {', '.join(f'{t:.1f}' for t in times)} s), {threads} of {os.cpu_count()} host threads")
+    out = dict(value=n / med, unit="points/s", cores=threads, kind="port",
+               sample=f"1 scene x {n} points (bench generator and model, fp32, PyTorch-CPU oracle), 1 warm-up + median of 3: "
+                      f"{med:.1f} s (runs {', '.join(f'{t:.1f}' for t in times)} s), {threads} of {os.cpu_count()} host threads")
+    return out, (inp, draws, ref)
+
+
+def parity_vs_cpu(model, dev, cpu_case, precisions):
+    """The HIP path on the cpu_baseline leg's own scene and draws against the CPU oracle's logits of that run (the oracle
+    as the checker, never as the thing measured): max |logit difference| and arg-max agreement per precision, at the
+    full 120k-point size - north_star's float bound (1e-3) is stated for the fp32 mode."""
+    inp, draws, ref = cpu_case
+    ref = ref.to(dev)
+    d = {k: torch.as_tensor(v).to(dev) for k, v in inp.items()}
+    keep_p, keep_n = model.precision, model.noise_source
+    out = {}
+    try:
+        model.noise_source = "torch_cpu"
+        for pr in precisions:
+            model.precision = pr
+            got = model.inference(dict(d), eval=False, draws=dict(draws))["seg_logits"]
+            out[pr] = dict(max_abs_logit_err_vs_cpu_oracle=float((got - ref).abs().max()),
+                           argmax_agreement_vs_cpu_oracle=float((got.argmax(1) == ref.argmax(1)).float().mean()))
+    finally:
+        model.precision, model.noise_source = keep_p, keep_n
+    return out
 
 
 def secondary_roofline(iso):
@@ -474,6 +497,19 @@ def main():
                        work=eng.forward_work(eng.last_plan))
         finally:
             eng.fork_stage = fork
+        # host side of a forward: wall and CPU time of the issuing thread from the call to the return of inference()
+        # (GPU idle at the start, no synchronisation at the end; the forward's own two host reads are inside) - what one
+        # rank's Python thread needs per forward, next to the GPU time of that forward (the scaling risk of
+        # 8 ranks on one host is this thread, not a collective)
+        hw, hc = [], []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t1, c1 = time.perf_counter(), time.thread_time()
+            model.inference(dict(fwd), eval=False)
+            hw.append(1e3 * (time.perf_counter() - t1))
+            hc.append(1e3 * (time.thread_time() - c1))
+        torch.cuda.synchronize()
+        iso["host_issue_ms"], iso["host_cpu_ms"] = float(np.median(hw)), float(np.median(hc))
         # bs = 1 latency (the reference tester's batch size, test.py:99), side-stream fork on
         one = dict(dicts[0])
         for _ in range(3):
@@ -522,6 +558,27 @@ def main():
                          reference="exact-fp32 HIP path (within 5e-6 of the reference's CPU logits, tests/)")
         model.precision = args.precision
         model.noise_source = "device"
+    parity_mode = None
+    if rank == 0 and low and not args.no_agreement:
+        # throughput of the exact-fp32 mode (the only one inside north_star's 1e-3 logit bound): 4 collated scenes per
+        # forward, one lane, the same scene generator
+        model.precision = "fp32"
+        try:
+            sub = [dict(d) for d in dicts[:4]]
+            for _ in range(2):
+                model.inference_many([dict(d) for d in sub], lanes=1, batch=4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                model.inference_many([dict(d) for d in sub], lanes=1, batch=4)
+            torch.cuda.synchronize()
+            el32 = (time.perf_counter() - t1) / 3
+            parity_mode = dict(precision="fp32", points_per_s=float(sum(sizes[:4]) / el32), ms_per_forward=1e3 * el32,
+                               scenes_per_forward=4,
+                               note="exact-fp32 MFMA path (v_mfma_f32_16x16x4_f32): within 6e-6 of the reference's CPU logits on the "
+                                    "golden fixtures (tests/test_gpu_e2e.py); the 16-bit trunk of the headline line is the IEEE-half build")
+        finally:
+            model.precision = args.precision
 
     # per-class intersection/union/target counters of the last scene: the per-scene record the reference
     # gathers over gloo (test.py:374) - here one RCCL all-reduce (random-init weights: the value is meaningless)
@@ -557,6 +614,12 @@ def main():
                        "points_per_scene_max": max(sizes), "precision": args.precision,
                        "scenes_per_step_per_gpu": scenes_per_step, "scenes_per_forward": args.scenes_per_forward,
                        "forwards_in_flight_per_gpu": args.lanes, "noise": "device Philox",
+                       "trunk_16bit_type": ("IEEE half (fp16)" if variant == "f16" else "bfloat16") if low else "none (fp32)",
+                       "trunk_16bit_note": "BASELINE.json configs[1] names bf16; the default trunk is IEEE half - the same MFMA rate and "
+                                           "bytes as bfloat16, 11 instead of 8 mantissa bits (arg-max agreement with the exact-fp32 path "
+                                           "99.94 % instead of 99.5 %; the reference's own GPU path computes its attention in half, "
+                                           "ptv3.py:282) - with fp32 residual stream, fp32 accumulation and fp32 heads; "
+                                           "--precision bf16+head runs the bfloat16 build; parity_mode = the exact-fp32 path",
                        "host_hints": ["offset_host"],
                        "host_hints_note": "the scene dicts carry offset_host (the batch offsets as Python ints) next to the "
                                           "reference's keys: saves the engine one device->host read per forward"},
@@ -615,12 +678,27 @@ def main():
                     tj = json.load(f)
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = "profiles/r03_attention_traffic.json (offline rocprofv3 --pmc passes over bench.py's own forwards)"
+        if iso and "host_issue_ms" in iso:
+            res["host_issue"] = {
+                "host_issue_ms_per_forward": iso["host_issue_ms"], "host_cpu_ms_per_forward": iso["host_cpu_ms"],
+                "host_issue_ms_per_step": iso["host_issue_ms"] * args.lanes,
+                "host_duty": iso["host_issue_ms"] * args.lanes / (1e3 * elapsed / args.steps),
+                "host_threads": os.cpu_count(),
+                "what": "one Python thread issues every launch of a rank (no data-path collective): wall / CPU time of that "
+                        "thread per collated forward, GPU idle at the start, no synchronisation at the end; host_duty = issue "
+                        "time of a step's forwards / the step's GPU-bound wall time.  N ranks need N such threads"}
         if agreement:
             res["agreement_vs_fp32"] = agreement
+        if parity_mode:
+            res["parity_mode"] = parity_mode
         m = cdist.metrics(counts)
         res["eval_counters"] = {"mIoU_random_init": m["mIoU"], "points_counted": int(counts[2].sum())}
         if args.cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_points, args.dataset, args.cpu_threads)
+            res["cpu_baseline"], cpu_case = cpu_baseline(cfg, sd, args.cpu_points, args.dataset, args.cpu_threads)
+            if low:
+                live = parity_vs_cpu(model, dev, cpu_case, ["fp32", args.precision])
+                res.setdefault("parity_mode", {"precision": "fp32"}).update(live["fp32"])
+                res["parity_vs_cpu_oracle"] = {"scene_points": int(cpu_case[2].shape[0]), **{k: v for k, v in live.items()}}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

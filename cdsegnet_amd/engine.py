@@ -188,6 +188,12 @@ class Engine:
         if precision not in self.PRECISIONS:
             raise ValueError(precision)
         self.model, self.precision = model, precision
+        bb = model.backbone
+        if getattr(bb, "condition", False) and not (bb.c_num_stages == 3 and bb.n_num_stages == 5):
+            # the c / n encoder interleave (which randperm draw a stage consumes) is hard-wired in the reference for exactly
+            # this shape (ptv3.py:1785-1794); every shipped config has it - reject anything else here, not mid-forward
+            raise ValueError(f"conditional PT-v3m1 needs 3 c-branch and 5 n-branch stages (ptv3.py:1785-1794), got "
+                             f"{bb.c_num_stages} / {bb.n_num_stages}")
         self.variant = variant or ("f16" if precision.startswith("fp16") else "bf16")
         self.T = torch.float32 if precision == "fp32" else ops.LP_DTYPES[self.variant]
         self.device = None
@@ -1069,7 +1075,7 @@ class Engine:
         # `fork_stage`: its throughput-bound 120k-point blocks then fill the CUs that the dominant branch's deep,
         # latency-bound stages (a few hundred to a few thousand points) leave idle.
         if cond:
-            assert bb.c_num_stages == 3 and bb.n_num_stages == 5, "interleave hard-wired as in ptv3.py:1785-1794"
+            # (3 c-branch / 5 n-branch stages: checked in Engine.__init__)
             p_c1, p_n1, p_n2, p_c2, p_n3, p_n4 = (next(pi) for _ in range(6))
             n_perms = [None, p_n1, p_n2, p_n3, p_n4]
 

@@ -14,6 +14,8 @@ of the tail) with the gradient of its input and of every parameter (weights, bia
 conv kernel).  Scope: one Block in eval mode (DropPath = identity); pooling / unpooling, the loss and the
 optimizer are the next steps of SURVEY 8(f4)'s training row; gradient all-reduce: cdsegnet_amd.dist.GradBucketer.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -58,6 +60,30 @@ def block_tail_forward(w, pre, x0, gidx, widx, patch_start, patch_start_host, nu
     return t
 
 
+_DERIVED = {}  # id(weight tensor) -> {kind: (version, data_ptr, derived tensor)}; dropped when the weight is collected
+
+
+def _derived(src, kind):
+    """Transposed ("T": dX = dY W is the inference GEMM on W^T) or mirrored-transposed ("convT": the conv's data gradient,
+    `_conv_bwd_weight`) copy of a weight, built ONCE per weight and reused by every backward call until the weight
+    changes (an optimizer step bumps `Tensor._version`).  Rebuilding them per call handed `ops.gemm` a fresh tensor as W
+    every time: its argument cache is keyed by W's address and keeps W alive, so every Block backward pinned up to six
+    weight-sized temporaries."""
+    ent = _DERIVED.get(id(src))
+    if ent is None:
+        ent = _DERIVED[id(src)] = {}
+        weakref.finalize(src, _DERIVED.pop, id(src), None)
+    hit = ent.get(kind)
+    if hit is not None and hit[0] == src._version and hit[1] == src.data_ptr():
+        return hit[2]
+    if kind == "T":
+        t = src.t().contiguous()
+    else:
+        t = _conv_bwd_weight(src, src.shape[0], src.shape[1] // 27)
+    ent[kind] = (src._version, src.data_ptr(), t)
+    return t
+
+
 def _wgrad(w, grads, key, x, dyy):
     dw = torch.zeros_like(w[key + ".w"])
     db = torch.zeros_like(w[key + ".b"]) if w.get(key + ".b") is not None else None
@@ -83,7 +109,7 @@ def _tail_backward(w, pre, t, dy, grads):
     the tail's parameters (Linears: dW = dY^T X by cdseg_linear_wgrad, LayerNorms: d gamma / d beta); activations the
     inference kernels fuse away (LN outputs, GELU output) are recomputed."""
     n, c = t.x0.shape
-    wt = lambda k: w[k].t().contiguous()  # noqa: E731 - dX = dY W is the inference GEMM on the transposed weight
+    wt = lambda k: _derived(w[k], "T")  # noqa: E731 - dX = dY W is the inference GEMM on the transposed weight
     # y = x1 + fc2(GELU(u)):  d g = dy W2 ; d u = d g * GELU'(u) ; d h2 = d u W1
     if grads is not None:
         h2 = torch.empty_like(t.x1)
@@ -166,7 +192,7 @@ def block_backward(w, pre, tape, dy):
     grads = {}
     ops.bind_stream()
     try:
-        wt = lambda k: w[k].t().contiguous()  # noqa: E731
+        wt = lambda k: _derived(w[k], "T")  # noqa: E731
         dx0 = _tail_backward(w, pre, t, dy, grads)["d_x0"]
         # ---- CPE: x0 = x_in + LN(z), z = Linear(yc), yc = conv(x_conv)
         dz = torch.empty_like(dx0)
@@ -184,7 +210,7 @@ def block_backward(w, pre, tape, dy):
         if dbc is not None:
             grads[pre + ".cpe0.b"] = dbc
         dxc = torch.empty((n, cin), **f32)
-        ops.gemm(dyc, _conv_bwd_weight(wc, cout, cin), dxc, nbr=nbr, kvol=27, nbr_kmajor=True)
+        ops.gemm(dyc, _derived(wc, "convT"), dxc, nbr=nbr, kvol=27, nbr_kmajor=True)
     finally:
         ops.unbind_stream()
     if tape["x_conv"] is tape["x_in"]:

@@ -181,3 +181,35 @@ def test_grad_bucketer_two_ranks_gloo(tmp_path):
     one = cdist.GradBucketer()  # no process group: pass-through
     one.add("w", torch.ones(3, 3))
     assert torch.equal(one.finish()["w"], torch.ones(3, 3))
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = [900, 400, 700, 300, 650]
+        mine = cdist.shard_scenes(sizes)
+        if rank == 1:
+            mine = []  # a rank without scenes takes part in the collectives all the same
+        items = [(i, (torch.arange(sizes[i]) * (i + 3) % 20 - 1).to(torch.int64)) for i in mine]
+        got = cdist.gather_predictions(items)
+        np.savez(os.path.join(out_dir, f"g{rank}.npz"), ids=np.array(sorted(got)), **{f"s{i}": v.numpy() for i, v in got.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prediction_gather_three_ranks_gloo(tmp_path):
+    """cdist.gather_predictions: every rank ends up with every scene's labels (int16), ragged scene sizes, an idle rank."""
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    sizes = [900, 400, 700, 300, 650]
+    on_idle = set(cdist.shard_scenes(sizes, 1, 3))
+    want = sorted(set(range(5)) - on_idle)
+    for r in range(3):
+        g = np.load(tmp_path / f"g{r}.npz")
+        assert list(g["ids"]) == want
+        for i in want:
+            assert g[f"s{i}"].dtype == np.int16
+            assert np.array_equal(g[f"s{i}"], (np.arange(sizes[i]) * (i + 3) % 20 - 1).astype(np.int16))
+    single = cdist.gather_predictions([(7, torch.tensor([1, -1, 19]))])
+    assert list(single) == [7] and single[7].dtype == torch.int16
