@@ -30,6 +30,14 @@ namespace {
 
 constexpr int DEEP_D = 4;  // weight ring depth in K steps (2 fragments = 8 VGPRs per step)
 
+#ifdef CDSEG_DEEP_TIMING
+// experimental builds only (tools/deep_timing.py): cycle stamps of wave 0 of the first 2048 blocks at the phase boundaries
+__device__ unsigned long long g_deep_t[2048 * 16];
+#define DT_STAMP(k) if (wave == 0 && lane == 0 && blockIdx.x < 2048) g_deep_t[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter()
+#else
+#define DT_STAMP(k)
+#endif
+
 template <int NCH>
 __device__ __forceinline__ int act_off(int row, int chunk) {  // byte offset of 16-byte chunk `chunk` of activation row `row`
   return row * (NCH * 16) + ((chunk ^ (row & 15)) << 4);
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
   const int p = lane & 15, g = lane >> 4;
   const long m0 = (long)blockIdx.x * BM;
   const uint4* wp = P.wimg + (size_t)wave * S * 128 + lane;
+  DT_STAMP(0);
   uint4 ring[DEEP_D][2];
   prime(ring, wp, 0);
   for (int c = tid; c < C; c += NT) {
@@ -201,6 +210,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
   load_tile<C, BM>(P.y, P.ldy, m0, P.n, bufA, tid);
   const int ch0 = 32 * wave + 8 * g;  // the lane's channels: ch0 + 4 f + r
   lds_barrier();  // tile + parameters visible
+  DT_STAMP(1);
 
   f32x4_t v[PTS][2];
   {
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
   // product, the residual rows and the statistics: the compiler spilled the prefetched fragments with vmcnt(0) waits
   // inside the product); the qkv stream is primed again once the residual rows are dead
   product<C, BM>(v, bufA, ring, wp, 0, KS - 1, p, g);
+  DT_STAMP(2);
   // residual rows: needed after the first LayerNorm's statistics, requested before them (live across the product
   // - where the scheduler hoists them unless fenced - they cost 190 spilled VGPRs)
   asm volatile("" ::: "memory");
@@ -227,6 +238,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
   float mean[PTS], rstd[PTS];
   const float inv_c = 1.0f / C;
   row_stats<PTS, NW>(v, st1, st2, wave, p, g, inv_c, P.eps, mean, rstd);
+  DT_STAMP(3);
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const f32x4_t ga = *reinterpret_cast<const f32x4_t*>(pr + C + ch0 + 4 * f);
@@ -240,7 +252,9 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
       if (m < P.n) *reinterpret_cast<f32x4_t*>(P.x + m * P.ldx + ch0 + 4 * f) = v[pt][f];
     }
   }
+  DT_STAMP(4);
   row_stats<PTS, NW>(v, st1, st2, wave, p, g, inv_c, P.eps, mean, rstd);
+  DT_STAMP(5);
   prime(ring, wp, KS);
   {
     // h = LN1(x) over the tile, in place of y (every wave is past its y reads: the statistics barriers above)
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
     }
   }
   lds_barrier();
+  DT_STAMP(6);
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {  // q, k, v column blocks
     f32x4_t a[PTS][2];
@@ -270,11 +285,13 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
     int po = p;  // opaque per iteration: h is loop invariant, and its 64 fragment reads (256 VGPRs) would be hoisted
     asm volatile("" : "+v"(po));
     product<C, BM>(a, bufA, ring, wp, KS * (1 + c), S - 1, po, g);
+    DT_STAMP(7 + 2 * c);
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) {
       const long m = m0 + 16 * pt + p;
       if (m < P.n) *reinterpret_cast<uint4*>(P.qkv + m * P.ldqkv + c * C + ch0) = pack8(a[pt][0], a[pt][1]);
     }
+    DT_STAMP(8 + 2 * c);
   }
 }
 
@@ -299,6 +316,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
   const int p = lane & 15, g = lane >> 4;
   const long m0 = (long)blockIdx.x * BM;
   const uint4* wp = P.wimg + (size_t)wave * S * 128 + lane;
+  DT_STAMP(0);
   uint4 ring[DEEP_D][2];
   prime(ring, wp, 0);
   for (int c = tid; c < C; c += NT) {
@@ -318,16 +336,20 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
       for (int f = 0; f < 2; ++f) xr[pt][f] = *reinterpret_cast<const f32x4_t*>(P.x + m * P.ldx + ch0 + 4 * f);
     }
     lds_barrier();
+    DT_STAMP(1);
     const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + ch0), b1 = *reinterpret_cast<const f32x4_t*>(pr + ch0 + 4);
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) { acc2[pt][0] = b0; acc2[pt][1] = b1; }
     product<C, BM>(acc2, bufA, ring, wp, 0, S - 1, p, g);
+    DT_STAMP(2);
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) { acc2[pt][0] += xr[pt][0]; acc2[pt][1] += xr[pt][1]; }
   }
   {
     float mean[PTS], rstd[PTS];
+    DT_STAMP(3);
     row_stats<PTS, NW>(acc2, st1, st2, wave, p, g, 1.0f / C, P.eps, mean, rstd);
+    DT_STAMP(4);
     const f32x4_t ga0 = *reinterpret_cast<const f32x4_t*>(pr + C + ch0), ga1 = *reinterpret_cast<const f32x4_t*>(pr + C + ch0 + 4);
     const f32x4_t be0 = *reinterpret_cast<const f32x4_t*>(pr + 2 * C + ch0), be1 = *reinterpret_cast<const f32x4_t*>(pr + 2 * C + ch0 + 4);
 #pragma unroll
@@ -342,8 +364,15 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
     }
   }
   lds_barrier();
+  DT_STAMP(5);
+#ifdef CDSEG_DEEP_TIMING
+  unsigned long long dt_fc1 = 0, dt_gelu = 0, dt_fc2 = 0;
+#endif
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {  // hidden units C j .. C j + C - 1
+#ifdef CDSEG_DEEP_TIMING
+    const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
     f32x4_t acc1[PTS][2];
     {
       const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + j * C + ch0);
@@ -354,6 +383,9 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
     int po = p;  // opaque per iteration: h is loop invariant (see deep_head_kernel)
     asm volatile("" : "+v"(po));
     product<C, BM>(acc1, bufA, ring, wp, KS * (1 + 2 * j), S - 1, po, g);
+#ifdef CDSEG_DEEP_TIMING
+    const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
     if (j) lds_barrier();  // every wave is done with the previous chunk's fc2 reads of bufU
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) {
@@ -362,8 +394,20 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
       *reinterpret_cast<uint4*>(bufU + act_off<NCH>(16 * pt + p, 4 * wave + g)) = pack8(acc1[pt][0], acc1[pt][1]);
     }
     lds_barrier();
+#ifdef CDSEG_DEEP_TIMING
+    const unsigned long long q2 = __builtin_readcyclecounter();
+#endif
     product<C, BM>(acc2, bufU, ring, wp, KS * (2 + 2 * j), S - 1, p, g);
+#ifdef CDSEG_DEEP_TIMING
+    dt_fc1 += q1 - q0; dt_gelu += q2 - q1; dt_fc2 += __builtin_readcyclecounter() - q2;
+#endif
   }
+#ifdef CDSEG_DEEP_TIMING
+  DT_STAMP(6);
+  if (wave == 0 && lane == 0 && blockIdx.x < 2048) {
+    g_deep_t[blockIdx.x * 16 + 8] = dt_fc1; g_deep_t[blockIdx.x * 16 + 9] = dt_gelu; g_deep_t[blockIdx.x * 16 + 10] = dt_fc2;
+  }
+#endif
   {
     const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + 3 * C + ch0), b1 = *reinterpret_cast<const f32x4_t*>(pr + 3 * C + ch0 + 4);
 #pragma unroll
@@ -377,6 +421,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
       }
     }
   }
+  DT_STAMP(7);
 }
 
 // ---- weight images.  One product phase: KS steps x 2 fragments per wave.  16-byte unit
@@ -441,6 +486,12 @@ int launch_tail(const DeepTailP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef CDSEG_DEEP_TIMING
+extern "C" int cdseg_debug_deep_timing(unsigned long long* host_dst, size_t count) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_deep_t), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 bool deep_supported(int channels) { return channels == 128 || channels == 256; }
 

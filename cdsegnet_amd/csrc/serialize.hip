@@ -375,6 +375,47 @@ __global__ void nbr_from_info_kernel(const int32_t* __restrict__ grid, const int
   nbr[kmajor ? (long)o * n + i : t] = res;
 }
 
+// k = 3, offset-major output: ONE thread per point.  Along an axis the targets g - 1, g, g + 1 fall into only two of the
+// three parent cells around the point's parent (which two depends on the parity of g), so a point touches 8 parent cells,
+// not 27: 8 map reads + 8 child_info reads produce all 27 entries, the point's grid / cluster words are read once, the 27
+// stores are coalesced across threads (row i of every offset), and there is no 64-bit division per entry (the per-entry
+// form above spent 127 us on the 960k-point level of an 8-scene batch: 0.8 TB/s of its output).
+__global__ __launch_bounds__(256) void nbr3_from_info_point_kernel(const int32_t* __restrict__ grid, const int32_t* __restrict__ cluster,
+                                                                   const int32_t* __restrict__ pnbr /* (27,m) */,
+                                                                   const int64_t* __restrict__ cinfo, long n, long m, int depth,
+                                                                   int32_t* __restrict__ nbr /* (27,n) */) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int gx = grid[3 * i], gy = grid[3 * i + 1], gz = grid[3 * i + 2];
+  const int cl = cluster[i];
+  const int lim = 1 << depth;
+  // per axis: parent offset of the target at +-1 in the direction that leaves the parent cell (the other two stay inside)
+  const int px = (gx & 1) ? 1 : -1, py = (gy & 1) ? 1 : -1, pz = (gz & 1) ? 1 : -1;
+  int64_t info[8];  // parent cells (ax, ay, az) with a. in {0 = own, 1 = the neighbour}
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int dx = (q & 4) ? px : 0, dy = (q & 2) ? py : 0, dz = (q & 1) ? pz : 0;
+    const int par = pnbr[(long)((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)) * m + cl];
+    info[q] = par >= 0 ? cinfo[par] : 0;  // occupancy 0: no children
+  }
+#pragma unroll
+  for (int o = 0; o < 27; ++o) {
+    const int a = o / 9, b = (o / 3) % 3, c = o % 3;
+    const int x = gx + a - 1, y = gy + b - 1, z = gz + c - 1;
+    int res = -1;
+    if (o == 13) {
+      res = (int)i;
+    } else if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+      // the target leaves the parent cell along an axis iff it moved in that axis' "outward" direction
+      const int q = (((x >> 1) != (gx >> 1)) ? 4 : 0) | (((y >> 1) != (gy >> 1)) ? 2 : 0) | (((z >> 1) != (gz >> 1)) ? 1 : 0);
+      const int64_t w = info[q];
+      const int occ = (int)(w & 255), oct = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
+      if ((occ >> oct) & 1) res = (int)(w >> 8) + __popc(occ & ((1 << oct) - 1));
+    }
+    nbr[(long)o * n + i] = res;
+  }
+}
+
 // attention slot plan (ptv3.py:188-244 in scatter form).  For padded slot p of batch element b:
 //   local < n_b  : rank = local                       (real slot, its output is kept)
 //   local >= n_b : rank = local - K                   (borrowed from the previous patch's tail)
@@ -769,8 +810,13 @@ int cdseg_nbr_table_from_info(const int32_t* grid, const int32_t* cluster, const
   if (n <= 0) return CDSEG_OK;
   if ((ksize != 3 && ksize != 5) || m <= 0) return CDSEG_ERR_ARG;
   const long total = n * ksize * ksize * ksize;
-  hipLaunchKernelGGL(nbr_from_info_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, grid, cluster, parent_nbr3,
-                     child_info, n, m, depth, ksize, kmajor, nbr);
+  if (ksize == 3 && kmajor) {
+    hipLaunchKernelGGL(nbr3_from_info_point_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, grid, cluster, parent_nbr3,
+                       child_info, n, m, depth, nbr);
+  } else {
+    hipLaunchKernelGGL(nbr_from_info_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, grid, cluster, parent_nbr3,
+                       child_info, n, m, depth, ksize, kmajor, nbr);
+  }
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

@@ -1218,3 +1218,16 @@ def test_deep_conv_group_skipping_random_map(ops, lp, n, C):
     out32 = torch.empty(n, C, dtype=torch.float32, device="cuda")
     ops.gemm(dev(x, bf), dev(w.reshape(C, -1), bf), out32, bias=dev(b), nbr=nd, nbr_kmajor=True, kvol=27)
     assert (out32 - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("n,seed,offset", [(1, 0, 0), (4097, 54421566, 3), (720003, (1 << 61) + 12345, (1 << 40) + 7)])
+def test_device_noise_matches_the_philox_oracle(ops, n, seed, offset):
+    """cdseg_randn (the benchmark configuration's noise-branch input, `noise_source="device"`) against oracle/philox.py -
+    Philox4x32-10, pinned to the Random123 known answers in tests/test_oracle.py - on the same (seed, stream offset):
+    the integer stream is the published algorithm's, so what may differ is the last ulp of logf / sincosf."""
+    from oracle import philox as P
+    got = ops.randn((n,), seed, offset, torch.device("cuda")).cpu().numpy()
+    ref = P.randn(n, seed, offset)
+    err = float(np.abs(got - ref).max())
+    report(f"device noise n={n}", max_abs_err=err)
+    assert err < 2e-5

@@ -354,3 +354,20 @@ def test_training_forward_oracle_matches_the_reference_train_step():
         if "p1." + k in fx.files:
             assert float((new - torch.as_tensor(fx["p1." + k])).abs().max()) < 2e-6
     assert worst < 2e-2  # (first-step AdamW moves every element by ~lr: g / (|g| + eps) amplifies gradients of ~1e-8)
+
+
+def test_philox_oracle_reproduces_the_random123_known_answers():
+    """oracle/philox.py (the CPU restatement of the benchmark configuration's device noise generator) against the
+    known-answer vectors of the Random123 reference implementation of Philox4x32-10 (kat_vectors: zero, all-ones and the
+    pi-digits counter / key)."""
+    from oracle import philox as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = P.philox4x32_10(np.array(c, dtype=np.uint32), np.array(k, dtype=np.uint32))
+        assert [int(v) for v in got] == list(want)
+    z = P.randn(400001, 54421566, 3)
+    assert z.dtype == np.float32 and z.shape == (400001,) and np.isfinite(z).all()
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
