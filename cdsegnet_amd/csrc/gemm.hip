@@ -1223,6 +1223,10 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   return CDSEG_OK;
 }
 
+// (A register-resident "streaming Linear" for the shallow products around the Blocks - K = 32 / 64, N = 64, whole weight
+// in MFMA fragments, 16-row groups straight from global memory, no LDS - was built and measured in round 4: 63 instead
+// of 90 us on the plain 960k x 32 -> 64 projection, but 335 us on the un-pooling form (gather-add + two outputs through
+// 16-byte pieces) and -0.8 % end to end in a same-box A/B, profiles/r04_ab_stream_linear.txt: dropped.)
 template <typename CT, bool GATHER>
 int launch(const GemmP& p, size_t ws_bytes, hipStream_t s) {
   const long ktot = (long)p.kvol * p.K;
