@@ -343,12 +343,17 @@ int cdseg_stem5(const void* x8, const void* wimg, const float* scale, const floa
                 const int32_t* cluster, const int32_t* parent_nbr3, const int64_t* child_info, long n, long m, int depth,
                 float* out, void* out2, void* stream);
 
-/* ------------------------------------------------------------------ Block head / tail, register-resident (C = 32 / 64, bf16)
- * Same contracts as cdseg_cpe_head_fused / cdseg_attn_tail_fused, different machine mapping (csrc/blockrr.hip): all
- * weights of the kernel resident in LDS as MFMA fragments, a wave owns 32 points, activations never leave registers.
- * Images: cdseg_block_rr_img_bytes(C, 0 = head | 1 = tail); cdseg_block_rr_pack builds them once per Block from the
- * bf16 row-major weights (head: cpe linear (C,C), qkv (3C,C); tail: proj (C,C), fc1 (4C,C), fc2 (C,4C)); either image
- * pointer may be NULL. */
+/* ------------------------------------------------------------------ Block head / tail on weight images (16-bit trunk)
+ * Same contracts as cdseg_cpe_head_fused / cdseg_attn_tail_fused (ptv3.py:401-427), two machine mappings chosen by the
+ * channel count:
+ *   C = 32 / 64   (csrc/blockrr.hip) all weights of the kernel resident in LDS as MFMA fragments, a wave owns 32 points,
+ *                 the activations never leave registers;
+ *   C = 128 / 256 (csrc/deep.hip) the activations of a 128- (or 32-) row tile resident in LDS for the whole chain of products,
+ *                 the weights streamed L2 -> registers: a wave owns 32 output channels of every product, its fragments are
+ *                 stored in the image in the order it consumes them.
+ * Images: cdseg_block_rr_img_bytes(C, 0 = head | 1 = tail) bytes; cdseg_block_rr_pack builds them once per Block from the
+ * 16-bit row-major weights (head: cpe linear (C,C), qkv (3C,C); tail: proj (C,C), fc1 (4C,C), fc2 (C,4C)); either image
+ * pointer may be NULL.  Other channel counts: CDSEG_ERR_UNSUPPORTED (cdseg_gemm + cdseg_layernorm sequences). */
 size_t cdseg_block_rr_img_bytes(int channels, int which);
 int cdseg_block_rr_pack(int channels, const void* wl, const void* wqkv, void* head_img, const void* wp, const void* w1,
                         const void* w2, void* tail_img, void* stream);
@@ -361,9 +366,10 @@ int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, const float
 
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the
- * block itself, carving its temporaries from the caller's scratch buffer: sparse-conv CPE, then for bf16 with
- * C = 32 / 64 the fused head (cdseg_cpe_head_fused), window attention and the fused tail (cdseg_attn_tail_fused);
- * otherwise Linear+LayerNorms, QKV, attention, proj, MLP (cdseg_mlp_fused for bf16 C = 128) as separate launches.
+ * block itself, carving its temporaries from the caller's scratch buffer: sparse-conv CPE, then for the 16-bit trunk with
+ * C = 32 / 64 the fused head (cdseg_cpe_head_fused), window attention and the fused tail (cdseg_attn_tail_rr), with
+ * C = 128 / 256 and head_img / tail_img given the deep-stage head and tail (cdseg_cpe_head_rr / cdseg_attn_tail_rr);
+ * otherwise Linear+LayerNorms, QKV, attention, proj, MLP as separate launches.
  * Replaces ~10 host round trips through the binding by one.  Weights are described once (cdseg_block_desc), the per-scene tensors per call
  * (cdseg_block_io). */
 typedef struct cdseg_block_desc {
@@ -392,7 +398,7 @@ typedef struct cdseg_block_desc {
   const void* fc2_w;       /* (C, hidden) T */
   const float* fc2_b;
   const void* cpe_conv_wimg; /* cdseg_subm_conv3_pack image of cpe_conv_w, or NULL: the conv runs on cdseg_gemm */
-  const void* head_img;      /* cdseg_block_rr_pack images, or NULL: cdseg_cpe_head_fused / cdseg_attn_tail_fused */
+  const void* head_img;      /* cdseg_block_rr_pack images (C = 32 / 64 / 128 / 256), or NULL: the unfused / tile-fused launches */
   const void* tail_img;
 } cdseg_block_desc;
 
