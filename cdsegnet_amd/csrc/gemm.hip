@@ -378,8 +378,9 @@ extern "C" int cdseg_debug_gemm_ktiming(unsigned long long* host_dst, size_t cou
 
 // ---- accumulators -> LDS C tile -> fused epilogue, 64 rows at a time (shared by both main loops).
 // Wave (wm, wn) owns rows wm * 32 .. + 32, columns wn * BN/2 .. of the BM x BN tile; smem is free for reuse.
-template <int BN, int BM>
-__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[2][BN / 32], char* smem, int tid, int lane,
+// SQ: 16 waves as 4 x 4, a wave owns 64 rows x 64 columns (acc[4][4]); else a wave owns 32 rows x BN / 2 columns (acc[2][BN / 32])
+template <int BN, int BM, bool SQ = false, int AI = 2, int AJ = BN / 32>
+__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[AI][AJ], char* smem, int tid, int lane,
                                               int wm, int wn, long m0, int n0, int zs) {
   constexpr int NT = 4 * BM;
   constexpr int TN = BN / 32;
@@ -406,7 +407,16 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[2][
     if (hh) lds_barrier();  // the previous 64 rows have left the C tile
     int zcol = 0;  // opaque zero in the column index: keeps the per-column epilogue vectors from being hoisted out of
     if constexpr (BM > 64) asm volatile("v_mov_b32 %0, 0" : "=v"(zcol));  // the loop (and into 100+ extra VGPRs)
-    if ((wm >> 1) == hh) {
+    if constexpr (SQ) {
+      if (wm == hh) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int j = 0; j < AJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(i * 16 + fg * 4 + r) * CLD + wn * 64 + j * 16 + fr] = acc[i][j][r];
+      }
+    } else if ((wm >> 1) == hh) {
       const int rbase = (wm & 1) * 32;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -719,13 +729,20 @@ struct DmaCfg {
 // A rows are not fetched (they would be 16 copies of the zero page) and its MFMAs not issued.  On z-ordered points a
 // 16-row group has 17 - 24 of the 27 offsets where the 128-row tile has 23 - 27 (tools: DESIGN 4.2), i.e. 12 - 25 % of
 // the tile's matrix work and gathered bytes go away.
-template <int BM, bool GATHER, int BN = 128, int NST = 2>
+// SQ (BM = BN = 256, 16 waves as 4 x 4 with 64 x 64 wave tiles, split-K over the compacted offsets): the C = 512 sparse
+// convs at 8+ scenes.  A K step moves the same 4 DMA pieces per wave as the 128 x 128 tile and feeds 32 MFMAs per wave
+// instead of 16.  It did NOT deliver the 1.5x the piece arithmetic promised (stamps: one 16-wave block per CU has all its
+// waves in the same phase - nothing multiplies while they issue - and the register budget of 128 forces the fragment reads
+// behind per-group branches); what it does buy at C = 512 is traffic: two column tiles instead of four.
+template <int BM, bool GATHER, int BN = 128, int NST = 2, bool SQ = false>
 __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
 #ifdef CDSEG_GEMM_TIMING
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), tc0 = __builtin_readcyclecounter();
 #endif
   using D = DmaCfg<BM, GATHER, BN, NST>;
   constexpr int TN = BN / 32;
+  constexpr int AI = SQ ? 4 : 2, AJ = SQ ? 4 : TN;
+  static_assert(!SQ || (BM == 256 && BN == 256), "square wave tiles: 256 x 256 blocks of 16 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tail = smem + D::STAGES + D::ITAB;
   int* live = reinterpret_cast<int*>(tail);  // [0] = count, [1..] = live offsets
@@ -736,7 +753,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = SQ ? wave >> 2 : wave >> 1, wn = SQ ? wave & 3 : wave & 1;
   int mt, sl;
   {
     const int bid = blockIdx.x, slices = g.gn * g.splits;
@@ -848,12 +865,14 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
   // Which of the live offsets this wave needs, as 64-bit masks over the live slots (bit jl <-> live offset jl; scalar
   // registers, no LDS access in the K loop): m_dma - the 16-row group this wave STAGES (rows 16 wave ..) has a neighbour
   // there; m_on0 / m_on1 - the two groups it MULTIPLIES (rows 32 wm .. / 32 wm + 16 ..) have one.
-  unsigned long long m_dma = ~0ull, m_on0 = ~0ull, m_on1 = ~0ull;
+  unsigned long long m_dma = ~0ull, m_on[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) m_on[i] = ~0ull;
   if (GATHER) {
     const int gl = lane < nlive ? glive[lane] : 0;
     m_dma = __ballot((gl >> wave) & 1);
-    m_on0 = __ballot((gl >> (2 * wm)) & 1);
-    m_on1 = __ballot((gl >> (2 * wm + 1)) & 1);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) m_on[i] = __ballot((gl >> (AI * wm + i)) & 1);
   }
   auto slot_of = [&](int kc) -> int { return GATHER ? ((kc * D::BK) >> kshift) : 0; };
   // gather indices of the step to be issued next (LDS reads, one step ahead of their DMA)
@@ -894,11 +913,11 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     return a_on ? D::W_PW + D::A_PW : D::W_PW;
   };
 
-  f32x4_t acc[2][TN];
+  f32x4_t acc[AI][AJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < AJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fg = lane >> 4;
 
   // prologue: NST - 1 steps in flight
@@ -957,7 +976,31 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     const char* As = smem + st * D::A_BYTES;
     const char* Bs = smem + NST * D::A_BYTES + st * D::W_BYTES;
     const int jl = slot_of(kc);
-    const bool on0 = (m_on0 >> jl) & 1ull, on1 = (m_on1 >> jl) & 1ull;
+    if constexpr (SQ) {
+      // (all fragments of a K half ahead of its MFMAs would be the faster form - behind a branch per row group the
+      // reads are eight serial LDS round trips per step - but 64 accumulator + 32 fragment registers do not fit the 128
+      // of a 16-wave block: 175 spilled VGPRs inside the loop)
+      bool on[4], any = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { on[i] = (m_on[i] >> jl) & 1ull; any |= on[i]; }
+      if (any) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8_t b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<8>(wn * 64 + j * 16 + fr, 4 * kk + fg));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (on[i]) {
+              const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(As + lds_off<8>(wm * 64 + i * 16 + fr, 4 * kk + fg));
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32_bf16(a, b[j], acc[i][j]);
+            }
+        }
+      }
+    } else {
+    const bool on0 = (m_on[0] >> jl) & 1ull, on1 = (m_on[1] >> jl) & 1ull;
     if (on0 || on1) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -983,6 +1026,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
         }
       }
     }
+    }
     if (!issue_first) issue_next();
     if (++st == NST) st = 0;
 #ifdef CDSEG_GEMM_TIMING
@@ -1006,7 +1050,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
 #ifdef CDSEG_GEMM_TIMING
   const unsigned long long tc1 = __builtin_readcyclecounter();
 #endif
-  tile_epilogue<BN, BM>(g, acc, smem, tid, lane, wm, wn, m0, n0, zs);
+  tile_epilogue<BN, BM, SQ, AI, AJ>(g, acc, smem, tid, lane, wm, wn, m0, n0, zs);
 #ifdef CDSEG_GEMM_TIMING
   if (tid == 0 && blockIdx.x < 16384) {
     unsigned long long* d = g_gemm_t + (size_t)blockIdx.x * 8;
@@ -1061,15 +1105,26 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
       if (want > 0) bm = dma_use_bm = want;
     }
   }
+  // deep sparse convs (C >= 256) at 8+ scenes: 256 x 256 tiles, 16 waves as 4 x 4, split-K (gemm_dma_kernel<256, true, 256, 2, true>)
+  bool sq = false;
+  if constexpr (GATHER && NCH == 16 && sizeof(CT) == 2) {
+    static const int sq_on = cdseg_knob("CDSEG_CONV_SQ", 1);
+    static const int sq_min_m = cdseg_knob("CDSEG_CONV_SQ_MIN_M", 5000);
+    // C = 512 only: 117 instead of 146 us at 6.2 k rows (two column tiles instead of four gather the rows twice instead of
+    // four times, W slices are read by 25 row tiles instead of 49); C = 256: 132 vs 129 us (profiles/r04_conv_sq.txt)
+    sq = sq_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= 512 && (p.N % 256) == 0 && !ln && p.kshift >= 6 &&
+         p.M >= sq_min_m && p.ws && p.vec_ok && !p.out_idx;
+    if (sq) bm = 256;
+  }
   const int gm = (int)((p.M + bm - 1) / bm);
   // deep sparse convs (C >= 256): 256-column tiles on a three-stage ring, one block per CU (gemm_dma_kernel<128, true, 256, 3>)
   bool wide = false;
   if constexpr (GATHER && NCH == 16 && sizeof(CT) == 2) {
     static const int wide_on = cdseg_knob("CDSEG_CONV_WIDE", 0);  // measured slower (r04): see DESIGN 4.2
-    wide = wide_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= 256 && (p.N % 256) == 0 && !ln;
+    wide = !sq && wide_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= 256 && (p.N % 256) == 0 && !ln;
   }
   // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
-  const int bn = wide ? 256 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
+  const int bn = (wide || sq) ? 256 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
   const int gn = (p.N + bn - 1) / bn;
   // split-K when the output tiles alone cannot fill the chip (deep stages: few points, long reductions)
   int splits = 1;
@@ -1081,7 +1136,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     int smax = (int)(nkc / 2);
     if (smax > split_max) smax = split_max;
     while (smax > 1 && (size_t)smax * p.M * p.N * sizeof(float) > ws_bytes) --smax;
-    if (wide) {
+    if (wide || sq) {
       // one block per CU: as many K slices as keep the grid within one round of the chip
       splits = (int)(256 / blocks);
     } else {
@@ -1089,7 +1144,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     }
     if (splits > smax) splits = smax;
     // prefer a slice count (column tiles x splits) that spreads evenly over the 8 XCDs
-    if (!wide)
+    if (!wide && !sq)
       for (int c = splits; c <= smax && c < splits + 4; ++c)
         if ((gn * c) % 8 == 0) { splits = c; break; }
     if (splits < 1) splits = 1;
@@ -1107,7 +1162,8 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   const int slices = gn * splits;
   const long wbytes = (long)p.N * p.kvol * p.K * (long)sizeof(CT);
   p.xmode = 0;
-  if (slices >= 8 && wbytes >= (1 << 20) && gm > 1) p.xmode = 1;
+  if (sq) p.xmode = gm >= 64 ? 2 : 0;
+  else if (slices >= 8 && wbytes >= (1 << 20) && gm > 1) p.xmode = 1;
   else if (GATHER && gm >= 64) p.xmode = 2;
   if (xmode_env >= 0) p.xmode = (xmode_env == 1 && slices < 8) ? 0 : xmode_env;
   unsigned nblk;
@@ -1122,7 +1178,19 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     static const int dma_bm = cdseg_knob("CDSEG_GEMM_DMA_BM", 0);
     const bool fused_ln_here = ln && gn == 1 && splits == 1;  // complete rows in one 64-row block: stays on the old loop
     if constexpr (GATHER) {
-      if (wide && dma_on && p.kshift >= 6) {
+      if (sq && dma_on) {
+        launched = true;
+        using Q = DmaCfg<256, true, 256, 2>;
+        static bool aq = false;
+        if (!aq) {
+          if (hipFuncSetAttribute((const void*)gemm_dma_kernel<256, true, 256, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Q::LDS) != hipSuccess)
+            return CDSEG_ERR_LAUNCH;
+          aq = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<256, true, 256, 2, true>), grid, dim3(1024), Q::LDS, s, p);
+      }
+      if (!launched && wide && dma_on && p.kshift >= 6) {
         launched = true;
         using W = DmaCfg<128, true, 256, 3>;
         static bool aw = false;

@@ -1188,7 +1188,7 @@ def test_deep_head_and_tail_vs_oracle_and_unfused_sequence(ops, lp, M, C, tb):
 
 
 @LPS
-@pytest.mark.parametrize("n,C", [(5000, 256), (2100, 512), (130, 256), (40000, 128), (30000, 256)])
+@pytest.mark.parametrize("n,C", [(5000, 256), (2100, 512), (130, 256), (40000, 128), (30000, 256), (6100, 512)])
 def test_deep_conv_group_skipping_random_map(ops, lp, n, C):
     """The deep-stage gathered conv (gemm.hip: 16-row groups without a neighbour at an offset are neither fetched nor
     multiplied; C >= 256: 256-column tiles on a three-stage LDS-DMA ring, split-K when the grid is small) on a random
