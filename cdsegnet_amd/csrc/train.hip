@@ -9,6 +9,8 @@
 // (slot plan, padding duplicates) against the reference's autograd.  The attention core and the weight gradients run on
 // the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); LayerNorm / GELU are row kernels.  The 16-bit recompute-P form of
 // attn_bf16_kernel's backward (what an AMP training step would run) is the next step.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -372,11 +374,18 @@ extern "C" size_t cdseg_attention_bwd_ws_bytes(long num_slots, int num_heads) {
 
 extern "C" int cdseg_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
                                    const int32_t* q_gidx, const int32_t* kv_gidx, const int32_t* widx,
-                                   const int32_t* patch_start, int num_patches, int num_heads, long num_slots, int num_tiles,
+                                   const int32_t* patch_start, int num_patches, int num_heads, long num_slots, int max_len,
                                    float scale, const void* dout, int lddo, void* dq, void* dk, void* dv, int lddq, int lddk,
                                    int lddv, int dtype, void* ws, size_t ws_bytes, void* stream) {
   if (num_patches <= 0 || num_heads <= 0) return CDSEG_OK;
   if (dtype != CDSEG_F32) return CDSEG_ERR_UNSUPPORTED;  // first slice: the exact-fp32 mode
+  // the patch-head lives in LDS (like the forward): a longer patch would write past the staged K / V / statistics
+  if (max_len <= 0 || max_len > CDSEG_MAX_PATCH) return CDSEG_ERR_UNSUPPORTED;
+  if (!q || !k || !v || !dout || !dq || !dk || !dv || !patch_start) return CDSEG_ERR_ARG;
+  // float4 operand loads: 16-byte aligned rows
+  if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return CDSEG_ERR_ARG;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) != 0)
+    return CDSEG_ERR_ARG;
   if (!ws || ws_bytes < cdseg_attention_bwd_ws_bytes(num_slots, num_heads)) return CDSEG_ERR_WORKSPACE;
   AttnBwdP p;
   p.q = (const float*)q; p.k = (const float*)k; p.v = (const float*)v; p.dout = (const float*)dout;
@@ -385,14 +394,13 @@ extern "C" int cdseg_attention_bwd(const void* q, const void* k, const void* v, 
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.num_heads = num_heads; p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
-  (void)num_tiles;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BW_Q_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BW_KV_LDS) != hipSuccess)
-      return CDSEG_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag attr_once;  // (one device per process: one process per GPU)
+  static bool attr_ok = false;
+  std::call_once(attr_once, [] {
+    attr_ok = hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BW_Q_LDS) == hipSuccess &&
+              hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BW_KV_LDS) == hipSuccess;
+  });
+  if (!attr_ok) return CDSEG_ERR_LAUNCH;
   dim3 grid((unsigned)num_patches, (unsigned)num_heads);
   hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, grid, dim3(BW_WAVES * 64), BW_Q_LDS, s, p);
   hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, grid, dim3(BW_WAVES * 64), BW_KV_LDS, s, p);

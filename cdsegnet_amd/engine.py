@@ -364,6 +364,14 @@ class Engine:
                 w["x.feat_scale"] = torch.full((c,), cb.tm_feat, dtype=torch.float32, device=device)
                 w["x.feat_zero"] = torch.zeros(c, dtype=torch.float32, device=device)
         self.w = w
+        if T == torch.float16:
+            # IEEE half ends at 65504 and torch's cast does not saturate (the kernels' own float -> half conversions do): a weight
+            # beyond the range would enter every product as inf.  One reduction over the cast weights, one host read
+            flags = [(~torch.isfinite(t)).any() for t in w.values() if torch.is_tensor(t) and t.dtype == torch.float16]
+            if flags and bool(torch.stack(flags).any().item()):
+                bad = [k for k, t in w.items() if torch.is_tensor(t) and t.dtype == torch.float16 and not bool(torch.isfinite(t).all())]
+                raise CdsegError(f"weights outside IEEE half's range (|w| > 65504) in {bad[:4]}: run this checkpoint with "
+                                 f"precision='bf16+head' (bfloat16 trunk, fp32's exponent range)")
         # native Block executor: one descriptor per Block (weights never move after prepare)
         # wide bf16 stages: fragment images of the Block's head / tail weights (register-resident kernels, blockrr.hip)
         for mod, pre in self._blocks_to_describe:

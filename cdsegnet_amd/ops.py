@@ -86,26 +86,38 @@ class KernelTimer:
 TIMER = None
 
 
+def _loaded_libs():
+    """Every build of the library this process has loaded (a process normally runs one precision, but the 16-bit type is
+    a per-thread choice: profiling switches and summaries must not depend on which thread asks - ADVICE r3)."""
+    libs = list(_lib._libs.values())
+    return libs if libs else [_lib.load()]
+
+
 def attention_prof_enable(on=True):
-    """Event-time every attention launch inside the library (works for the native Block executor too)."""
-    check(_lib.load().cdseg_prof_enable(1 if on else 0), "prof_enable")
+    """Event-time every attention / sparse-conv launch inside the library (works for the native Block executor too); applies
+    to every loaded build."""
+    for lib in _loaded_libs():
+        check(lib.cdseg_prof_enable(1 if on else 0), "prof_enable")
 
 
 def attention_prof_summary():
-    """(total_ms, launches) since attention_prof_enable(True); call after torch.cuda.synchronize()."""
-    ms, cnt = ctypes.c_double(0.0), ctypes.c_long(0)
-    check(_lib.load().cdseg_prof_summary(ctypes.byref(ms), ctypes.byref(cnt)), "prof_summary")
-    return ms.value, cnt.value
+    """(total_ms, launches) since attention_prof_enable(True), summed over the loaded builds; call after torch.cuda.synchronize()."""
+    return prof_summary(PROF_ATTENTION)
 
 
 PROF_ATTENTION, PROF_CONV = 0, 1
 
 
 def prof_summary(cls):
-    """(total_ms, launches) of one profiled kernel class since attention_prof_enable(True); after a device sync."""
-    ms, cnt = ctypes.c_double(0.0), ctypes.c_long(0)
-    check(_lib.load().cdseg_prof_summary_class(int(cls), ctypes.byref(ms), ctypes.byref(cnt)), "prof_summary_class")
-    return ms.value, cnt.value
+    """(total_ms, launches) of one profiled kernel class since attention_prof_enable(True), summed over the loaded builds;
+    after a device sync."""
+    tot_ms, tot_cnt = 0.0, 0
+    for lib in _loaded_libs():
+        ms, cnt = ctypes.c_double(0.0), ctypes.c_long(0)
+        check(lib.cdseg_prof_summary_class(int(cls), ctypes.byref(ms), ctypes.byref(cnt)), "prof_summary_class")
+        tot_ms += ms.value
+        tot_cnt += cnt.value
+    return tot_ms, tot_cnt
 
 
 def set_timer(t):
@@ -943,8 +955,8 @@ def attention_bwd(q, k, v, q_gidx, kv_gidx, widx, patch_start, patch_start_host,
         raise _lib.CdsegError("attention_bwd: exact-fp32 mode only (first slice of the training path)")
     ps = [int(x) for x in patch_start_host]
     num_patches = len(ps) - 1
-    tiles = sum((ps[i + 1] - ps[i] + 63) // 64 for i in range(num_patches))
-    if num_patches and max(ps[i + 1] - ps[i] for i in range(num_patches)) > 1024:
+    max_len = max((ps[i + 1] - ps[i] for i in range(num_patches)), default=0)
+    if max_len > 1024:
         raise _lib.CdsegError("attention_bwd: a patch holds at most 1024 slots (the patch-head lives in LDS, like the forward)")
     for t, ld in ((q, q.stride(0)), (k, k.stride(0)), (v, v.stride(0)), (dout, dout.stride(0))):
         if ld % 4 or t.data_ptr() % 16:
@@ -952,7 +964,7 @@ def attention_bwd(q, k, v, q_gidx, kv_gidx, widx, patch_start, patch_start_host,
     lib = _lib.load()
     ws = torch.empty(max(1, lib.cdseg_attention_bwd_ws_bytes(ps[-1], int(num_heads))), dtype=torch.uint8, device=q.device)
     check(lib.cdseg_attention_bwd(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),
-                                  _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads), ps[-1], tiles,
+                                  _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads), ps[-1], max(1, max_len),
                                   float(scale), _ptr(dout), dout.stride(0), _ptr(dq), _ptr(dk), _ptr(dv), dq.stride(0),
                                   dk.stride(0), dv.stride(0), dt(q), _ptr(ws), ws.numel(), _stream()), "attention_bwd")
 

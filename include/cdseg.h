@@ -427,8 +427,8 @@ int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, 
  * cdseg_attention_bwd: gradients of cdseg_attention's inputs.  dout (rows, H*16) is the gradient of its output; dq / dk /
  *   dv are ACCUMULATED into (+=, the caller zeroes them) at the gathered rows - a point that the padding plan put into
  *   two slots collects both (the backward of the reference's `qkv[order]` gather); slots without an output row (widx -1)
- *   receive no output gradient but still act as keys.  num_slots = patch_start[num_patches]; num_tiles = sum over patches
- *   of ceil(L / 64) (unused since the MFMA form).  L <= 1024 per patch (the patch-head lives in LDS), 16-byte aligned rows.
+ *   receive no output gradient but still act as keys.  num_slots = patch_start[num_patches]; max_len = the longest patch,
+ *   <= 1024 (the patch-head lives in LDS: longer -> CDSEG_ERR_UNSUPPORTED); rows 16-byte aligned (else CDSEG_ERR_ARG).
  *   ws: cdseg_attention_bwd_ws_bytes.  dtype: CDSEG_F32 only so far.
  * cdseg_layernorm_bwd: dx (=, or += when accumulate) for y = LayerNorm(x) * gamma + beta; optional dgamma / dbeta (+=).
  * cdseg_gelu_bwd: dx = dy * d/du GELU(u) on the pre-activation u (erf form, torch.nn.GELU()).
@@ -442,7 +442,7 @@ int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, 
 size_t cdseg_attention_bwd_ws_bytes(long num_slots, int num_heads);
 int cdseg_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const int32_t* q_gidx,
                         const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
-                        int num_heads, long num_slots, int num_tiles, float scale, const void* dout, int lddo, void* dq,
+                        int num_heads, long num_slots, int max_len, float scale, const void* dout, int lddo, void* dq,
                         void* dk, void* dv, int lddq, int lddk, int lddv, int dtype, void* ws, size_t ws_bytes, void* stream);
 int cdseg_layernorm_bwd(const float* x, int ldx, const float* gamma, float eps, const float* dy, int lddy, float* dx, int lddx,
                         int accumulate, float* dgamma, float* dbeta, long m, int c, void* stream);

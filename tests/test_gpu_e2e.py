@@ -718,3 +718,21 @@ def test_half_trunk_survives_large_activations(gain):
     e_bf, a_bf = report(f"weights x{gain}: bf16+head vs fp32", bf, ref)
     assert e_half < e_bf and a_half >= a_bf
     assert e_half < 0.02 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_half_build_rejects_weights_outside_its_range():
+    """torch's float -> half cast does not saturate: a weight beyond 65504 would enter every product as inf.  The half
+    engine checks its cast weights once at prepare time and says which precision to use instead (the bfloat16 engine takes
+    the same checkpoint)."""
+    from cdsegnet_amd._lib import CdsegError
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = fixture_cfg(fx), dict(fixture_state_dict(fx))
+    key = next(k for k in sd if k.endswith("attn.qkv.weight"))
+    w = sd[key].clone()
+    w[0, 0] = 1.0e5
+    sd[key] = w
+    inp, draws = fixture_input(fx), fixture_draws(fx)
+    with pytest.raises(CdsegError, match="IEEE half"):
+        run(build(cfg, sd, "fp16+head", enable_flash=False), inp, draws)
+    out = run(build(cfg, sd, "bf16+head", enable_flash=False), inp, draws)
+    assert np.isfinite(out).all()
