@@ -669,7 +669,9 @@ def main():
                             "tools/test_time.py; its published figure for the 312-scene ScanNet val split is 56 s on an RTX 3090 "
                             "(BASELINE.md; other hardware, real scans, data loading excluded there too)",
                 "points_per_scene_mean": pts_per_step / scenes_per_step}
-            tpath = os.path.join(ROOT, "profiles", "r03_attention_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r04_attention_traffic.json")
+            if not os.path.exists(tpath):
+                tpath = os.path.join(ROOT, "profiles", "r03_attention_traffic.json")
             if low and os.path.exists(tpath):
                 # HBM bytes per launch (mean over every attention launch of this bench's forwards) from separate rocprofv3
                 # --pmc passes, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE: tools/pmc_bench_traffic.sh, an OFFLINE
@@ -677,7 +679,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
-                res["roofline"]["traffic_source"] = "profiles/r03_attention_traffic.json (offline rocprofv3 --pmc passes over bench.py's own forwards)"
+                res["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tpath)} (offline rocprofv3 --pmc passes over bench.py's own forwards)"
         if iso and "host_issue_ms" in iso:
             res["host_issue"] = {
                 "host_issue_ms_per_forward": iso["host_issue_ms"], "host_cpu_ms_per_forward": iso["host_cpu_ms"],
