@@ -378,11 +378,12 @@ extern "C" int cdseg_debug_gemm_ktiming(unsigned long long* host_dst, size_t cou
 
 // ---- accumulators -> LDS C tile -> fused epilogue, 64 rows at a time (shared by both main loops).
 // Wave (wm, wn) owns rows wm * 32 .. + 32, columns wn * BN/2 .. of the BM x BN tile; smem is free for reuse.
-// SQ: 16 waves as 4 x 4, a wave owns 64 rows x 64 columns (acc[4][4]); else a wave owns 32 rows x BN / 2 columns (acc[2][BN / 32])
+// SQ: 8 waves as 4 x 2, a wave owns 64 rows x BN / 2 columns (acc[4][BN / 32]); else a wave owns 32 rows x BN / 2 columns
+// (acc[2][BN / 32])
 template <int BN, int BM, bool SQ = false, int AI = 2, int AJ = BN / 32>
 __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[AI][AJ], char* smem, int tid, int lane,
                                               int wm, int wn, long m0, int n0, int zs) {
-  constexpr int NT = 4 * BM;
+  constexpr int NT = SQ ? 512 : 4 * BM;
   constexpr int TN = BN / 32;
   constexpr int CLD = BN + 4;
   const int fr = lane & 15, fg = lane >> 4;
@@ -414,7 +415,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4_t (&acc)[AI]
 #pragma unroll
           for (int j = 0; j < AJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[(i * 16 + fg * 4 + r) * CLD + wn * 64 + j * 16 + fr] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) Cs[(i * 16 + fg * 4 + r) * CLD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
       }
     } else if ((wm >> 1) == hh) {
       const int rbase = (wm & 1) * 32;
@@ -711,9 +712,9 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
 //     hipcc drains vmcnt(0) around compiler-visible LDS-DMA, and no other VMEM instruction lives in the loop.
 __device__ uint4 g_zero_page[8];  // 128 zero bytes: the source of a missing neighbour's row chunk
 
-template <int BM, bool GATHER = true, int BN = 128, int NST = 2>
+template <int BM, bool GATHER = true, int BN = 128, int NST = 2, bool SQ = false>
 struct DmaCfg {
-  static constexpr int WAVES = BM / 16, NT = WAVES * 64, BK = 64;
+  static constexpr int WAVES = SQ ? 8 : BM / 16, NT = WAVES * 64, BK = 64;
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
   static constexpr int A_PW = (BM / 8) / WAVES, W_PW = (BN / 8) / WAVES;  // DMA instructions per wave and step (2, BN / 8 / WAVES)
   static constexpr int STAGES = NST * (A_BYTES + W_BYTES);
@@ -729,20 +730,23 @@ struct DmaCfg {
 // A rows are not fetched (they would be 16 copies of the zero page) and its MFMAs not issued.  On z-ordered points a
 // 16-row group has 17 - 24 of the 27 offsets where the 128-row tile has 23 - 27 (tools: DESIGN 4.2), i.e. 12 - 25 % of
 // the tile's matrix work and gathered bytes go away.
-// SQ (BM = BN = 256, 16 waves as 4 x 4 with 64 x 64 wave tiles, split-K over the compacted offsets): the C = 512 sparse
-// convs at 8+ scenes.  A K step moves the same 4 DMA pieces per wave as the 128 x 128 tile and feeds 32 MFMAs per wave
-// instead of 16.  It did NOT deliver the 1.5x the piece arithmetic promised (stamps: one 16-wave block per CU has all its
-// waves in the same phase - nothing multiplies while they issue - and the register budget of 128 forces the fragment reads
-// behind per-group branches); what it does buy at C = 512 is traffic: two column tiles instead of four.
+// SQ (BM = 256 rows x BN = 256 columns, EIGHT waves as 4 x 2 with 64 x 128 wave tiles - acc[4][8] = 128 registers of a
+// 256-register budget - split-K over the compacted offsets): the deep sparse convs (C >= 256) at 8+ scenes.  Per FLOP the
+// tile moves half the bytes of the 128 x 128 one through the L2 -> LDS fill path these launches are bound by; a K step is
+// 8 DMA pieces and 64 MFMAs per wave, all fragments of a K half are read ahead of its 32 MFMAs, and the two waves of a
+// SIMD run in opposite phase (waves 0 - 3 issue the next step's DMAs and then multiply, waves 4 - 7 multiply first): one
+// block per CU, so nothing else would use the matrix pipe while a wave issues.  (The first form of this tile - 16 waves
+// as 4 x 4, 128 registers, fragment reads behind per-group branches, every wave in the same phase - spent 2.4x the MFMA
+// time in its multiply section and only paid at C = 512: profiles/r04_conv_sq.txt.)
 template <int BM, bool GATHER, int BN = 128, int NST = 2, bool SQ = false>
-__global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
+__global__ __launch_bounds__(SQ ? 512 : 4 * BM) void gemm_dma_kernel(GemmP g) {
 #ifdef CDSEG_GEMM_TIMING
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), tc0 = __builtin_readcyclecounter();
 #endif
-  using D = DmaCfg<BM, GATHER, BN, NST>;
+  using D = DmaCfg<BM, GATHER, BN, NST, SQ>;
   constexpr int TN = BN / 32;
-  constexpr int AI = SQ ? 4 : 2, AJ = SQ ? 4 : TN;
-  static_assert(!SQ || (BM == 256 && BN == 256), "square wave tiles: 256 x 256 blocks of 16 waves");
+  constexpr int AI = SQ ? 4 : 2, AJ = TN;  // a wave owns 16 AI rows x BN / 2 columns
+  static_assert(!SQ || (BM == 256 && NST == 2 && GATHER), "SQ: 256-row tiles of 8 waves, two stages, sparse convs");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tail = smem + D::STAGES + D::ITAB;
   int* live = reinterpret_cast<int*>(tail);  // [0] = count, [1..] = live offsets
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = SQ ? wave >> 2 : wave >> 1, wn = SQ ? wave & 3 : wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;
   int mt, sl;
   {
     const int bid = blockIdx.x, slices = g.gn * g.splits;
@@ -865,12 +869,17 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
   // Which of the live offsets this wave needs, as 64-bit masks over the live slots (bit jl <-> live offset jl; scalar
   // registers, no LDS access in the K loop): m_dma - the 16-row group this wave STAGES (rows 16 wave ..) has a neighbour
   // there; m_on0 / m_on1 - the two groups it MULTIPLIES (rows 32 wm .. / 32 wm + 16 ..) have one.
-  unsigned long long m_dma = ~0ull, m_on[AI];
+  constexpr int DG = D::A_PW / 2;  // 16-row groups this wave stages (two 8-row pieces each): rows 16 DG wave ..
+  static_assert(D::A_PW == 2 * DG, "a wave stages whole 16-row groups");
+  unsigned long long m_dma[DG], m_on[AI];
+#pragma unroll
+  for (int d = 0; d < DG; ++d) m_dma[d] = ~0ull;
 #pragma unroll
   for (int i = 0; i < AI; ++i) m_on[i] = ~0ull;
   if (GATHER) {
     const int gl = lane < nlive ? glive[lane] : 0;
-    m_dma = __ballot((gl >> wave) & 1);
+#pragma unroll
+    for (int d = 0; d < DG; ++d) m_dma[d] = __ballot((gl >> (DG * wave + d)) & 1);
 #pragma unroll
     for (int i = 0; i < AI; ++i) m_on[i] = __ballot((gl >> (AI * wm + i)) & 1);
   }
@@ -884,6 +893,9 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
       for (int i = 0; i < D::A_PW; ++i) idx_n[i] = itab[a_row[i] * 27 + jl];
     }
   };
+  const unsigned a_pitch = (unsigned)g.lda * 2u;  // bytes per A row (launch condition: M * lda * 2 < 2^32 for the gather form)
+  const unsigned long long a_base = (unsigned long long)(uintptr_t)g.A;
+  const unsigned long long z_page = (unsigned long long)(uintptr_t)g_zero_page + (unsigned)(slot * 16);
   // issues the DMAs of step kc into stage st; returns how many instructions this wave issued
   auto issue = [&](int kc, int st) -> int {
     const int kv = kc * D::BK;
@@ -895,22 +907,30 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     }
 #pragma unroll
     for (int i = 0; i < D::W_PW; ++i) dma16(w_src[i] + wcol, w_stage(st) + (wave * D::W_PW + i) * 1024);
-    const bool a_on = (m_dma >> slot_of(kc)) & 1ull;  // this wave stages rows 16 wave .. 16 wave + 15 = group `wave`
-    if (a_on) {
+    int issued = D::W_PW;
 #pragma unroll
-      for (int i = 0; i < D::A_PW; ++i) {
-        const void* src;
-        if (GATHER) {
-          const int sidx = idx_n[i];
-          src = sidx >= 0 ? (const void*)((const bf16_t*)g.A + (long)sidx * g.lda + cc + a_chunk[i] * 8)
-                          : (const void*)((const char*)g_zero_page + slot * 16);
-        } else {
-          src = a_src[i] + cc;
+    for (int d = 0; d < DG; ++d) {
+      if ((m_dma[d] >> slot_of(kc)) & 1ull) {  // the 16-row group has a neighbour at this offset (else: not read either)
+        issued += 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = 2 * d + h;
+          const void* src;
+          if (GATHER) {
+            // one 32 x 32 -> 64-bit multiply-add and two selects (written as `sidx >= 0 ? row address : zero page` this
+            // compiled into a divergent branch around two 64-bit multiplies per piece)
+            const int sidx = idx_n[i];
+            const unsigned long long pa = (unsigned long long)(unsigned)sidx * a_pitch + (a_base + (unsigned)((cc + a_chunk[i] * 8) * 2));
+            const unsigned lo = sidx >= 0 ? (unsigned)pa : (unsigned)z_page, hi = sidx >= 0 ? (unsigned)(pa >> 32) : (unsigned)(z_page >> 32);
+            src = (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+          } else {
+            src = a_src[i] + cc;
+          }
+          dma16(src, a_stage(st) + (wave * D::A_PW + i) * 1024);
         }
-        dma16(src, a_stage(st) + (wave * D::A_PW + i) * 1024);
       }
     }
-    return a_on ? D::W_PW + D::A_PW : D::W_PW;
+    return issued;
   };
 
   f32x4_t acc[AI][AJ];
@@ -935,6 +955,68 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
   unsigned long long kt_wait = 0, kt_bar = 0, kt_issue = 0, kt_mma = 0;
   const unsigned long long kt_pro = __builtin_readcyclecounter() - tc0;
 #endif
+  if constexpr (SQ) {
+    // ---- 256-row tiles.  ONE copy of the issue code and ONE of the multiply code in the loop (the K halves of a step are
+    // a loop that is not unrolled; half 1's fragments sit 64 bytes from half 0's, an XOR on the swizzled offsets): with
+    // the issue code inlined at two or three places next to 128 accumulator registers hipcc spilled inside the loop.
+    // The early waves (0 - 3) issue the next step's DMAs ahead of K half 0, the late ones (4 - 7, g.alt != 0) ahead of K
+    // half 1: a SIMD's two waves then use the fill path and the matrix pipe at the same time, and a late wave's DMAs
+    // still have half a multiply section to land.
+    const int my_slot = (g.alt && wave >= D::WAVES / 2) ? 1 : 0;
+    const int a_off0 = lds_off<8>(wm * 64 + fr, fg), b_off0 = lds_off<8>(wn * (BN / 2) + fr, fg);  // + 2048 per 16 rows
+#pragma unroll 1
+    for (int kc = kc0; kc < kc1; ++kc) {
+      KT_STAMP(k0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of step kc have landed
+      KT_STAMP(k1);
+      __builtin_amdgcn_s_barrier();  // ... everybody's have, and nobody still reads the stage issued into next
+      KT_STAMP(k2);
+      const int jl = slot_of(kc);
+      bool on[4], any = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { on[i] = (m_on[i] >> jl) & 1ull; any |= on[i]; }
+      const bool more = kc + 1 < kc1;
+      const char* As = smem + st * D::A_BYTES;
+      const char* Bs = smem + NST * D::A_BYTES + st * D::W_BYTES;
+#ifdef CDSEG_GEMM_TIMING
+      unsigned long long ki = 0;
+#endif
+#pragma unroll 1
+      for (int kk = 0; kk < 2; ++kk) {
+        if (more && kk == my_slot) {
+          KT_STAMP(i0);
+          issue(kc + 1, st ^ 1);
+          if (kc + 2 < kc1) fetch_idx(kc + 2);
+#ifdef CDSEG_GEMM_TIMING
+          ki = __builtin_readcyclecounter() - i0;
+#endif
+        }
+        if (any) {
+          // all twelve fragments of the K half are requested ahead of its MFMAs (a dead group's A rows are stale bytes,
+          // never multiplied)
+          const int x = kk << 6;
+          bf16x8_t a[4], b[AJ];
+#pragma unroll
+          for (int j = 0; j < AJ; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + ((b_off0 ^ x) + 2048 * j));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + ((a_off0 ^ x) + 2048 * i));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (on[i]) {
+#pragma unroll
+              for (int j = 0; j < AJ; ++j) acc[i][j] = mfma_16x16x32_bf16(a[i], b[j], acc[i][j]);
+            }
+        }
+      }
+      st ^= 1;
+#ifdef CDSEG_GEMM_TIMING
+      {
+        const unsigned long long k4 = __builtin_readcyclecounter();
+        kt_wait += k1 - k0; kt_bar += k2 - k1; kt_issue += ki; kt_mma += k4 - k2 - ki;
+      }
+#endif
+    }
+  } else {
 #pragma unroll 1
   for (int kc = kc0; kc < kc1; ++kc) {
     KT_STAMP(k0);
@@ -943,7 +1025,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (pending == D::W_PW) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::W_PW) : "memory");
-    } else {
+    } else {  // (three stages: 128-row tiles only, one staged group per wave)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::W_PW + D::A_PW) : "memory");
     }
     KT_STAMP(k1);
@@ -976,30 +1058,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     const char* As = smem + st * D::A_BYTES;
     const char* Bs = smem + NST * D::A_BYTES + st * D::W_BYTES;
     const int jl = slot_of(kc);
-    if constexpr (SQ) {
-      // (all fragments of a K half ahead of its MFMAs would be the faster form - behind a branch per row group the
-      // reads are eight serial LDS round trips per step - but 64 accumulator + 32 fragment registers do not fit the 128
-      // of a 16-wave block: 175 spilled VGPRs inside the loop)
-      bool on[4], any = false;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { on[i] = (m_on[i] >> jl) & 1ull; any |= on[i]; }
-      if (any) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          bf16x8_t b[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<8>(wn * 64 + j * 16 + fr, 4 * kk + fg));
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (on[i]) {
-              const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(As + lds_off<8>(wm * 64 + i * 16 + fr, 4 * kk + fg));
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32_bf16(a, b[j], acc[i][j]);
-            }
-        }
-      }
-    } else {
+    {
     const bool on0 = (m_on[0] >> jl) & 1ull, on1 = (m_on[1] >> jl) & 1ull;
     if (on0 || on1) {
 #pragma unroll
@@ -1036,6 +1095,7 @@ __global__ __launch_bounds__(4 * BM) void gemm_dma_kernel(GemmP g) {
     }
 #endif
   }
+  }  // !SQ
 #ifdef CDSEG_GEMM_TIMING
   if (lane == 0 && blockIdx.x < 4096 && wave < 16) {
     unsigned long long* d = g_gemm_kt + ((size_t)blockIdx.x * 16 + wave) * 8;
@@ -1105,16 +1165,18 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
       if (want > 0) bm = dma_use_bm = want;
     }
   }
-  // deep sparse convs (C >= 256) at 8+ scenes: 256 x 256 tiles, 16 waves as 4 x 4, split-K (gemm_dma_kernel<256, true, 256, 2, true>)
+  // deep sparse convs (C >= 256) at 8+ scenes: 256 x 256 tiles, 8 waves as 4 x 2, split-K (gemm_dma_kernel<256, true, 256, 2, true>)
   bool sq = false;
   if constexpr (GATHER && NCH == 16 && sizeof(CT) == 2) {
     static const int sq_on = cdseg_knob("CDSEG_CONV_SQ", 1);
     static const int sq_min_m = cdseg_knob("CDSEG_CONV_SQ_MIN_M", 5000);
-    // C = 512 only: 117 instead of 146 us at 6.2 k rows (two column tiles instead of four gather the rows twice instead of
-    // four times, W slices are read by 25 row tiles instead of 49); C = 256: 132 vs 129 us (profiles/r04_conv_sq.txt)
-    sq = sq_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= 512 && (p.N % 256) == 0 && !ln && p.kshift >= 6 &&
+    static const int sq_min_n = cdseg_knob("CDSEG_CONV_SQ_MIN_N", 256);
+    sq = sq_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= sq_min_n && (p.N % 256) == 0 && !ln && p.kshift >= 6 &&
          p.M >= sq_min_m && p.ws && p.vec_ok && !p.out_idx;
-    if (sq) bm = 256;
+    if (sq) {
+      bm = 256;
+      p.alt = cdseg_knob("CDSEG_CONV_SQ_ALT", 1);
+    }
   }
   const int gm = (int)((p.M + bm - 1) / bm);
   // deep sparse convs (C >= 256): 256-column tiles on a three-stage ring, one block per CU (gemm_dma_kernel<128, true, 256, 3>)
@@ -1180,7 +1242,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     if constexpr (GATHER) {
       if (sq && dma_on) {
         launched = true;
-        using Q = DmaCfg<256, true, 256, 2>;
+        using Q = DmaCfg<256, true, 256, 2, true>;
         static bool aq = false;
         if (!aq) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<256, true, 256, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1188,7 +1250,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
             return CDSEG_ERR_LAUNCH;
           aq = true;
         }
-        hipLaunchKernelGGL((gemm_dma_kernel<256, true, 256, 2, true>), grid, dim3(1024), Q::LDS, s, p);
+        hipLaunchKernelGGL((gemm_dma_kernel<256, true, 256, 2, true>), grid, dim3(Q::NT), Q::LDS, s, p);
       }
       if (!launched && wide && dma_on && p.kshift >= 6) {
         launched = true;
