@@ -918,7 +918,9 @@ __global__ __launch_bounds__(SQ ? 512 : 4 * BM) void gemm_dma_kernel(GemmP g) {
           const void* src;
           if (GATHER) {
             // one 32 x 32 -> 64-bit multiply-add and two selects (written as `sidx >= 0 ? row address : zero page` this
-            // compiled into a divergent branch around two 64-bit multiplies per piece)
+            // compiled into a divergent branch around two 64-bit multiplies per piece).  NOT fetching the rows without a
+            // neighbour at all (lanes off in the DMA instruction, the multiply side reading a zero row instead) was
+            // measured slower: the fill path's cost is per DMA instruction, not per active lane (profiles/r04_conv_sq8.txt)
             const int sidx = idx_n[i];
             const unsigned long long pa = (unsigned long long)(unsigned)sidx * a_pitch + (a_base + (unsigned)((cc + a_chunk[i] * 8) * 2));
             const unsigned lo = sidx >= 0 ? (unsigned)pa : (unsigned)z_page, hi = sidx >= 0 ? (unsigned)(pa >> 32) : (unsigned)(z_page >> 32);

@@ -22,4 +22,4 @@ done
 echo "--- level 2"; timeout 120 python tools/conv_timing.py 2 8 2>&1 | tail -2
 } > gpurun_out/sq8_conv_timing.txt 2>&1
 cat gpurun_out/sq8_conv_timing.txt
-bash tools/ab_bench.sh sq8 base > gpurun_out/sq8_ab.txt 2>&1; cat gpurun_out/sq8_ab.txt
+bash tools/ab_bench.sh mask sq8 > gpurun_out/sq8_ab.txt 2>&1; cat gpurun_out/sq8_ab.txt
