@@ -1191,7 +1191,8 @@ def test_deep_head_and_tail_vs_oracle_and_unfused_sequence(ops, lp, M, C, tb):
 @pytest.mark.parametrize("n,C", [(5000, 256), (2100, 512), (130, 256), (40000, 128), (30000, 256), (6100, 512)])
 def test_deep_conv_group_skipping_random_map(ops, lp, n, C):
     """The deep-stage gathered conv (gemm.hip: 16-row groups without a neighbour at an offset are neither fetched nor
-    multiplied; C >= 256: 256-column tiles on a three-stage LDS-DMA ring, split-K when the grid is small) on a random
+    multiplied; C >= 256 at >= 5000 rows: 256 x 256 tiles on 8 waves with split-K over the live offsets - the (5000, 256),
+    (30000, 256) and (6100, 512) cases, ragged last tiles included - else 128 x 128 tiles, split-K when the grid is small) on a random
     offset-major kernel map with whole dead (group, offset) pairs, dead offsets and ragged last tiles, against a plain
     fp32 torch gather + matmul per offset on the same 16-bit operands (ref: spconv.SubMConv3d call sites ptv3.py:356-362)."""
     g = torch.Generator().manual_seed(n + C)
