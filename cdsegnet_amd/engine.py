@@ -201,6 +201,7 @@ class Engine:
         self.rng_offset = 0
         self._rng_seed = None  # torch.initial_seed() the device-RNG cursor belongs to
         self.use_native_blocks = True  # one library call per Block instead of ~8 binding calls
+        self.exact_attention_core = False  # budget tool only: fp32 attention core inside a 16-bit trunk (binding path)
         self._pad_keys = None
         self._side = {}
         self.fork_stage = 1  # dominant-branch encoder stage at which the noise-branch encoder is forked (None: serial)
@@ -651,8 +652,16 @@ class Engine:
         _, _, _, _, patch_start, max_len, sum_l2 = lv.pad(att.patch_size, att.enable_flash)
         self._add_work(64.0 * att.num_heads * sum_l2, 4.0 * n * c * qkv.element_size())
         o = self._buf(n, c, self.T)
-        ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads, max_len,
-                      att.scale, o, work=64.0 * att.num_heads * sum_l2)
+        if self.exact_attention_core and self.T != torch.float32:
+            # error-budget tool only (tools/bf16_budget.py): the attention core in fp32 on the 16-bit q k v
+            q32 = qkv.float()
+            o32 = self._buf(n, c, torch.float32)
+            ops.attention(q32[:, :c], q32[:, c:2 * c], q32[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads,
+                          max_len, att.scale, o32, work=0.0)
+            o.copy_(o32)
+        else:
+            ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads,
+                          max_len, att.scale, o, work=64.0 * att.num_heads * sum_l2)
         hid = w[pre + ".fc1.w"].shape[0]
         if (pre + ".tail_img") in w and not ops.attn_tail_fused_ok(o, hid):  # deep stages: proj + LN2 + MLP, one launch
             st.xc = self._buf(n, c, self.T)

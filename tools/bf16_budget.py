@@ -1,7 +1,7 @@
 """Error budget of the bf16 mode: which stages of the network the bf16-vs-fp32 logit error and
 the arg-max disagreements come from, and what each exact-fp32 stage costs.  One bench scene; the reference is the
 exact-fp32 HIP path on the same draws; `hi` = the stages run through the fp32 twin engine (Engine.hi).
-usage: python tools/bf16_budget.py [points] > profiles/r03_bf16_budget.txt"""
+usage: python tools/bf16_budget.py [points] [bf16|fp16] > profiles/r03_bf16_budget.txt   (r04_precision.txt: fp16)"""
 import os, sys, time
 import numpy as np
 import torch
@@ -13,6 +13,7 @@ from cdsegnet_amd.registry import build_model
 import cdsegnet_amd.models  # noqa: F401
 
 points = int(sys.argv[1]) if len(sys.argv) > 1 else 103000
+LOWP = sys.argv[2] if len(sys.argv) > 2 else "bf16"  # the 16-bit trunk under study
 dev = torch.device("cuda")
 cfg = configs.cdsegnet_config("scannet")
 model = build_model(cfg)
@@ -26,10 +27,17 @@ draws = dict(noise=torch.normal(0, 1, size=(n, cfg["c_in_channels"]), dtype=torc
              perms=[torch.randperm(4, generator=gen).tolist() for _ in range(8)])
 model.noise_source = "torch_cpu"
 
-def run(precision, hi=()):
+def run(precision, hi=(), exact_attention=False):
     model.precision = precision
     eng = model.engine()
     eng.hi = frozenset(hi) if precision != "fp32" else frozenset()
+    eng.exact_attention_core = exact_attention  # (binding path only: the native Block executor is switched off with it)
+    if exact_attention:
+        model._drop_engine()
+        eng = model.engine()
+        eng.use_native_blocks = False
+        eng.hi = frozenset(hi)
+        eng.exact_attention_core = True
     out = model.inference(dict(d0), eval=False, draws=dict(draws))["seg_logits"].clone()
     torch.cuda.synchronize()
     ts = []
@@ -50,7 +58,7 @@ ENC = [f"n_enc{s}" for s in range(5)]
 DEC = [f"n_dec{s}" for s in range(4)]
 CB = ["c_emb", "c_enc0", "c_enc1", "c_enc2"]
 ALL = ["n_emb"] + ENC + CB + ["x"] + DEC + ["n_head"]
-rows = [("pure bf16", ())]
+rows = [(f"pure {LOWP}", ())]
 rows += [(f"fp32: {k}", (k,)) for k in ALL]
 rows += [("fp32: head + n_dec0", ("n_head", "n_dec0")),
          ("fp32: whole n-decoder + head", tuple(DEC) + ("n_head",)),
@@ -61,8 +69,9 @@ rows += [("fp32: head + n_dec0", ("n_head", "n_dec0")),
          ("fp32: everything (sanity)", tuple(ALL))]
 base_t = None
 print(f"{'configuration':58s} {'arg-max agree':>13s} {'max |dlogit|':>13s} {'rms dlogit':>11s} {'ms/scene':>9s} {'cost':>7s}")
+rows.append((f"{LOWP} trunk, attention core (softmax(q k^T) v) in fp32", "ATT"))
 for name, hi in rows:
-    out, t = run("bf16", hi)
+    out, t = run(LOWP, () if hi == "ATT" else hi, exact_attention=(hi == "ATT"))
     if base_t is None:
         base_t = t
     diff = (out - ref)
