@@ -101,10 +101,11 @@ class Block(nn.Module):
     """ref: ptv3.py:326-428."""
 
     def __init__(self, channels, num_heads, patch_size=48, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
-                 order_index=0, cpe_indice_key=None, enable_flash=True, T_dim=-1, pre_norm=True):
+                 order_index=0, cpe_indice_key=None, enable_flash=True, T_dim=-1, pre_norm=True, drop_path=0.0):
         super().__init__()
         _reject(pre_norm=(pre_norm, True))
         self.channels, self.T_dim = channels, T_dim
+        self.drop_prob = float(drop_path)  # stochastic depth of the training forward (timm DropPath, ptv3.py:392-394): rows
         self.cpe = PointSequential(
             SubMConv3d(channels, channels, 3, bias=True, indice_key=cpe_indice_key),
             nn.Linear(channels, channels),
@@ -202,8 +203,9 @@ class CrossBlock(nn.Module):
 
     def __init__(self, q_channels, kv_channels, num_heads, q_patch_size, kv_patch_size, mlp_ratio=4.0, qkv_bias=True,
                  qk_scale=None, order_index=0, q_cpe_indice_key=None, kv_cpe_indice_key=None, enable_flash=True,
-                 tm_feat=1.0):
+                 tm_feat=1.0, drop_path=0.0):
         super().__init__()
+        self.drop_prob = float(drop_path)
         if not isinstance(tm_feat, (int, float)):
             raise NotImplementedError(f"tm_feat={tm_feat!r}: learned fusion scales are off in every shipped config")
         self.tm_feat = float(tm_feat)
@@ -268,6 +270,14 @@ class PointTransformerV3(nn.Module):
 
         no = len(self.order)
         blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, enable_flash=enable_flash)
+
+        def rates(depths):  # stochastic-depth schedule over the blocks of one coder (ptv3.py:1459-1466)
+            return [float(x) for x in torch.linspace(0, drop_path, sum(depths))]
+
+        def stage_rates(all_rates, depths, s, reverse=False):
+            r = all_rates[sum(depths[:s]): sum(depths[:s + 1])]
+            return r[::-1] if reverse else r  # (decoders: ptv3.py:1515-1518)
+        n_enc_dp, n_dec_dp = rates(n_enc_depths), rates(n_dec_depths)
         self._n_embedding = Embedding(n_in_channels, n_enc_channels[0])
         self._n_enc = PointSequential()
         for s in range(self.n_num_stages):
@@ -276,7 +286,8 @@ class PointTransformerV3(nn.Module):
                 enc.add(SerializedPooling(n_enc_channels[s - 1], n_enc_channels[s], stride=n_stride[s - 1]), name="down")
             for i in range(n_enc_depths[s]):
                 enc.add(Block(n_enc_channels[s], n_enc_num_head[s], n_enc_patch_size[s], order_index=i % no,
-                              cpe_indice_key=f"stage{s}", **blk), name=f"block{i}")
+                              cpe_indice_key=f"stage{s}", drop_path=stage_rates(n_enc_dp, n_enc_depths, s)[i], **blk),
+                        name=f"block{i}")
             if len(enc) != 0:
                 self._n_enc.add(enc, name=f"enc{s}")
         self._n_dec = PointSequential()
@@ -290,13 +301,15 @@ class PointTransformerV3(nn.Module):
                     name="up")
             for i in range(n_dec_depths[s]):
                 dec.add(Block(n_dec_channels[s], n_dec_num_head[s], n_dec_patch_size[s], order_index=i % no,
-                              cpe_indice_key=f"stage{s}", **blk), name=f"block{i}")
+                              cpe_indice_key=f"stage{s}", drop_path=stage_rates(n_dec_dp, n_dec_depths, s, True)[i], **blk),
+                        name=f"block{i}")
             self._n_dec.add(dec, name=f"dec{s}")
         self._n_head = nn.Linear(n_dec_channels[0], num_classes) if num_classes > 0 else nn.Identity()
 
         if self.condition:
             self.c_num_stages = len(c_enc_depths)
             assert self.c_num_stages == len(c_stride) + 1 == len(c_enc_channels) == len(c_enc_num_head)
+            c_enc_dp, c_dec_dp = rates(c_enc_depths), rates(c_dec_depths)
             self._c_embedding = Embedding(c_in_channels, c_enc_channels[0])
             if T_dim != -1:
                 self.fc_t1 = nn.Linear(T_dim, 4 * T_dim)
@@ -309,7 +322,8 @@ class PointTransformerV3(nn.Module):
                                               T_dim=T_dim), name="down")
                 for i in range(c_enc_depths[s]):
                     enc.add(Block(c_enc_channels[s], c_enc_num_head[s], c_enc_patch_size[s], order_index=i % no,
-                                  cpe_indice_key=f"stage{s}", T_dim=T_dim, **blk), name=f"block{i}")
+                                  cpe_indice_key=f"stage{s}", T_dim=T_dim,
+                                  drop_path=stage_rates(c_enc_dp, c_enc_depths, s)[i], **blk), name=f"block{i}")
                 if len(enc) != 0:
                     self._c_enc.add(enc, name=f"enc{s}")
             self._c_dec = PointSequential()
@@ -321,14 +335,16 @@ class PointTransformerV3(nn.Module):
                                             skip_connection_scale=skip_connection_scale), name="up")
                 for i in range(c_dec_depths[s]):
                     dec.add(Block(c_dec_channels[s], c_dec_num_head[s], c_dec_patch_size[s], order_index=i % no,
-                                  cpe_indice_key=f"stage{s}", T_dim=T_dim, **blk), name=f"block{i}")
+                                  cpe_indice_key=f"stage{s}", T_dim=T_dim,
+                                  drop_path=stage_rates(c_dec_dp, c_dec_depths, s, True)[i], **blk), name=f"block{i}")
                 self._c_dec.add(dec, name=f"dec{s}")
             self._c_head = nn.Linear(n_dec_channels[0], c_in_channels) if num_classes > 0 else nn.Identity()
             self._tm_dec0 = TransferModule(
                 q_channels=n_dec_channels[-1], kv_channels=c_dec_channels[-1], num_heads=n_enc_num_head[-1],
                 q_patch_size=n_enc_patch_size[-1], kv_patch_size=c_enc_patch_size[-1], mlp_ratio=mlp_ratio,
                 qkv_bias=qkv_bias, qk_scale=qk_scale, order_index=0, q_cpe_indice_key="stage2",
-                kv_cpe_indice_key="stage2", enable_flash=enable_flash, tm_feat=tm_feat)
+                kv_cpe_indice_key="stage2", enable_flash=enable_flash, tm_feat=tm_feat,
+                drop_path=c_enc_dp[2] if len(c_enc_dp) > 2 else 0.0)  # (ptv3.py:1735-1736)
 
     def forward(self, c_point=None, n_point=None):
         raise NotImplementedError(
@@ -418,6 +434,7 @@ class DefaultSegmentorV2(nn.Module):
     # -- engine cache management -------------------------------------------------------------
     def _drop_engine(self):
         self._engine = None
+        self._train_graph = None
 
     def load_state_dict(self, *a, **k):
         self._drop_engine()
@@ -543,5 +560,12 @@ class DefaultSegmentorV2(nn.Module):
         return dict(seg_logits=self.engine().inference_ddim(input_dict, step=step, mode=mode, noise_level=noise_level,
                                                             draws=draws))
 
-    def forward(self, input_dict):
-        raise NotImplementedError("training forward (default.py:424-493) is outside the single-step-inference hot path")
+    def forward(self, input_dict, draws=None):
+        """Training forward (ref: default.py:424-493): returns dict(loss=...) under torch autograd - `loss.backward()` fills
+        the `.grad` of this module's parameters like the reference's does (engines/train.py:216-271).  fp32, on the HIP
+        kernels behind torch.autograd.Functions: cdsegnet_amd/train_graph.py.  `draws` replays recorded random draws."""
+        from .train_graph import TrainGraph
+        if getattr(self, "_train_graph", None) is None:
+            self._train_graph = TrainGraph(self)
+        out = self._train_graph.forward(input_dict, draws)
+        return out if draws is not None else dict(loss=out["loss"])

@@ -537,24 +537,27 @@ def iou_counts(pred, target, num_classes, ignore_index=-1, pred_idx=None):
 
 # ------------------------------------------------------------------ training path (cdsegnet_amd/train.py on the CPU)
 def attention_bwd(q, k, v, q_gidx, kv_gidx, widx, patch_start, patch_start_host, num_heads, scale, dout, dq, dk, dv):
-    """Autograd through the oracle's patch attention on the library's slot plan; += into dq / dk / dv like the kernel."""
+    """Autograd through the oracle's patch attention on the library's slot plan; += into dq / dk / dv like the kernel.
+    (enable_grad: the callers include torch.autograd.Function.backward, where recording is off.)"""
     ps = np.asarray(patch_start_host, dtype=np.int64)
-    qq, kk, vv = (t.detach().clone().float().requires_grad_(True) for t in (q, k, v))
-    o = OM._patch_attention(qq[q_gidx.long()], kk[kv_gidx.long()], vv[kv_gidx.long()], ps, num_heads, scale)
-    m = widx >= 0
-    full = torch.zeros_like(dout)
-    full = full.index_put((widx[m].long(),), o[m])
-    (full * dout).sum().backward()
+    with torch.enable_grad():
+        qq, kk, vv = (t.detach().clone().float().requires_grad_(True) for t in (q, k, v))
+        o = OM._patch_attention(qq[q_gidx.long()], kk[kv_gidx.long()], vv[kv_gidx.long()], ps, num_heads, scale)
+        m = widx >= 0
+        full = torch.zeros_like(dout)
+        full = full.index_put((widx[m].long(),), o[m])
+        (full * dout).sum().backward()
     dq += qq.grad
     dk += kk.grad
     dv += vv.grad
 
 
 def layernorm_bwd(x, gamma, dy, dx, accumulate=False, eps=1e-5, dgamma=None, dbeta=None):
-    xr = x.detach().clone().requires_grad_(True)
-    g = gamma.detach().clone().requires_grad_(True)
-    b = torch.zeros_like(gamma).requires_grad_(True)
-    F.layer_norm(xr, (x.shape[1],), g, b, eps).backward(dy)
+    with torch.enable_grad():
+        xr = x.detach().clone().requires_grad_(True)
+        g = gamma.detach().clone().requires_grad_(True)
+        b = torch.zeros_like(gamma).requires_grad_(True)
+        F.layer_norm(xr, (x.shape[1],), g, b, eps).backward(dy)
     if accumulate:
         dx += xr.grad
     else:
@@ -567,8 +570,9 @@ def layernorm_bwd(x, gamma, dy, dx, accumulate=False, eps=1e-5, dgamma=None, dbe
 
 
 def gelu_bwd(u, dy):
-    ur = u.detach().clone().requires_grad_(True)
-    F.gelu(ur).backward(dy)
+    with torch.enable_grad():
+        ur = u.detach().clone().requires_grad_(True)
+        F.gelu(ur).backward(dy)
     return ur.grad
 
 

@@ -352,3 +352,49 @@ def test_whole_block_backward_host_chain_on_the_emulated_ops(monkeypatch):
     for mine, ref in names.items():
         r = rg[pre + ref].reshape(grads[mine].shape)
         assert float((grads[mine] - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max())), mine
+
+
+def test_training_step_graph_on_the_emulated_ops_vs_reference_fixture(monkeypatch):
+    """cdsegnet_amd/train_graph.py - the model's training forward under torch autograd (q_sample, both branches and both
+    decoders, train-mode BatchNorm, recorded stochastic-depth masks mapped from the reference's row order of every level
+    to the plan's, the GLS criteria) and `loss.backward()` into the nn.Parameters' .grad - on the PyTorch-CPU emulation of
+    the ops, against the reference's own training step (tests/golden/train_step_mini.npz): loss, both predictions, the
+    norm of EVERY parameter gradient, eight gradients in full.  The CPU twin of tests/test_gpu_train.py's whole-step test."""
+    import cdsegnet_amd.engine as engine
+    import cdsegnet_amd.train_graph as tg
+    from cdsegnet_amd import configs
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    from tests.helpers import load_fixture
+    monkeypatch.setattr(engine, "ops", emu_ops)
+    monkeypatch.setattr(tg, "ops", emu_ops)
+    fx = load_fixture("train_step_mini.npz")
+    cfg = configs.mini_config()
+    cfg["backbone"]["enable_flash"] = False  # the fixture was captured on the reference's non-flash (CPU) attention path
+    cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+                       dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
+                       dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(fx["sd_seed"])))
+    model.train()
+    masks = {str(k): [fx[f"mask.{i}.{j}"] for j in range(int(fx["mask_counts"][i]))] for i, k in enumerate(fx["mask_names"])}
+    draws = dict(ts=fx["ts"], noise=fx["noise"], perms=[list(p) for p in fx["perms"]], masks=masks)
+    inp = {k: torch.as_tensor(fx[k]) for k in ("coord", "grid_coord", "feat", "offset", "segment")}
+    out = model(inp, draws=draws)
+    assert abs(float(out["loss"].detach()) - float(fx["loss"])) < 2e-5
+    assert float((out["n_pred"].detach() - torch.as_tensor(fx["n_pred"])).abs().max()) < 1e-4
+    assert float((out["c_pred"].detach() - torch.as_tensor(fx["c_pred"])).abs().max()) < 1e-4
+    out["loss"].backward()
+    named = dict(model.named_parameters())
+    names = [str(n) for n in fx["grad_names"]]
+    gn = np.array([float(named[k].grad.norm()) if named[k].grad is not None else -1.0 for k in names])
+    ref = fx["grad_norms"]
+    assert (gn >= 0).all() and len(gn) == 508
+    assert (np.abs(gn - ref) <= 1e-3 * ref + 1e-5 * ref.max()).all()
+    checked = 0
+    for k in fx.files:
+        if k.startswith("g."):
+            r = fx[k]
+            assert float((named[k[2:]].grad - torch.as_tensor(r)).abs().max()) <= 1e-3 * float(np.abs(r).max()), k
+            checked += 1
+    assert checked == 8
