@@ -259,37 +259,77 @@ __global__ __launch_bounds__(BW_WAVES * 64) void attn_bwd_kv_mfma_kernel(AttnBwd
 constexpr int BW_Q_LDS = 2 * BW_MAXL * 64;
 constexpr int BW_KV_LDS = 2 * BW_MAXL * 64 + 3 * BW_MAXL * 4;
 
-// ---- LayerNorm backward: dx = (1/sigma) (dyg - mean(dyg) - xhat mean(dyg xhat)), dyg = dy * gamma; one wave per row
+// ---- LayerNorm backward: dx = (1/sigma) (dyg - mean(dyg) - xhat mean(dyg xhat)), dyg = dy * gamma.  One wave per row, 16 rows
+// per wave; d gamma / d beta are summed over the block's 64 rows in registers + LDS and leave with ONE atomic per column
+// and block (the first version issued one atomic per element onto C addresses: 82 of a 450 ms training step).
+constexpr int LNB_ROWS = 16, LNB_MAXC = 512;
+
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                             float eps, const float* __restrict__ dy, int lddy, float* dx, int lddx,
                                                             int accumulate, float* dgamma, float* dbeta, long m, int c) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= m) return;
-  const float* xr = x + row * ldx;
-  const float* gr = dy + row * lddy;
-  float s = 0.f, ss = 0.f;
-  for (int j = lane; j < c; j += 64) { const float t = xr[j]; s += t; }
-  s = wave_sum(s);
-  const float mean = s / c;
-  for (int j = lane; j < c; j += 64) { const float t = xr[j] - mean; ss = fmaf(t, t, ss); }
-  ss = wave_sum(ss);
-  const float rstd = rsqrtf(ss / c + eps);
-  float a = 0.f, b = 0.f;
-  for (int j = lane; j < c; j += 64) {
-    const float xh = (xr[j] - mean) * rstd, dg = gr[j] * gamma[j];
-    a += dg;
-    b = fmaf(dg, xh, b);
+  __shared__ float red[2][4][LNB_MAXC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * LNB_ROWS;
+  const bool sums = (dgamma || dbeta) && c <= LNB_MAXC;
+  float pg[LNB_MAXC / 64], pb[LNB_MAXC / 64];
+#pragma unroll
+  for (int t = 0; t < LNB_MAXC / 64; ++t) pg[t] = pb[t] = 0.f;
+  for (int r = 0; r < LNB_ROWS; ++r) {
+    const long row = row0 + r;
+    if (row >= m) break;
+    const float* xr = x + row * ldx;
+    const float* gr = dy + row * lddy;
+    float s = 0.f, ss = 0.f;
+    for (int j = lane; j < c; j += 64) { const float t = xr[j]; s += t; }
+    s = wave_sum(s);
+    const float mean = s / c;
+    for (int j = lane; j < c; j += 64) { const float t = xr[j] - mean; ss = fmaf(t, t, ss); }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / c + eps);
+    float a = 0.f, b = 0.f;
+    for (int j = lane; j < c; j += 64) {
+      const float xh = (xr[j] - mean) * rstd, dg = gr[j] * gamma[j];
+      a += dg;
+      b = fmaf(dg, xh, b);
+    }
+    a = wave_sum(a) / c;
+    b = wave_sum(b) / c;
+    if (sums) {
+#pragma unroll
+      for (int t = 0; t < LNB_MAXC / 64; ++t) {
+        const int j = lane + 64 * t;
+        if (j < c) {
+          const float xh = (xr[j] - mean) * rstd, g = gr[j], dg = g * gamma[j];
+          const float v = rstd * (dg - a - xh * b);
+          float* o = dx + row * lddx + j;
+          *o = accumulate ? *o + v : v;
+          pg[t] = fmaf(g, xh, pg[t]);
+          pb[t] += g;
+        }
+      }
+    } else {
+      for (int j = lane; j < c; j += 64) {
+        const float xh = (xr[j] - mean) * rstd, dg = gr[j] * gamma[j];
+        const float v = rstd * (dg - a - xh * b);
+        float* o = dx + row * lddx + j;
+        *o = accumulate ? *o + v : v;
+        if (dgamma) atomicAdd(dgamma + j, gr[j] * xh);  // (rows wider than 512: per-element atomics)
+        if (dbeta) atomicAdd(dbeta + j, gr[j]);
+      }
+    }
   }
-  a = wave_sum(a) / c;
-  b = wave_sum(b) / c;
-  for (int j = lane; j < c; j += 64) {
-    const float xh = (xr[j] - mean) * rstd, dg = gr[j] * gamma[j];
-    const float r = rstd * (dg - a - xh * b);
-    float* o = dx + row * lddx + j;
-    *o = accumulate ? *o + r : r;
-    if (dgamma) atomicAdd(dgamma + j, gr[j] * xh);
-    if (dbeta) atomicAdd(dbeta + j, gr[j]);
+  if (!sums) return;  // (block-uniform)
+#pragma unroll
+  for (int t = 0; t < LNB_MAXC / 64; ++t) {
+    const int j = lane + 64 * t;
+    if (j < c) { red[0][wave][j] = pg[t]; red[1][wave][j] = pb[t]; }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < c; j += 256) {
+    const float g = (red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j]);
+    const float b = (red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j]);
+    if (dgamma) atomicAdd(dgamma + j, g);
+    if (dbeta) atomicAdd(dbeta + j, b);
   }
 }
 
@@ -411,7 +451,7 @@ extern "C" int cdseg_attention_bwd(const void* q, const void* k, const void* v, 
 extern "C" int cdseg_layernorm_bwd(const float* x, int ldx, const float* gamma, float eps, const float* dy, int lddy, float* dx,
                                    int lddx, int accumulate, float* dgamma, float* dbeta, long m, int c, void* stream) {
   if (m <= 0) return CDSEG_OK;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)cdiv(m, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, eps, dy,
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)cdiv(m, 4 * LNB_ROWS)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, eps, dy,
                      lddy, dx, lddx, accumulate, dgamma, dbeta, m, c);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;

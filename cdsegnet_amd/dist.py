@@ -247,3 +247,47 @@ class GradBucketer:
         self.pending = []
         self.buckets_reduced = n_buckets
         return out
+
+
+class GradSync:
+    """Data-parallel training of a model whose backward is torch autograd (cdsegnet_amd/train_graph.py): every parameter
+    hands its gradient to a GradBucketer the moment autograd has accumulated it (post-accumulate hooks: last layers first,
+    so the all-reduce of a full bucket runs next to the rest of the backward), `finish()` waits and writes the averages
+    back into `.grad`.  What torch's DistributedDataParallel does for the reference (engines/defaults.py:38,
+    engines/train.py:216-271), with buckets sized for xGMI (GradBucketer) and no second copy of the parameters.
+
+        sync = GradSync(model)                    # once
+        loss = model(batch)["loss"]; loss.backward(); sync.finish(); optimizer.step()
+
+    Every rank must run the same graph (same model, same options): the order in which gradients become ready - and with it
+    the bucket layout - is the graph's topological order, as in DDP."""
+
+    def __init__(self, model, bucket_bytes=64 << 20, group=None):
+        self.kw = dict(bucket_bytes=bucket_bytes, group=group)
+        self.named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.bucketer = None
+        self.buckets_reduced = 0
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook(n)) for n, p in self.named]
+
+    def _hook(self, name):
+        def hook(p):
+            if self.bucketer is None:
+                self.bucketer = GradBucketer(**self.kw)
+            self.bucketer.add(name, p.grad)
+        return hook
+
+    def finish(self):
+        """Wait for the outstanding all-reduces; every parameter's .grad becomes the mean over the ranks."""
+        b, self.bucketer = self.bucketer, None
+        if b is None:
+            return
+        avg = b.finish()
+        self.buckets_reduced = b.buckets_reduced
+        for n, p in self.named:
+            if n in avg:
+                p.grad.copy_(avg[n])
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []

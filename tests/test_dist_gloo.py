@@ -213,3 +213,74 @@ def test_prediction_gather_three_ranks_gloo(tmp_path):
             assert np.array_equal(g[f"s{i}"], (np.arange(sizes[i]) * (i + 3) % 20 - 1).astype(np.int16))
     single = cdist.gather_predictions([(7, torch.tensor([1, -1, 19]))])
     assert list(single) == [7] and single[7].dtype == torch.int16
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cdsegnet_amd.engine as engine_mod
+        import cdsegnet_amd.models  # noqa: F401
+        import cdsegnet_amd.train_graph as tg
+        from cdsegnet_amd import configs, synth
+        from cdsegnet_amd.param_init import fill_state_dict
+        from cdsegnet_amd.registry import build_model
+        from tests import emu_ops
+        engine_mod.ops = emu_ops
+        tg.ops = emu_ops
+        torch.set_num_threads(2)
+        cfg = configs.mini_config()
+        cfg["backbone"]["enable_flash"] = False
+        cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+                           dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
+                           dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
+        model = build_model(cfg).train()
+        if rank == 0:
+            model.load_state_dict(fill_state_dict(model.state_dict(), seed=3))
+        cdist.broadcast_model(model, src=0)
+
+        def batch(i):  # rank i's scene (seeded: any rank can rebuild any batch) and its recorded draws
+            sc = synth.room_scene(300 + i, 500 + 150 * i, num_classes=cfg["num_classes"])
+            inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset", "segment")}
+            g = torch.Generator().manual_seed(40 + i)
+            n = inp["feat"].shape[0]
+            draws = dict(ts=torch.randint(0, cfg["T"], (1, 1), generator=g), noise=torch.randn(n, cfg["c_in_channels"], generator=g),
+                         perms=[torch.randperm(4, generator=g).tolist() for _ in range(8)], masks={})  # masks {}: no stochastic depth
+            return inp, draws
+
+        sync = cdist.GradSync(model, bucket_bytes=256 * 1024)  # small buckets: several all-reduces per backward
+        inp, draws = batch(rank)
+        loss = model(inp, draws=draws)["loss"]
+        loss.backward()
+        sync.finish()
+        got = {k: p.grad.clone() for k, p in model.named_parameters()}
+        nb = sync.buckets_reduced
+        sync.remove()
+        ref = None
+        if rank == 0:  # single-process reference: the mean of the two ranks' gradients
+            ref = {}
+            for i in range(world):
+                model.zero_grad()
+                inp, draws = batch(i)
+                model(inp, draws=draws)["loss"].backward()
+                for k, p in model.named_parameters():
+                    ref[k] = ref.get(k, 0) + p.grad / world
+        torch.save(dict(got=got, ref=ref, loss=float(loss.detach()), buckets=nb), os.path.join(out_dir, f"train{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_two_ranks_gloo(tmp_path):
+    """Two ranks, one scene each: the training forward + loss.backward() of cdsegnet_amd/train_graph.py with GradSync's
+    bucketed all-reduce (hooked on the parameters) leaves the SAME averaged gradients on both ranks, equal to the mean of the
+    two scenes' gradients computed in one process (ref: DDP in engines/defaults.py:38 + engines/train.py:216-271)."""
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "train0.pt"), torch.load(tmp_path / "train1.pt")
+    assert r0["buckets"] == r1["buckets"] and r0["buckets"] >= 2
+    assert abs(r0["loss"] - r1["loss"]) > 1e-6  # different scenes
+    assert set(r0["got"]) == set(r1["got"]) and len(r0["got"]) == 508
+    for k in r0["got"]:
+        assert torch.equal(r0["got"][k], r1["got"][k]), k
+        r = r0["ref"][k]
+        assert float((r0["got"][k] - r).abs().max()) <= 1e-5 * max(1e-3, float(r.abs().max())), k
