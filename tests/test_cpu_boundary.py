@@ -150,3 +150,36 @@ def test_model_config_equals_the_reference_config_files(ds, variant):
     assert list(sd)[:3] == ref["first_keys"] and list(sd)[-3:] == ref["last_keys"]
     assert hashlib.sha256(schema.encode()).hexdigest() == ref["schema_sha256"]
     assert sum(p.numel() for p in model.parameters()) == ref["n_params"]
+
+
+def test_criteria_reproduce_the_reference_loss_parts():
+    """cdsegnet_amd/losses.py (MSE over the labelled points, cross entropy, multi-class Lovasz-Softmax; "EW" and "GLS"
+    combinations, ref: losses/builder.py:14-52, misc.py:24-132, lovasz.py:118-265) on the predictions the REFERENCE produced
+    in its recorded training step (tests/golden/train_step_mini.npz): the three parts, the GLS loss, d loss / d prediction."""
+    import numpy as np
+    import torch
+    from cdsegnet_amd.losses import build_criteria
+    from tests.helpers import load_fixture
+    fx = load_fixture("train_step_mini.npz")
+    cfg = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+           dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
+           dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
+    n_pred = torch.as_tensor(fx["n_pred"]).requires_grad_(True)
+    c_pred = torch.as_tensor(fx["c_pred"]).requires_grad_(True)
+    point = dict(n_pred=n_pred, c_pred=c_pred, c_target=torch.as_tensor(fx["noise"]), n_target=torch.as_tensor(fx["segment"]),
+                 offset=torch.as_tensor(fx["offset"]), loss_mode="train")
+    crit = build_criteria(cfg, loss_type="GLS", task_num=2)
+    parts = np.array([float(c(point)) for c in crit.criteria])
+    assert np.abs(parts - fx["loss_parts"]).max() < 1e-5
+    loss = crit(point)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5
+    loss.backward()
+    assert float((n_pred.grad - torch.as_tensor(fx["d_n_pred"])).abs().max()) < 1e-7
+    assert float((c_pred.grad - torch.as_tensor(fx["d_c_pred"])).abs().max()) < 1e-7
+    ew = build_criteria(cfg, loss_type="EW", task_num=2)
+    assert abs(float(ew(dict(point))) - float(fx["loss_parts"].sum())) < 1e-5  # "EW": the plain sum
+    point["loss_mode"] = "eval"
+    assert abs(float(crit(point)) - float(fx["loss_parts"].sum())) < 1e-5      # eval mode sums whatever the loss_type
+    import pytest
+    with pytest.raises(NotImplementedError):
+        build_criteria([dict(type="BinaryFocalLoss")])
