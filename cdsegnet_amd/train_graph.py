@@ -23,7 +23,6 @@ statistics), GELU between them, the swish timestep MLP on B rows, row masks of s
 (C -> classes) heads, and the criteria (cdsegnet_amd.losses).  All integer work - serialization, pooling structure,
 kernel maps, padded patch plans - is the inference engine's plan (Engine.build_plan), shared with the inference path.
 """
-import numpy as np
 import torch
 import torch.nn.functional as F
 
