@@ -207,6 +207,10 @@ def _bn_gelu(x, bn):
     return F.gelu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps))
 
 
+def feat_is_cuda(input_dict):
+    return bool(getattr(input_dict.get("feat"), "is_cuda", False))
+
+
 class _St:
     """A branch's point set at one level: features in the plan's physical (batch | z) order."""
 
@@ -343,7 +347,18 @@ class TrainGraph:
     def forward(self, input_dict, draws=None):
         """input_dict: coord, grid_coord, feat, offset, segment on the model's device.  draws (optional, for replaying a
         recorded step): ts (B, 1), noise (N, c_in), perms (8 x 4), masks {DropPath module name: [row masks]}.
-        Returns dict(loss, n_pred, c_pred, c_target)."""
+        Returns dict(loss, n_pred, c_pred, c_target).
+
+        The reference trainer calls the model inside `torch.cuda.amp.autocast(enabled=cfg.enable_amp)` and scales the loss
+        with a GradScaler (engines/train.py:226-240).  This forward is exact fp32 whatever the context: autocast is switched
+        off inside it (torch's own ops here - heads, BatchNorm, GELU - would otherwise hand half tensors to fp32 kernels), so
+        the trainer's AMP branch runs unchanged: the scaler multiplies an fp32 loss and finds no overflow."""
+        if feat_is_cuda(input_dict):
+            with torch.autocast(device_type="cuda", enabled=False):
+                return self._forward(input_dict, draws)
+        return self._forward(input_dict, draws)
+
+    def _forward(self, input_dict, draws=None):
         model, bb = self.model, self.model.backbone
         feat, coord = input_dict["feat"].float(), input_dict["coord"].float()
         dev = feat.device

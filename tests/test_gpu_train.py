@@ -322,3 +322,43 @@ def test_training_forward_default_draws_runs_and_descends():
         opt.step()
     print(f"[measure] training loop on one batch, 4 steps: loss {losses}")
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_reference_run_step_sequence_with_amp_and_grad_scaler():
+    """The reference trainer's run_step (engines/train.py:216-271) with cfg.enable_amp = True, verbatim: the model called
+    inside torch.cuda.amp.autocast, scaler.scale(loss).backward(), gradient clipping, scaler.step(optimizer),
+    scaler.update(), scheduler.step().  The forward stays exact fp32 inside the autocast context (cdsegnet_amd/train_graph.py),
+    so the step must equal the plain fp32 step on the same draws: same loss, same updated parameters."""
+    fx = load_fixture("train_step_mini.npz")
+    dev = torch.device("cuda")
+    masks = lambda: {str(k): [fx[f"mask.{i}.{j}"] for j in range(int(fx["mask_counts"][i]))] for i, k in enumerate(fx["mask_names"])}  # noqa: E731
+    inp = {k: torch.as_tensor(fx[k]).to(dev) for k in ("coord", "grid_coord", "feat", "offset", "segment")}
+    results = []
+    for amp in (False, True):
+        model, _ = _mini_training_model(fx, dev)
+        opt = torch.optim.AdamW(model.parameters(), lr=0.002, weight_decay=0.05)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.002, total_steps=10)
+        scaler = torch.cuda.amp.GradScaler() if amp else None
+        draws = dict(ts=fx["ts"], noise=fx["noise"], perms=[list(p) for p in fx["perms"]], masks=masks())
+        with torch.cuda.amp.autocast(enabled=amp):
+            loss = model(inp, draws=draws)["loss"]
+        assert loss.dtype == torch.float32
+        opt.zero_grad()
+        if amp:
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scale = scaler.get_scale()
+            scaler.update()
+            if scale <= scaler.get_scale():
+                sched.step()
+        else:
+            loss.backward()
+            opt.step()
+            sched.step()
+        torch.cuda.synchronize()
+        results.append((float(loss.detach()), {k: p.detach().clone() for k, p in model.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    worst = max(float((p0[k] - p1[k]).abs().max()) for k in p0)
+    print(f"[measure] run_step with AMP context + GradScaler vs plain fp32 step: loss {l0:.6f} / {l1:.6f}, worst parameter difference {worst:.3e}")
+    assert abs(l0 - l1) < 1e-6 and abs(l0 - float(fx["loss"])) < 1e-4
+    assert worst < 1e-5  # (the scaler's 65536x on the gradients and back is exact in fp32 up to rounding of the scaled values)
