@@ -457,10 +457,14 @@ class DefaultSegmentorV2(nn.Module):
         ``draws`` (optional) injects the random draws: dict(noise=(N,c_in) tensor, perms=[8 x (4,)],
         feat_noise=(N,C) when noise_level is set); by default they are drawn from torch's CPU generator in
         the reference's consumption order, so ``torch.manual_seed`` reproduces the reference bit-for-bit."""
+        logits = self.engine().inference(input_dict, noise_level=noise_level, draws=draws)
         if eval:
-            raise NotImplementedError("eval=True (loss computation) is outside the inference hot path; "
-                                      "the reference tester calls inference(eval=False) (engines/test.py:216)")
-        return dict(seg_logits=self.engine().inference(input_dict, noise_level=noise_level, draws=draws))
+            # ref: default.py:414-420 - the criteria in "eval" mode on the n-branch prediction only (the MSE term finds no
+            # c_pred and contributes 0.0, losses/misc.py:53-54): cross entropy + Lovasz, summed whatever the loss_type
+            from .losses import build_criteria
+            point = dict(n_pred=logits, n_target=input_dict["segment"], loss_mode="eval")
+            return dict(loss=build_criteria(self.criteria_cfg, self.loss_type, self.task_num)(point), seg_logits=logits)
+        return dict(seg_logits=logits)
 
     @torch.no_grad()
     def inference_many(self, input_dicts, lanes=4, noise_level=None, draws=None, threads=False, batch=1):
@@ -551,14 +555,16 @@ class DefaultSegmentorV2(nn.Module):
     def inference_ddim(self, input_dict, T=1000, step=1, report=10, eval=True, mode="avg", noise_level=None, draws=None):
         """Multi-step inference (ref: default.py:278-369): MSAI mode="avg", MSFI mode="final".  The step-invariant
         plan (serialization, kernel maps, slot plans) is built once and reused by all step+1 backbone calls."""
-        if eval:
-            raise NotImplementedError("eval=True (loss computation) is outside the inference hot path")
         if T != self.T:
             raise ValueError("T differs from the model's diffusion length")
         if mode not in ("avg", "final"):
             raise ValueError(mode)
-        return dict(seg_logits=self.engine().inference_ddim(input_dict, step=step, mode=mode, noise_level=noise_level,
-                                                            draws=draws))
+        logits = self.engine().inference_ddim(input_dict, step=step, mode=mode, noise_level=noise_level, draws=draws)
+        if eval:  # ref: default.py:361-367
+            from .losses import build_criteria
+            point = dict(n_pred=logits, n_target=input_dict["segment"], loss_mode="eval")
+            return dict(loss=build_criteria(self.criteria_cfg, self.loss_type, self.task_num)(point), seg_logits=logits)
+        return dict(seg_logits=logits)
 
     def forward(self, input_dict, draws=None):
         """Training forward (ref: default.py:424-493): returns dict(loss=...) under torch autograd - `loss.backward()` fills

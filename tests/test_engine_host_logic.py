@@ -398,3 +398,36 @@ def test_training_step_graph_on_the_emulated_ops_vs_reference_fixture(monkeypatc
             assert float((named[k[2:]].grad - torch.as_tensor(r)).abs().max()) <= 1e-3 * float(np.abs(r).max()), k
             checked += 1
     assert checked == 8
+
+
+def test_inference_eval_true_returns_the_eval_mode_loss(monkeypatch):
+    """inference(eval=True) (ref: default.py:414-420): the criteria in "eval" mode on the n-branch logits - the MSE term finds
+    no c_pred and contributes nothing, cross entropy + Lovasz are summed whatever the loss_type - next to the same logits the
+    eval=False call returns."""
+    import cdsegnet_amd.engine as engine
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.losses import lovasz_softmax
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    from oracle import model as OM
+    monkeypatch.setattr(engine, "ops", emu_ops)
+    cfg = configs.mini_config()
+    cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+                       dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
+                       dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
+    cfg["loss_type"], cfg["task_num"] = "GLS", 2
+    model = build_model(cfg).eval()
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=4))
+    model.precision = "fp32"
+    sc = synth.room_scene(5, 600, num_classes=cfg["num_classes"])
+    inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")}
+    seg = torch.as_tensor(np.asarray(sc["segment"]).astype(np.int64))
+    seg[::11] = -1
+    inp["segment"] = seg
+    draws = OM.draw_rng(3, len(seg), cfg["c_in_channels"])
+    a = model.inference(dict(inp), eval=False, draws=dict(draws))["seg_logits"]
+    out = model.inference(dict(inp), eval=True, draws=dict(draws))
+    assert torch.equal(out["seg_logits"], a)
+    valid = seg != -1
+    want = torch.nn.functional.cross_entropy(a[valid], seg[valid]) + lovasz_softmax(a.softmax(1), seg, -1)
+    assert abs(float(out["loss"]) - float(want)) < 1e-6
