@@ -431,3 +431,73 @@ def test_inference_eval_true_returns_the_eval_mode_loss(monkeypatch):
     valid = seg != -1
     want = torch.nn.functional.cross_entropy(a[valid], seg[valid]) + lovasz_softmax(a.softmax(1), seg, -1)
     assert abs(float(out["loss"]) - float(want)) < 1e-6
+
+
+def test_training_graph_without_condition_vs_oracle_autograd(monkeypatch):
+    """Plain PTv3 (condition=False: configs/*/PTv3.py, default.py:485-489 - no c-branch, no diffusion target): the training
+    forward of cdsegnet_amd/train_graph.py on the emulated ops against torch autograd over the oracle's functions in train mode
+    (batch-statistics BatchNorm; stochastic depth off), cross entropy + Lovasz summed ("EW"): loss and every parameter gradient."""
+    import cdsegnet_amd.engine as engine
+    import cdsegnet_amd.train_graph as tg
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    from oracle import model as OM
+    from oracle import train as OT
+    monkeypatch.setattr(engine, "ops", emu_ops)
+    monkeypatch.setattr(tg, "ops", emu_ops)
+    cfg = configs.mini_config()
+    cfg["condition"] = cfg["backbone"]["condition"] = False
+    cfg["dm"] = False
+    cfg["backbone"]["enable_flash"] = False
+    cfg["backbone"]["drop_path"] = 0.0
+    cfg["criteria"] = [dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
+                       dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
+    cfg["loss_type"] = "EW"
+    model = build_model(cfg).train()
+    sd = fill_state_dict(model.state_dict(), seed=8)
+    model.load_state_dict(sd)
+    sc = synth.collate([synth.room_scene(31, 500, num_classes=cfg["num_classes"]), synth.room_scene(32, 350, num_classes=cfg["num_classes"])])
+    inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")}
+    seg = torch.as_tensor(np.asarray(sc["segment"]).astype(np.int64)) % cfg["num_classes"]
+    seg[::13] = -1
+    inp["segment"] = seg
+    perms = [[2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0], [1, 0, 3, 2], [0, 2, 1, 3], [2, 3, 0, 1], [3, 1, 2, 0]]
+    out = model(inp, draws=dict(perms=perms, masks={}))
+    out["loss"].backward()
+    # ---- oracle: the same functions as oracle.model.inference_ptv3, under autograd and in train mode
+    bcfg = cfg["backbone"]
+    sdt = {k: (v.clone().float().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    OM.FLASH_SEMANTICS = False
+    OM.TRAIN = OT._TrainCtx({})
+    try:
+        B = "backbone"
+        orders, pi = bcfg.get("order", OM.DEFAULT_ORDERS), iter(perms)
+        n = OM.make_point(inp["coord"].float(), np.asarray(inp["grid_coord"], dtype=np.int64), np.asarray(inp["offset"], dtype=np.int64),
+                          inp["feat"].float())
+        OM.serialize_point(n, orders, next(pi))
+        n = OM.embedding(n, sdt, B + "._n_embedding")
+        nd, nh, nK, ns = bcfg["n_enc_depths"], bcfg["n_enc_num_head"], bcfg["n_enc_patch_size"], bcfg["n_stride"]
+        for s in range(len(nd)):
+            n = OM._stage(n, sdt, B + "._n_enc", s, nd[s], nh[s], nK[s], ns[s - 1] if s else None, next(pi) if s else None, False, len(orders))
+        ndd, ndh, ndK = bcfg["n_dec_depths"], bcfg["n_dec_num_head"], bcfg["n_dec_patch_size"]
+        for s in reversed(range(len(nd) - 1)):
+            n = OM.unpooling(n, sdt, f"{B}._n_dec.dec{s}.up", "add", False, None)
+            for i in range(ndd[s]):
+                n = OM.block(n, sdt, f"{B}._n_dec.dec{s}.block{i}", ndh[s], i % len(orders), ndK[s], False)
+        logits = OM.linear(n.feat, sdt, B + "._n_head")
+    finally:
+        OM.TRAIN = None
+    valid = seg != -1
+    ref_loss = torch.nn.functional.cross_entropy(logits[valid], seg[valid]) + OT.lovasz_softmax(logits, seg, -1)
+    ref_loss.backward()
+    assert abs(float(out["loss"].detach()) - float(ref_loss.detach())) < 2e-5
+    assert float((out["n_pred"].detach() - logits.detach()).abs().max()) < 1e-4
+    checked = 0
+    for k, p in model.named_parameters():
+        r = sdt[k].grad
+        assert r is not None and p.grad is not None, k
+        assert float((p.grad - r).abs().max()) <= 1e-3 * max(float(r.abs().max()), 1e-4), k
+        checked += 1
+    assert checked > 250
