@@ -2,7 +2,7 @@
 """One full-width training step (forward under autograd, loss.backward(), AdamW) on a synthetic ScanNet-shaped batch, fp32,
 on the HIP kernels (cdsegnet_amd/train_graph.py).  Not a BASELINE metric - the reference publishes no training throughput -
 a first number for the training row of SURVEY 8(f4).
-usage: python tools/bench_train_step.py [scenes=1] [points=120000] [steps=4]"""
+usage: python tools/bench_train_step.py [scenes=1] [points=120000] [steps=4] [dataset=scannet|scannet200|nuscenes]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -16,15 +16,16 @@ import cdsegnet_amd.models  # noqa: F401
 scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 points = int(sys.argv[2]) if len(sys.argv) > 2 else 120000
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+dataset = sys.argv[4] if len(sys.argv) > 4 else "scannet"
 dev = torch.device("cuda")
-cfg = configs.cdsegnet_config("scannet")
+cfg = configs.cdsegnet_config(dataset)
 cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
                    dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
                    dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
 model = build_model(cfg)
 model.load_state_dict(fill_state_dict(model.state_dict(), seed=0), strict=True)
 model = model.to(dev).train()
-sc = synth.collate([synth.room_scene(i, points) for i in range(scenes)])
+sc = synth.collate([(synth.lidar_scene(i, points) if dataset == "nuscenes" else synth.room_scene(i, points)) for i in range(scenes)])
 inp = {k: torch.as_tensor(sc[k]).to(dev) for k in ("coord", "grid_coord", "feat", "offset")}
 inp["segment"] = (torch.as_tensor(np.asarray(sc["segment"]).astype(np.int64)) % cfg["num_classes"]).to(dev)
 n = inp["feat"].shape[0]
@@ -49,6 +50,6 @@ for it in range(steps + 1):
     if it:
         times.append((t1 - t0, t2 - t1, t3 - t2))
 t = np.median(np.array(times), axis=0) * 1e3
-print(f"training step, full width (101 M parameters), fp32, {scenes} scene(s), {n} points: forward {t[0]:.1f} ms, backward {t[1]:.1f} ms, "
+print(f"training step, {dataset}, full width, fp32, {scenes} scene(s), {n} points: forward {t[0]:.1f} ms, backward {t[1]:.1f} ms, "
       f"AdamW {t[2]:.1f} ms = {t.sum():.1f} ms/step = {n / t.sum() * 1e3 / 1e6:.2f} M points/s; peak memory "
       f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; loss over the steps {[round(v, 4) for v in losses]}")
