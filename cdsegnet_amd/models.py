@@ -573,5 +573,8 @@ class DefaultSegmentorV2(nn.Module):
         from .train_graph import TrainGraph
         if getattr(self, "_train_graph", None) is None:
             self._train_graph = TrainGraph(self)
+        # a training forward is followed by an optimizer step and updates the BatchNorm buffers: the inference engine's
+        # prepared weights (16-bit casts, folded BatchNorm, fragment images) are rebuilt at the next inference() call
+        self._engine = None
         out = self._train_graph.forward(input_dict, draws)
         return out if draws is not None else dict(loss=out["loss"])

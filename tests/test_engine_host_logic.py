@@ -501,3 +501,42 @@ def test_training_graph_without_condition_vs_oracle_autograd(monkeypatch):
         assert float((p.grad - r).abs().max()) <= 1e-3 * max(float(r.abs().max()), 1e-4), k
         checked += 1
     assert checked > 250
+
+
+def test_inference_after_a_training_step_uses_the_updated_weights(monkeypatch):
+    """The inference engine caches prepared weights (casts, folded BatchNorm, fragment images); a training forward drops it,
+    so inference() after loss.backward() + optimizer.step() runs on the NEW parameters and BatchNorm statistics - equal to a
+    freshly built model loaded with the trained state_dict."""
+    import cdsegnet_amd.engine as engine
+    import cdsegnet_amd.train_graph as tg
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    from oracle import model as OM
+    monkeypatch.setattr(engine, "ops", emu_ops)
+    monkeypatch.setattr(tg, "ops", emu_ops)
+    cfg = configs.mini_config()
+    cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+                       dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1),
+                       dict(type="LovaszLoss", mode="multiclass", loss_weight=1.0, ignore_index=-1)]
+    cfg["loss_type"] = "GLS"
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=6))
+    model.precision = "fp32"
+    sc = synth.room_scene(12, 500, num_classes=cfg["num_classes"])
+    inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")}
+    inp["segment"] = torch.as_tensor(np.asarray(sc["segment"]).astype(np.int64)) % cfg["num_classes"]
+    draws = OM.draw_rng(1, len(inp["segment"]), cfg["c_in_channels"])
+    before = model.eval().inference(dict(inp), eval=False, draws=dict(draws))["seg_logits"].clone()
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    torch.manual_seed(0)
+    model(inp)["loss"].backward()
+    opt.step()
+    after = model.eval().inference(dict(inp), eval=False, draws=dict(draws))["seg_logits"]
+    assert float((after - before).abs().max()) > 1e-4
+    fresh = build_model(cfg).eval()
+    fresh.load_state_dict(model.state_dict())
+    fresh.precision = "fp32"
+    want = fresh.inference(dict(inp), eval=False, draws=dict(draws))["seg_logits"]
+    assert torch.equal(after, want)
