@@ -171,14 +171,21 @@ class _SegmentMax(torch.autograd.Function):
         one = torch.ones(c, dtype=torch.float32, device=y.device)
         out = _f32((m, c), y)
         ops.segment_max(y, seg, m, one, torch.zeros_like(one), ops.ACT_NONE, out)
-        ctx.save_for_backward(y, out, cluster)
+        ctx.save_for_backward(y, out, seg[:m + 1], cluster)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, out, cluster = ctx.saved_tensors
+        y, out, seg, cluster = ctx.saved_tensors
         cl = cluster.long()
-        return (y == out[cl]).to(dout.dtype) * dout[cl], None, None, None
+        hit = y == out[cl]
+        # exactly ONE child per (pooled row, channel) receives the gradient - the first that holds the maximum, like
+        # segment_csr's arg-max (torch_scatter updates its arg only on a strictly larger value); ties are rare but exist
+        # (GELU outputs saturate, duplicate points)
+        cs = hit.to(torch.int32).cumsum(0)
+        before = (cs - hit.to(torch.int32))[seg[:-1].long()]  # hits in front of each segment, per channel
+        first = hit & ((cs - before[cl]) == 1)
+        return first.to(dout.dtype) * dout[cl], None, None, None
 
 
 class _SceneRows(torch.autograd.Function):

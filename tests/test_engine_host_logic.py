@@ -540,3 +540,21 @@ def test_inference_after_a_training_step_uses_the_updated_weights(monkeypatch):
     fresh.precision = "fp32"
     want = fresh.inference(dict(inp), eval=False, draws=dict(draws))["seg_logits"]
     assert torch.equal(after, want)
+
+
+def test_segment_max_backward_sends_the_gradient_to_the_first_maximum(monkeypatch):
+    """train_graph._SegmentMax: forward = per-channel maximum over contiguous children; backward = the pooled row's gradient
+    to exactly one child per channel, the FIRST that holds the maximum (torch_scatter.segment_csr's arg-max) - with ties."""
+    import cdsegnet_amd.train_graph as tg
+    monkeypatch.setattr(tg, "ops", emu_ops)
+    y = torch.tensor([[1., 5., 2.], [3., 5., 2.], [3., 1., 2.],      # segment 0: ties in every channel
+                      [0., 0., 7.],                                   # segment 1: one child
+                      [4., 9., 1.], [4., 2., 1.]], requires_grad=True)  # segment 2
+    seg = torch.tensor([0, 3, 4, 6], dtype=torch.int32)
+    cluster = torch.tensor([0, 0, 0, 1, 2, 2], dtype=torch.int32)
+    out = tg._SegmentMax.apply(y, seg, cluster, 3)
+    assert torch.equal(out, torch.tensor([[3., 5., 2.], [0., 0., 7.], [4., 9., 1.]]))
+    g = torch.arange(1., 10.).reshape(3, 3)
+    out.backward(g)
+    want = torch.tensor([[0., 2., 3.], [1., 0., 0.], [0., 0., 0.], [4., 5., 6.], [7., 8., 9.], [0., 0., 0.]])
+    assert torch.equal(y.grad, want)
