@@ -155,6 +155,10 @@ SIGNATURES = {
     "cdseg_segment_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_int,
                                   c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "cdseg_segment_mean": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
+    "cdseg_pool_fused_img_bytes": (c_size_t, [c_int, c_int]),
+    "cdseg_pool_fused_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "cdseg_pool_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p, c_int, c_int, c_int, c_void_p]),
     "cdseg_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cdseg_randn": (c_int, [c_void_p, c_long, c_uint64, c_uint64, c_void_p]),
     "cdseg_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),

@@ -139,15 +139,22 @@ template <> struct Cvt<bf16_t> {
 // rounding): one v_rcp + one v_exp + a 5-term Horner chain.  libm's erff costs ~3x as much and was 40 % of the
 // fc1 (Linear -> GELU) launches on the 120k-point stages.
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-  const float erf_abs = 1.0f - p * t * e;  // erf(|x| / sqrt 2)
-  return 0.5f * x + 0.5f * fabsf(x) * erf_abs;  // 0.5 x (1 + sign(x) erf_abs)
+  // every rounding is written out (no implicit contraction): the same inputs give the same bits in every kernel that
+  // inlines this - cdseg_pool_fused and cdseg_segment_max evaluate the same epilogue and are compared bit for bit
+#pragma clang fp contract(off)
+  const float ax = fabsf(x);
+  const float z = ax * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float zz = z * z;
+  const float e = __builtin_amdgcn_exp2f(zz * -1.44269504088896340736f);
+  const float pt = p * t;
+  const float erf_abs = __builtin_fmaf(-pt, e, 1.0f);  // erf(|x| / sqrt 2)
+  const float hx = 0.5f * x, hax = 0.5f * ax;
+  return __builtin_fmaf(hax, erf_abs, hx);  // 0.5 x (1 + sign(x) erf_abs)
 }
 
 // erf-form GELU where the result is rounded to the 16-bit type next (hidden activations of the MLPs): x Phi(x) with

@@ -111,7 +111,9 @@ __global__ void segment_max_kernel(const void* __restrict__ y, int y_dtype, int 
     if (scale) {
       const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * ch);
       const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * ch);
-      mx.x = mx.x * sc.x + sh.x; mx.y = mx.y * sc.y + sh.y; mx.z = mx.z * sc.z + sh.z; mx.w = mx.w * sc.w + sh.w;
+      // (explicit fused multiply-adds: cdseg_pool_fused evaluates the same expression and must agree bit for bit)
+      mx.x = __builtin_fmaf(mx.x, sc.x, sh.x); mx.y = __builtin_fmaf(mx.y, sc.y, sh.y);
+      mx.z = __builtin_fmaf(mx.z, sc.z, sh.z); mx.w = __builtin_fmaf(mx.w, sc.w, sh.w);
     }
     if (act == CDSEG_ACT_GELU) {
       mx.x = gelu_erf(mx.x); mx.y = gelu_erf(mx.y); mx.z = gelu_erf(mx.z); mx.w = gelu_erf(mx.w);

@@ -286,6 +286,9 @@ class Engine:
         def pool(mod, pre):
             lin(mod.proj, pre + ".proj")
             bn(mod.norm[0], pre + ".bn")
+            pw = w[pre + ".proj.w"]
+            if hasattr(ops, "pool_fused_ok") and ops.pool_fused_ok(pw.shape[1], pw.shape[0], T):
+                w[pre + ".proj.wimg"] = ops.pool_fused_pack(pw)  # one-launch pooling of the wide stages (csrc/pool.hip)
 
         def unpool(mod, pre):
             lin(mod.proj[0], pre + ".proj")
@@ -709,12 +712,19 @@ class Engine:
         fine, coarse = st.level, plan.levels[cum_to]
         _, seg = plan.link(fine.cum, cum_to)
         cout = w[pre + ".proj.w"].shape[0]
-        y = self._buf(fine.n, cout, self.T)
-        ops.gemm(st.xc, w[pre + ".proj.w"], y, bias=w[pre + ".proj.b"])
         x = self._buf(coarse.n, cout, torch.float32)
         xc = x if self.T == torch.float32 else self._buf(coarse.n, cout, self.T)
-        ops.segment_max(y, seg, coarse.n, w[pre + ".bn.scale"], w[pre + ".bn.shift"], ops.ACT_GELU, x,
-                        None if xc is x else xc)
+        if (pre + ".proj.wimg") in w and st.xc.stride(0) == st.xc.shape[1] and fine.n <= 5 * coarse.n:
+            # wide 16-bit stages: projection + maximum + BatchNorm + GELU in one launch, the projected rows stay on the CU
+            # (one octree step, ~2.2 children per pooled row: 118 -> 67 us on the first pooling of a collated forward; the
+            # c-branch's two-step pooling, ~8.4 children, folds too many rows per lane and stays on the two launches)
+            ops.pool_fused(st.xc, w[pre + ".proj.wimg"], w[pre + ".proj.b"], seg, coarse.n, w[pre + ".bn.scale"],
+                           w[pre + ".bn.shift"], ops.ACT_GELU, x, xc)
+        else:
+            y = self._buf(fine.n, cout, self.T)
+            ops.gemm(st.xc, w[pre + ".proj.w"], y, bias=w[pre + ".proj.b"])
+            ops.segment_max(y, seg, coarse.n, w[pre + ".bn.scale"], w[pre + ".bn.shift"], ops.ACT_GELU, x,
+                            None if xc is x else xc)
         curves = st.curves if perm is None else [st.curves[int(j)] for j in perm]
         out = State(coarse, x, xc, curves)
         out.parent = st

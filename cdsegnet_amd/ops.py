@@ -748,6 +748,31 @@ def segment_max(y, seg_start, m, scale, shift, act, out, out2=None):
     return out
 
 
+def pool_fused_ok(cin, cout, dtype):
+    """The one-launch pooling (csrc/pool.hip) covers the wide 16-bit stages: 32 -> 64 and 64 -> 128 channels."""
+    return is_lp(dtype) and (int(cin), int(cout)) in ((32, 64), (64, 128))
+
+
+def pool_fused_pack(w):
+    """(cout, cin) 16-bit projection weight -> its MFMA-fragment image (built once per weight)."""
+    _need_gpu(w)
+    cout, cin = w.shape
+    lib = _lib.load()
+    img = torch.empty(lib.cdseg_pool_fused_img_bytes(cin, cout), dtype=torch.uint8, device=w.device)
+    check(lib.cdseg_pool_fused_pack(_ptr(w), cin, cout, _ptr(img), _stream()), "pool_fused_pack")
+    return img
+
+
+def pool_fused(x, wimg, bias, seg_start, m, scale, shift, act, out, out2=None):
+    """out (m, cout) fp32 = act(scale * max over each run of round16(x W^T + bias) + shift), out2 its 16-bit copy."""
+    _need_gpu(x, out)
+    cin, cout = x.shape[1], out.shape[1]
+    check(_lib.load().cdseg_pool_fused(_ptr(x), x.stride(0), _ptr(wimg), _ptr(bias), _ptr(seg_start), int(m), _ptr(scale),
+                                       _ptr(shift), int(act), _ptr(out), out.stride(0), _ptr(out2),
+                                       out2.stride(0) if out2 is not None else 0, cin, cout, _stream()), "pool_fused")
+    return out
+
+
 def segment_mean(x, seg_start, m):
     out = torch.empty((m, x.shape[1]), dtype=torch.float32, device=x.device)
     check(_lib.load().cdseg_segment_mean(_ptr(x), x.stride(0), _ptr(seg_start), m, x.shape[1], _ptr(out),

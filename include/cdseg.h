@@ -232,6 +232,16 @@ int cdseg_prof_summary_class(int cls, double* total_ms, long* launches);
 int cdseg_segment_max(const void* y, int y_dtype, int ldy, const int32_t* seg_start, long m, int c,
                       const float* scale, const float* shift, int act, float* out, int ldo, void* out2,
                       int out2_dtype, int ldo2, void* stream);
+/* The whole SerializedPooling feature path in one launch (16-bit trunk; ref: ptv3.py:506-515 proj + segment_csr("max"),
+ * :548-551 norm + act):   out[j] = act(scale * max_{i in run j} round16(W x_i + bias) + shift),   out2 = 16-bit copy.
+ * Bit-identical to cdseg_gemm (16-bit output) followed by cdseg_segment_max; the projected rows never reach HBM.
+ * (cin, cout) = (32, 64) or (64, 128), else CDSEG_ERR_UNSUPPORTED (callers use the two-launch form).  wimg: fragment image
+ * of W (cout, cin) built once by cdseg_pool_fused_pack (cdseg_pool_fused_img_bytes bytes).  act: NONE or GELU. */
+size_t cdseg_pool_fused_img_bytes(int cin, int cout);
+int cdseg_pool_fused_pack(const void* w, int cin, int cout, void* wimg, void* stream);
+int cdseg_pool_fused(const void* x, int ldx, const void* wimg, const float* bias, const int32_t* seg_start, long m,
+                     const float* scale, const float* shift, int act, float* out, int ldo, void* out2, int ldo2,
+                     int cin, int cout, void* stream);
 /* segment mean of coord (ref: ptv3.py:513-515) */
 int cdseg_segment_mean(const float* x, int ldx, const int32_t* seg_start, long m, int c, float* out, int ldo,
                        void* stream);

@@ -395,6 +395,20 @@ def segment_max(y, seg_start, m, scale, shift, act, out, out2=None):
     return out
 
 
+def pool_fused_ok(cin, cout, dtype):
+    return is_lp(dtype) and (int(cin), int(cout)) in ((32, 64), (64, 128))
+
+
+def pool_fused_pack(w):
+    return w.clone()  # the emulation keeps the row-major weight as its "image"
+
+
+def pool_fused(x, wimg, bias, seg_start, m, scale, shift, act, out, out2=None):
+    y = torch.empty((x.shape[0], wimg.shape[0]), dtype=x.dtype)
+    gemm(x, wimg, y, bias=bias)
+    return segment_max(y, seg_start, m, scale, shift, act, out, out2)
+
+
 def segment_mean(x, seg_start, m):
     seg = seg_start[:m + 1].long()
     cluster = np.repeat(np.arange(m), np.diff(seg.numpy()))

@@ -1223,6 +1223,55 @@ def test_deep_conv_group_skipping_random_map(ops, lp, n, C):
 
 
 @LPS
+@pytest.mark.parametrize("cin,cout,m,maxrun,seed", [(32, 64, 1000, 8, 0), (64, 128, 777, 8, 1), (32, 64, 5, 70, 2), (32, 64, 40000, 8, 3),
+                                                  (64, 128, 3000, 64, 4), (32, 64, 1, 1, 5)])
+def test_pool_fused_equals_gemm_then_segment_max(ops, lp, cin, cout, m, maxrun, seed):
+    """cdseg_pool_fused (csrc/pool.hip: SerializedPooling's projection + segment maximum + folded BatchNorm + GELU in one
+    launch, ref: ptv3.py:506-515, 548-551) == cdseg_gemm into a 16-bit buffer followed by cdseg_segment_max, BIT FOR BIT
+    (rounding to the 16-bit type is monotonic, so it commutes with the maximum), on ragged runs - single children, runs longer
+    than a 16-row strip (the c-branch pools 4 x 4 x 4 cells), a last chunk of fewer than 16 pooled rows - and against plain
+    torch on the same 16-bit operands."""
+    g = torch.Generator().manual_seed(seed)
+    bf = LP()
+    runs = torch.randint(1, maxrun + 1, (m,), generator=g)
+    seg = torch.cat([torch.zeros(1, dtype=torch.int64), runs.cumsum(0)]).int()
+    n = int(seg[-1])
+    x = _bf16_round(torch.randn(n, cin, generator=g))
+    w = _bf16_round(torch.randn(cout, cin, generator=g) / cin ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.3
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    sc[::7] *= -1.0  # a folded BatchNorm scale can be negative: the maximum is taken BEFORE it
+    xd, wd, segd = dev(x, bf), dev(w, bf), dev(seg)
+    assert ops.pool_fused_ok(cin, cout, bf)
+    img = ops.pool_fused_pack(wd)
+    out = torch.full((m, cout), float("nan"), device="cuda")
+    out2 = torch.full((m, cout), float("nan"), dtype=bf, device="cuda")
+    ops.pool_fused(xd, img, dev(b), segd, m, dev(sc), dev(sh), ops.ACT_GELU, out, out2)
+    y = torch.empty(n, cout, dtype=bf, device="cuda")
+    ops.gemm(xd, wd, y, bias=dev(b))
+    ref, ref2 = torch.empty(m, cout, device="cuda"), torch.empty(m, cout, dtype=bf, device="cuda")
+    ops.segment_max(y, segd, m, dev(sc), dev(sh), ops.ACT_GELU, ref, ref2)
+    report(f"pool fused vs two launches {cin}->{cout} m={m} {lp}", fp32_mismatches=int((out != ref).sum()),
+           lp_mismatches=int((out2 != ref2).sum()), max_diff=(out - ref).abs().max().item())
+    assert torch.equal(out, ref) and torch.equal(out2, ref2)
+    cluster = torch.repeat_interleave(torch.arange(m), runs)
+    yt = _bf16_round(x @ w.t() + b)
+    mx = torch.full((m, cout), -float("inf")).scatter_reduce(0, cluster[:, None].expand(-1, cout), yt, "amax")
+    want = F.gelu(mx * sc + sh)
+    err = (out.cpu() - want).abs().max().item()
+    report(f"pool fused {cin}->{cout} m={m} {lp}", max_err=err)
+    assert err < (2e-2 if lp == "bf16" else 3e-3)  # (a projected value on a 16-bit rounding boundary: fp32 summation order)
+    # no scale / shift / activation, no 16-bit copy
+    out3 = torch.empty(m, cout, device="cuda")
+    ops.pool_fused(xd, img, None, segd, m, None, None, ops.ACT_NONE, out3)
+    y0 = torch.empty(n, cout, dtype=bf, device="cuda")
+    ops.gemm(xd, wd, y0)
+    ref3 = torch.empty(m, cout, device="cuda")
+    ops.segment_max(y0, segd, m, None, None, ops.ACT_NONE, ref3)
+    assert torch.equal(out3, ref3)
+
+
+@LPS
 @pytest.mark.parametrize("npts,C,tb", [(900, 32, True), (2300, 64, False), (2300, 128, True), (5300, 256, False), (40, 256, True)])
 def test_native_block_executor_vs_oracle_block(ops, lp, npts, C, tb):
     """cdseg_block_forward - ONE host call per Block: sparse conv, fused head, attention, fused tail, the kernels the
