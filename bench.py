@@ -657,7 +657,7 @@ def main():
                 gbs = iso["conv_bytes"] / (iso["conv_ms"] * 1e-3) / 1e9
                 res["roofline_conv"] = {
                     "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                    "kernel": "conv_ll_kernel<32|64> + gemm_dma_kernel<128, GATHER> (all k = 3 sparse convs of the forward; the C >= 128 ones are MFMA-side bound)",
+                    "kernel": "conv_ll_kernel<32|64> + gemm_dma_kernel<128 | 256, GATHER> (all k = 3 sparse convs of the forward; the C >= 128 ones - 128 x 128 tiles, C >= 256: 256 x 256 tiles of 8 waves - are bound by the LDS fill path and the matrix pipe, DESIGN 4.2)",
                     "launches_per_forward": iso["conv_launches"] / r, "kernel_ms_per_forward": iso["conv_ms"] / r,
                     "algorithmic_mb_per_forward": iso["conv_bytes"] / r / 1e6,
                     "bytes": "features in + out, kernel map as stored (27 x int32 per point), weights once"}
