@@ -49,6 +49,7 @@ class BlockDesc(Structure):
         ("norm2_g", c_void_p), ("norm2_b", c_void_p), ("fc1_w", c_void_p), ("fc1_b", c_void_p),
         ("fc2_w", c_void_p), ("fc2_b", c_void_p), ("cpe_conv_wimg", c_void_p),
         ("head_img", c_void_p), ("tail_img", c_void_p),
+        ("attn_flags", c_int),
     ]
 
 
@@ -117,7 +118,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "cdseg_cpe_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int,
-                                     c_void_p]),
+                                     c_int, c_void_p]),
     "cdseg_subm_conv3_wimg_bytes": (c_size_t, [c_int]),
     "cdseg_subm_conv3_pack": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "cdseg_subm_conv3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
@@ -129,7 +130,7 @@ SIGNATURES = {
     "cdseg_block_rr_img_bytes": (c_size_t, [c_int, c_int]),
     "cdseg_block_rr_pack": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cdseg_cpe_head_rr": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                  c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+                                  c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "cdseg_attn_tail_rr": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
@@ -138,6 +139,9 @@ SIGNATURES = {
                                 c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "cdseg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "cdseg_attention_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cdseg_attention_schedule": (c_long, [c_int, c_int, c_int, c_int, c_void_p, c_long]),
     "cdseg_attention_bwd_ws_bytes": (c_size_t, [c_long, c_int]),
     "cdseg_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_long, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -34,11 +34,14 @@
 // barrier-free dataflow form (tasks claimed by LDS compare-and-swap, stage recycled by the last finisher: 261 us
 // against 233 us for this form at 960k points x 2 heads).
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 #include "prof.h"
 
 namespace {
+
+constexpr int ATTN_ZONES = 5;
 
 struct AttnP {
   const void* q;
@@ -52,35 +55,58 @@ struct AttnP {
   int ldq, ldk, ldv, ldo;
   int num_heads;
   int num_patches;
-  int qsplit;
-  int hgroups;  // head groups per patch: the unit pinned to one XCD is (patch, head group)
   float scale_log2e;
+  int flags;  // CDSEG_ATTN_Q_PRESCALED | CDSEG_ATTN_V_BF16
+  // schedule: the (patch, head) units of an XCD, in launch order, fall into zones - zcnt[k] units (-1: whatever the XCD
+  // has left = the bulk zone) cut into zsplit[k] query slices each
+  int nzones;
+  int zcnt[ATTN_ZONES];
+  int zsplit[ATTN_ZONES];
+  int zfixed;    // sum of the fixed zone sizes
+  int bulk_max;  // largest bulk zone over the XCDs (the grid's extent of that zone)
 };
 
-// XCD-aware block -> (patch, head, query-slice) map.  Workgroups are dispatched round-robin over the 8 XCDs
-// (block b -> XCD b % 8, a performance-only assumption).  The unit pinned to one XCD is a (patch, head group): all its
-// blocks (heads and query slices read the same gathered rows) get ids that are equal mod 8 and adjacent in time, so
-// the rows are fetched into ONE L2 once.  XCD x owns the CONTIGUOUS run of groups [G x / 8, G (x + 1) / 8): patches
-// that follow each other on the curve are neighbours in space and their rows interleave in memory (a 192-byte qkv
-// row shares a 128-byte line with the next row), so neighbouring patches belong on the same L2 - with the patches
-// dealt round-robin the shared lines were fetched by two XCDs (1.27x the algorithmic HBM bytes at C = 32).  With
-// fewer than 8 patches (deep stages) the heads of a patch are split into `hgroups` groups so that all XCDs still get
-// work.  Grid = ceil(G / 8) * 8 * (H / hgroups) * Q blocks with G = P * hgroups; surplus ids exit.
-__device__ __forceinline__ bool decode_block(const AttnP& p, int& patch, int& head, int& qslice) {
-  const int hpg = p.num_heads / p.hgroups;  // heads per group
-  const int per_group = hpg * p.qsplit;
-  const int G = p.num_patches * p.hgroups;
-  const int B = blockIdx.x;
+// XCD-aware block -> (patch, head, query slice) map.  Workgroups are dispatched round-robin over the 8 XCDs (block b ->
+// XCD b % 8, a performance-only assumption).  The U = P * H (patch, head) units are numbered patch-major and XCD x owns
+// the CONTIGUOUS run [U x / 8, U (x + 1) / 8): the heads of a patch read the same gathered rows (a 192-byte qkv row at
+// C = 32 holds both heads), and patches that follow each other on the curve are neighbours in space whose rows interleave
+// in memory, so neighbouring units belong on the same L2, adjacent in time - with the patches dealt round-robin the
+// shared lines were fetched by two XCDs (1.27x the algorithmic HBM bytes at C = 32).  At most 7 patches per launch
+// straddle two XCDs.  Surplus block ids exit.
+//
+// Graded schedule (round 5).  A launch of equal blocks on S block slots ends with a round in which the slots drain: the
+// in-kernel stamps show a 4096-wave chip 80 % occupied over a 1876-block launch and 9 % over its last tenth
+// (profiles/r03_attention_timing.txt, r05_attention_sched.txt).  So the blocks an XCD runs LAST (and, optionally, some of
+// its first ones) cover fewer queries: zones, in launch order, of (units, slices per unit); a slice stages the whole
+// K / V of its patch-head and takes every `split`-th run of 8 query tiles.  The host sizes the zones (plan_zones);
+// a block's `qsplit` is zone-dependent and wave-uniform.  Results do not depend on the schedule (every output row is
+// written by exactly one lane pair, with the same arithmetic).
+__host__ __device__ __forceinline__ bool decode_block(const AttnP& p, int B, int& patch, int& head, int& qslice, int& qsplit) {
+  const int U = p.num_patches * p.num_heads;
   const int xcd = B & 7;
-  const int t = B >> 3;
-  const int r = t % per_group;
-  const int g = (int)(((long)G * xcd) >> 3) + t / per_group;
-  if (g >= (int)(((long)G * (xcd + 1)) >> 3)) return false;
-  patch = g / p.hgroups;
-  const int hg = g - patch * p.hgroups;
-  head = hg * hpg + r / p.qsplit;
-  qslice = r % p.qsplit;
-  return true;
+  int t = B >> 3;
+  const int u0 = (int)(((long)U * xcd) >> 3), u1 = (int)(((long)U * (xcd + 1)) >> 3);
+  int j0 = 0;
+  for (int z = 0; z < p.nzones; ++z) {
+    const int fixed = p.zcnt[z];
+    const int cnt = fixed >= 0 ? fixed : (u1 - u0) - p.zfixed;  // this XCD's units in the zone
+    const int ext = fixed >= 0 ? fixed : p.bulk_max;            // the grid's extent of the zone
+    const int split = p.zsplit[z];
+    const int nb = ext * split;
+    if (t < nb) {
+      const int jl = t / split;
+      if (jl >= cnt) return false;
+      const int u = u0 + j0 + jl;
+      patch = u / p.num_heads;
+      head = u - patch * p.num_heads;
+      qslice = t - jl * split;
+      qsplit = split;
+      return true;
+    }
+    t -= nb;
+    j0 += cnt;
+  }
+  return false;
 }
 
 constexpr int VT_STRIDE_F32 = 4128;  // 1024 f32 + 32 B pad
@@ -104,6 +130,25 @@ constexpr int SMEM_F32 = KS_BYTES_F32 + 16 * VT_STRIDE_F32;
 #endif
 #ifndef ATTN_PRIO_OUTSIDE
 #define ATTN_PRIO_OUTSIDE 1
+#endif
+#ifndef ATTN_STORE16
+#define ATTN_STORE16 1
+#endif
+// graded schedule: blocks per XCD in the lead / tail zones (plan_zones; 0 = zone off)
+#ifndef ATTN_LEAD_BLOCKS
+#define ATTN_LEAD_BLOCKS 0
+#endif
+#ifndef ATTN_TAIL1_BLOCKS
+#define ATTN_TAIL1_BLOCKS 64
+#endif
+#ifndef ATTN_TAIL2_BLOCKS
+#define ATTN_TAIL2_BLOCKS 64
+#endif
+// ... and only for launches of at least this many (patch, head) units per XCD (1.5 rounds of its 64 block slots): below,
+// the chip is not full to begin with and every extra slice is a K / V staging that buys nothing (measured -10 .. -25 % on
+// the deep stages and on single scenes, profiles/r05_attention_sched.txt)
+#ifndef ATTN_ZONE_MIN_UNITS
+#define ATTN_ZONE_MIN_UNITS 96
 #endif
 constexpr int ATTN_THREADS = 512;  // 8 waves: 2 per SIMD per block, 2 blocks per CU (LDS 66 KB each)
 constexpr int ATTN_WAVES = ATTN_THREADS / 64;
@@ -186,8 +231,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int patch, head, qslice;
-  if (!decode_block(p, patch, head, qslice)) return;
+  int patch, head, qslice, qsplit;
+  if (!decode_block(p, (int)blockIdx.x, patch, head, qslice, qsplit)) return;
 #ifdef CDSEG_ATTN_TIMING
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_loop = 0, t_first = 0, t_epi = 0, n_tiles = 0;
@@ -215,11 +260,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
       unsigned i = 0;
       if (lane == 0) i = atomicAdd(s_next, 1u);
       i = __builtin_amdgcn_readfirstlane(i);
-      if (ATTN_FIRST_STATIC && p.qsplit == 1) {  // tiles 4w are pre-assigned (below): hand out the others, in order
+      if (ATTN_FIRST_STATIC && qsplit == 1) {  // tiles 4w are pre-assigned (below): hand out the others, in order
         const int t = (int)(i + i / 3u + 1u);
         return t < nqt ? t : -1;
       }
-      const int base = (qslice + (int)(i >> 3) * p.qsplit) * ATTN_WAVES;
+      // a slice takes every qsplit-th run of 8 query tiles; the tiles of its first run are pre-assigned (run base + wave,
+      // below: the counter starts at 8)
+      const int base = (qslice + (int)(i >> 3) * qsplit) * ATTN_WAVES;
       if (base >= nqt) return -1;
       const int t = base + (int)(i & 7);
       if (t < nqt) return t;
@@ -245,7 +292,12 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     int gq[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) gq[i] = p.q_gidx[ps + min(wave * 128 + i * 64 + lane, L - 1)];
-    if (tid == 0) *s_next = 0u;
+    // the wave's FIRST query tile is fixed: tile 4 w of an unsliced patch-head (its rows are the first 32 of the indices
+    // just loaded), tile `first run of the slice` + w of a slice (its row indices are fetched here, with the others)
+    const int qt_slice0 = qslice * ATTN_WAVES + wave;
+    int gfirst = 0;
+    if (ATTN_FIRST_STATIC && qsplit > 1) gfirst = p.q_gidx[ps + min(qt_slice0 * 32 + ql, L - 1)];
+    if (tid == 0) *s_next = (ATTN_FIRST_STATIC && qsplit > 1) ? 8u : 0u;
     // (the compiler waits for its own loads above; the DMAs are invisible to it and are waited for by hand below)
     // all source addresses first (pinned by the empty asm): the compiler's vmcnt(0) for an index load must not sit
     // between two DMAs, where it would wait for the DMA before it as well
@@ -273,10 +325,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     // query rows are fetched here, next to the K / V DMAs: claimed and fetched after the barrier, they were an exposed
     // index -> row load chain issued at key-loop priority behind the older waves (in-kernel stamps: 14.5 % of a wave's
     // life between the barrier and its first key loop)
-    if (ATTN_FIRST_STATIC && p.qsplit == 1 && 4 * wave < nqt) {
+    if (ATTN_FIRST_STATIC && qsplit == 1 && 4 * wave < nqt) {
       qt_first = 4 * wave;
       const int g = __shfl(gq[0], lane & 31, 64);
       q_first = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + (long)g * p.ldq + head * 16 + h * 8);
+    } else if (ATTN_FIRST_STATIC && qsplit > 1 && qt_slice0 < nqt) {
+      qt_first = qt_slice0;
+      q_first = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + (long)gfirst * p.ldq + head * 16 + h * 8);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) s_qidx[wave * 128 + i * 64 + lane] = gq[i];
@@ -290,8 +345,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     for (int i = 0; i < 4; ++i) {
       const int pc = wave + ATTN_WAVES * i;
       if (pc < nkt) {
-        if (LP_IS_F16) {
-          // half build: Q and K stay half (the scores keep 11-bit operands), the P V product runs in bfloat16 - P =
+        if (LP_IS_F16 && !(p.flags & CDSEG_ATTN_V_BF16)) {
+          // half build, V in half (a producer that writes V as bfloat16 sets CDSEG_ATTN_V_BF16 and this pass is skipped): Q and K stay half (the scores keep 11-bit operands), the P V product runs in bfloat16 - P =
           // exp2(s - bound) needs fp32's exponent range (the bound may be loose by tens of octaves, half underflows at
           // 2^-24) - so the lane rewrites the 8 V values it fetched itself as bfloat16, in place
           uint4* vp = reinterpret_cast<uint4*>(smem + KV_STAGE + pc * 1024 + lane * 16);
@@ -340,15 +395,22 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
   while (qt >= 0) {
     // Q' = Q * (softmax scale * log2 e), rounded to bf16 once: scores come out of the MFMA in exp2 units (consumed
     // BEFORE the next loads are issued: the compiler's wait for q_cur then has nothing younger in the queue)
+    // (CDSEG_ATTN_Q_PRESCALED: the producer's weights already carry that factor - Engine.prepare folds it into Wq / bq -
+    // and the fetched row IS the operand)
     bf16x8_t qf;
     {
       union { bf16x8_t v; uint32_t u[4]; } qs;
       const uint32_t qr[4] = {q_cur.x, q_cur.y, q_cur.z, q_cur.w};
+      if (p.flags & CDSEG_ATTN_Q_PRESCALED) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float lo, hi;
-        unpack_bf16x2(qr[j], lo, hi);
-        qs.u[j] = pack_bf16x2(lo * c, hi * c);
+        for (int j = 0; j < 4; ++j) qs.u[j] = qr[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo, hi;
+          unpack_bf16x2(qr[j], lo, hi);
+          qs.u[j] = pack_bf16x2(lo * c, hi * c);
+        }
       }
       qf = qs.v;
       asm volatile("" : "+v"(qf));
@@ -427,15 +489,29 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     // ---- epilogue: O^T rows (r&3) + 8*(r>>2) + 4h; row 16 (lane h=0, r=8) is the denominator
     const float lsum = __shfl(o[8], ql, 64);
     const float inv = 1.0f / lsum;
-    if (w >= 0) {
-      bf16_t* orow = (bf16_t*)p.out + (long)w * p.ldo + head * 16 + 4 * h;
-      uint2 a, b;
+    {
+      uint2 a, b;  // a: d = 4h .. 4h+3, b: d = 8+4h .. 8+4h+3 of query ql
       a.x = pack_bf16x2(o[0] * inv, o[1] * inv);
       a.y = pack_bf16x2(o[2] * inv, o[3] * inv);
       b.x = pack_bf16x2(o[4] * inv, o[5] * inv);
       b.y = pack_bf16x2(o[6] * inv, o[7] * inv);
-      *reinterpret_cast<uint2*>(orow) = a;      // d = 4h .. 4h+3
-      *reinterpret_cast<uint2*>(orow + 8) = b;  // d = 8+4h .. 8+4h+3
+#if ATTN_STORE16
+      // one 16-byte store per lane instead of two 8-byte ones: lanes q and q + 32 hold the two halves of each 8-dim run
+      // of query q; v_permlane32_swap exchanges a[32..63] with b[0..31], after which lane q holds d = 0..7 and lane
+      // q + 32 holds d = 8..15 (a = first, b = second half of the run)
+      const auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+      if (w >= 0) {
+        bf16_t* orow = (bf16_t*)p.out + (long)w * p.ldo + head * 16 + 8 * h;
+        *reinterpret_cast<uint4*>(orow) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
+#else
+      if (w >= 0) {
+        bf16_t* orow = (bf16_t*)p.out + (long)w * p.ldo + head * 16 + 4 * h;
+        *reinterpret_cast<uint2*>(orow) = a;      // d = 4h .. 4h+3
+        *reinterpret_cast<uint2*>(orow + 8) = b;  // d = 8+4h .. 8+4h+3
+      }
+#endif
     }
     qt = qt_nxt;
     q_cur = q_nxt;
@@ -463,8 +539,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_f32_kernel(AttnP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  int patch, head, qslice;
-  if (!decode_block(p, patch, head, qslice)) return;
+  int patch, head, qslice, qsplit;
+  if (!decode_block(p, (int)blockIdx.x, patch, head, qslice, qsplit)) return;
   const int ps = p.patch_start[patch];
   const int L = p.patch_start[patch + 1] - ps;
   const int nkt = (L + 15) >> 4;  // 16-key tiles
@@ -501,7 +577,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_f32_kernel(AttnP p) {
   const float c = p.scale_log2e;
   const int nqt = (L + 15) >> 4;
 
-  for (int qt = qslice * ATTN_WAVES + wave; qt < nqt; qt += p.qsplit * ATTN_WAVES) {
+  for (int qt = qslice * ATTN_WAVES + wave; qt < nqt; qt += qsplit * ATTN_WAVES) {
     const int qslot = qt * 16 + ql;
     const bool qvalid = qslot < L;
     f32x4_t qf = {0.f, 0.f, 0.f, 0.f};
@@ -568,21 +644,49 @@ extern "C" int cdseg_debug_attn_timing(unsigned long long* host_dst, size_t coun
 }
 #endif
 
-extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
-                               const int32_t* q_gidx, const int32_t* kv_gidx, const int32_t* widx,
-                               const int32_t* patch_start, int num_patches, int num_heads, int max_len, float scale,
-                               void* out, int ldo, int dtype, void* stream) {
-  if (num_patches <= 0 || num_heads <= 0) return CDSEG_OK;
-  if (max_len <= 0 || max_len > CDSEG_MAX_PATCH) return CDSEG_ERR_UNSUPPORTED;
-  const int esz = dtype == CDSEG_F32 ? 4 : 2;
-  // 16-byte alignment of every gathered row slice
-  if (((long)ldq * esz) & 15 || ((long)ldk * esz) & 15 || ((long)ldv * esz) & 15) return CDSEG_ERR_ARG;
-  if (dtype == CDSEG_F32 ? (ldo & 3) : (ldo & 3)) return CDSEG_ERR_ARG;
-  AttnP p;
-  p.q = q; p.k = k; p.v = v; p.q_gidx = q_gidx; p.kv_gidx = kv_gidx; p.widx = widx; p.patch_start = patch_start;
-  p.out = out; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.num_heads = num_heads;
-  p.scale_log2e = scale * 1.44269504088896340736f;
-  hipStream_t s = (hipStream_t)stream;
+// Zones of the graded schedule (see decode_block), sized in BLOCKS per XCD (an XCD has 32 CUs x 2 resident blocks = 64
+// slots) and converted to whole (patch, head) units here.  tail1 / tail2: the last blocks of an XCD are half / quarter
+// slices, so the launch's last round is short; lead: the first 32 blocks stay whole and the next `lead` are half slices -
+// the two blocks a CU starts with then end at different times and later K / V stagings on that CU run next to the other
+// block's key loop.  s0 = slices of the bulk (1 when the launch has enough patch-heads to fill the chip).  Defaults from the
+// interleaved same-process sweep in profiles/r05_attention_sched.txt (tools/attn_sweep.py): tails of 64 + 64 blocks give
+// +1 .. +2 % on the 1700 - 3400-unit launches of stages 0 / 1 and +7 .. +12 % on the 800 - 1600-unit ones; the lead zone
+// measured +-0 and stays off.
+static unsigned plan_zones(AttnP& p, int s0, int max_split, int lead, int tail1, int tail2) {
+  const int U = p.num_patches * p.num_heads;
+  const int n_min = U / 8, n_max = (U + 7) / 8;
+  const int s1 = 2 * s0 <= max_split ? 2 * s0 : 0, s2 = 4 * s0 <= max_split ? 4 * s0 : 0;
+  auto units = [&](int blocks, int split) { return split && blocks > 0 ? (blocks + split - 1) / split : 0; };
+  if (n_min < cdseg_knob("CDSEG_ATTN_ZONE_MIN", ATTN_ZONE_MIN_UNITS)) lead = tail1 = tail2 = 0;
+  int u_lead = units(lead, s1), u_head = u_lead ? units(32, s0) : 0;
+  int u_t1 = units(tail1, s1), u_t2 = units(tail2, s2);
+  // too few units per XCD for all the zones: drop the lead, then shrink the tails (at least a third stays bulk)
+  if (u_head + u_lead + u_t1 + u_t2 > n_min - n_min / 3) u_head = u_lead = 0;
+  while (u_t1 + u_t2 > n_min - n_min / 3 && (u_t1 | u_t2)) {
+    u_t1 -= u_t1 > 0;
+    if (u_t1 + u_t2 > n_min - n_min / 3) u_t2 -= u_t2 > 0;
+  }
+  int z = 0;
+  auto add = [&](int cnt, int split) {
+    if (cnt == 0) return;
+    p.zcnt[z] = cnt; p.zsplit[z] = split; ++z;
+  };
+  add(u_head, s0);
+  add(u_lead, s1);
+  add(-1, s0);
+  add(u_t1, s1);
+  add(u_t2, s2);
+  p.nzones = z;
+  p.zfixed = u_head + u_lead + u_t1 + u_t2;
+  p.bulk_max = n_max - p.zfixed;
+  long per_xcd = 0;
+  for (int i = 0; i < z; ++i) per_xcd += (long)(p.zcnt[i] >= 0 ? p.zcnt[i] : p.bulk_max) * p.zsplit[i];
+  return (unsigned)(per_xcd * 8);
+}
+
+// Fills the schedule fields of p (and num_patches / num_heads); returns the grid size.
+static unsigned make_schedule(AttnP& p, int num_patches, int num_heads, int max_len, int dtype) {
+  p.num_heads = num_heads;
   // K/V staging is per block, so split a patch-head's queries over as few blocks as still fill
   // the chip (2 resident blocks per CU -> ~512 block slots)
   const int tile = dtype == CDSEG_F32 ? 16 : 32;
@@ -595,22 +699,47 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
   const int max_split = (nqt + ATTN_WAVES - 1) / ATTN_WAVES;
   while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
   p.num_patches = num_patches;
-  p.qsplit = qsplit;
-  int hgroups = 1;  // smallest divisor of H giving every XCD a group (or H itself)
-  while (hgroups < num_heads && (num_patches * hgroups < 8 || num_heads % hgroups)) ++hgroups;
-  p.hgroups = hgroups;
-  const int groups = num_patches * hgroups;
-  dim3 grid((unsigned)(((groups + 7) / 8) * 8 * (num_heads / hgroups) * qsplit)), block(ATTN_THREADS);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BF16) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F32) !=
-            hipSuccess)
-      return CDSEG_ERR_LAUNCH;
-    attr_done = true;
-  }
+  for (int z = 0; z < ATTN_ZONES; ++z) p.zcnt[z] = p.zsplit[z] = 0;
+  // (the fp32 parity kernel keeps the uniform schedule: one bulk zone)
+  const bool graded = dtype == CDSEG_BF16;
+  const unsigned nblocks =
+      plan_zones(p, qsplit, max_split, graded ? cdseg_knob("CDSEG_ATTN_LEAD", ATTN_LEAD_BLOCKS) : 0,
+                 graded ? cdseg_knob("CDSEG_ATTN_TAIL1", ATTN_TAIL1_BLOCKS) : 0,
+                 graded ? cdseg_knob("CDSEG_ATTN_TAIL2", ATTN_TAIL2_BLOCKS) : 0);
+  return nblocks;
+}
+
+extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                                  const int32_t* q_gidx, const int32_t* kv_gidx, const int32_t* widx,
+                                  const int32_t* patch_start, int num_patches, int num_heads, int max_len, float scale,
+                                  void* out, int ldo, int dtype, int flags, void* stream) {
+  if (num_patches <= 0 || num_heads <= 0) return CDSEG_OK;
+  if (max_len <= 0 || max_len > CDSEG_MAX_PATCH) return CDSEG_ERR_UNSUPPORTED;
   if (dtype != CDSEG_BF16 && dtype != CDSEG_F32) return CDSEG_ERR_ARG;
+  if (flags & ~(CDSEG_ATTN_Q_PRESCALED | CDSEG_ATTN_V_BF16)) return CDSEG_ERR_ARG;
+  if (dtype == CDSEG_F32 && (flags & CDSEG_ATTN_V_BF16)) return CDSEG_ERR_ARG;
+  const int esz = dtype == CDSEG_F32 ? 4 : 2;
+  // 16-byte alignment of every gathered row slice and of every output piece
+  if (((long)ldq * esz) & 15 || ((long)ldk * esz) & 15 || ((long)ldv * esz) & 15 || ((long)ldo * esz) & 15) return CDSEG_ERR_ARG;
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return CDSEG_ERR_ARG;
+  AttnP p;
+  p.q = q; p.k = k; p.v = v; p.q_gidx = q_gidx; p.kv_gidx = kv_gidx; p.widx = widx; p.patch_start = patch_start;
+  p.out = out; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.num_heads = num_heads;
+  // Q pre-scaled: the producer's weights carry softmax scale * log2(e) (`scale` is then ignored)
+  p.scale_log2e = (flags & CDSEG_ATTN_Q_PRESCALED) ? 1.0f : scale * 1.44269504088896340736f;
+  p.flags = flags;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned nblocks = make_schedule(p, num_patches, num_heads, max_len, dtype);
+  dim3 grid(nblocks), block(ATTN_THREADS);
+  static std::once_flag attr_once;
+  static bool attr_ok = false;
+  std::call_once(attr_once, [] {
+    attr_ok = hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BF16) ==
+                  hipSuccess &&
+              hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F32) ==
+                  hipSuccess;
+  });
+  if (!attr_ok) return CDSEG_ERR_LAUNCH;
   CdsegProfToken tok;
   const bool prof = cdseg_prof_begin(CDSEG_PROF_ATTENTION, s, &tok);
   if (dtype == CDSEG_BF16) {
@@ -621,4 +750,30 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
   if (prof) cdseg_prof_end(tok, s);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
+}
+
+extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                               const int32_t* q_gidx, const int32_t* kv_gidx, const int32_t* widx,
+                               const int32_t* patch_start, int num_patches, int num_heads, int max_len, float scale,
+                               void* out, int ldo, int dtype, void* stream) {
+  return cdseg_attention_ex(q, k, v, ldq, ldk, ldv, q_gidx, kv_gidx, widx, patch_start, num_patches, num_heads, max_len,
+                            scale, out, ldo, dtype, 0, stream);
+}
+
+// Diagnostic (host only, no device work): the block -> (patch, head, query slice, slices) table cdseg_attention_ex would
+// launch for this shape, 4 ints per block id (-1 x 4 for ids that exit).  Returns the number of block ids, or a negative
+// status; writes at most `capacity` rows.  tests/test_attention_schedule.py checks that every (patch, head, slice) appears
+// exactly once for the shapes of the model.
+extern "C" long cdseg_attention_schedule(int num_patches, int num_heads, int max_len, int dtype, int32_t* table,
+                                         long capacity) {
+  if (num_patches <= 0 || num_heads <= 0 || max_len <= 0 || max_len > CDSEG_MAX_PATCH) return CDSEG_ERR_ARG;
+  if (dtype != CDSEG_BF16 && dtype != CDSEG_F32) return CDSEG_ERR_ARG;
+  AttnP p{};
+  const unsigned nb = make_schedule(p, num_patches, num_heads, max_len, dtype);
+  for (long b = 0; b < (long)nb && b < capacity && table; ++b) {
+    int patch = -1, head = -1, qslice = -1, qsplit = -1;
+    if (!decode_block(p, (int)b, patch, head, qslice, qsplit)) patch = head = qslice = qsplit = -1;
+    table[4 * b] = patch; table[4 * b + 1] = head; table[4 * b + 2] = qslice; table[4 * b + 3] = qsplit;
+  }
+  return (long)nb;
 }

@@ -373,15 +373,18 @@ extern "C" int cdseg_block_rr_pack(int channels, const void* wl, const void* wqk
 extern "C" int cdseg_cpe_head_rr(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g,
                                  const float* lnp_b, float* x, int ldx, const float* colbias, const float* ln1_g,
                                  const float* ln1_b, float eps, const float* bqkv, void* qkv, int ldqkv, long n,
-                                 int channels, void* stream) {
+                                 int channels, int qkv_flags, void* stream) {
   if (n <= 0) return CDSEG_OK;
+  if (qkv_flags & ~CDSEG_ATTN_V_BF16) return CDSEG_ERR_ARG;
+  // (the register-resident head of the wide stages - off in the product, tools only - writes v in the build's own type)
+  if (qkv_flags && !deep_supported(channels)) return CDSEG_ERR_UNSUPPORTED;
   if (!y || !head_img || !bl || !lnp_g || !lnp_b || !x || !ln1_g || !ln1_b || !bqkv || !qkv) return CDSEG_ERR_ARG;
   if (channels != 32 && channels != 64 && !deep_supported(channels)) return CDSEG_ERR_UNSUPPORTED;
   if ((ldy & 7) || (ldx & 3) || (ldqkv & 7) || (((uintptr_t)y | (uintptr_t)x | (uintptr_t)qkv | (uintptr_t)head_img) & 15))
     return CDSEG_ERR_ARG;
   if (deep_supported(channels))
     return deep_head(y, ldy, head_img, bl, lnp_g, lnp_b, x, ldx, colbias, ln1_g, ln1_b, eps, bqkv, qkv, ldqkv, n, channels,
-                     (hipStream_t)stream);
+                     qkv_flags, (hipStream_t)stream);
   HeadRR p;
   p.y = (const bf16_t*)y; p.wimg = (const uint4*)head_img; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.bqkv = bqkv; p.qkv = (bf16_t*)qkv;

@@ -8,6 +8,6 @@ int deep_pack(int channels, const void* wl, const void* wqkv, void* head_img, co
               void* tail_img, hipStream_t s);
 int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b, float* x,
               int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
-              int ldqkv, long n, int channels, hipStream_t s);
+              int ldqkv, long n, int channels, int qkv_flags, hipStream_t s);
 int deep_tail(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b, float eps,
               const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n, int channels, hipStream_t s);

@@ -54,6 +54,12 @@ __device__ __forceinline__ uint4 pack8(const f32x4_t& a, const f32x4_t& b) {
   r.z = pack_bf16x2(b[0], b[1]); r.w = pack_bf16x2(b[2], b[3]);
   return r;
 }
+__device__ __forceinline__ uint4 pack8_truebf16(const f32x4_t& a, const f32x4_t& b) {
+  uint4 r;
+  r.x = pack_truebf16x2(a[0], a[1]); r.y = pack_truebf16x2(a[2], a[3]);
+  r.z = pack_truebf16x2(b[0], b[1]); r.w = pack_truebf16x2(b[2], b[3]);
+  return r;
+}
 
 // BM x C tile of 16-bit rows, global -> LDS (swizzled).  Rows past the end re-read the last row (computed, never stored).
 template <int C, int BM>
@@ -183,6 +189,7 @@ struct DeepHeadP {
   const bf16_t* y; const uint4* wimg; const float* bl; const float* lnp_g; const float* lnp_b; float* x;
   const float* colbias; const float* ln1_g; const float* ln1_b; const float* bqkv; bf16_t* qkv;
   long n; int ldy, ldx, ldqkv; float eps;
+  int v_bf16;  // IEEE-half build: write the v third as bfloat16 (CDSEG_ATTN_V_BF16)
 };
 
 template <int C, int BM>
@@ -289,7 +296,9 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) {
       const long m = m0 + 16 * pt + p;
-      if (m < P.n) *reinterpret_cast<uint4*>(P.qkv + m * P.ldqkv + c * C + ch0) = pack8(a[pt][0], a[pt][1]);
+      if (m < P.n)
+        *reinterpret_cast<uint4*>(P.qkv + m * P.ldqkv + c * C + ch0) =
+            (LP_IS_F16 && c == 2 && P.v_bf16) ? pack8_truebf16(a[pt][0], a[pt][1]) : pack8(a[pt][0], a[pt][1]);
     }
     DT_STAMP(8 + 2 * c);
   }
@@ -519,8 +528,9 @@ int deep_pack(int C, const void* wl, const void* wqkv, void* head_img, const voi
 
 int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b, float* x,
               int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
-              int ldqkv, long n, int channels, hipStream_t s) {
+              int ldqkv, long n, int channels, int qkv_flags, hipStream_t s) {
   DeepHeadP p;
+  p.v_bf16 = (qkv_flags & CDSEG_ATTN_V_BF16) ? 1 : 0;
   p.y = (const bf16_t*)y; p.wimg = (const uint4*)head_img; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.bqkv = bqkv; p.qkv = (bf16_t*)qkv;
   p.n = n; p.ldy = ldy; p.ldx = ldx; p.ldqkv = ldqkv; p.eps = eps;

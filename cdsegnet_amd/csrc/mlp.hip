@@ -350,6 +350,7 @@ struct HeadP {
   const bf16_t* wqkv;   // (3C, C)
   const float* bqkv;    // (3C)
   bf16_t* qkv;          // (n, ldqkv)
+  int v_bf16;           // IEEE-half build: write the v third as bfloat16 (what cdseg_attention_ex's CDSEG_ATTN_V_BF16 reads)
   long n;
   int ldy, ldx, ldqkv;
   float eps;
@@ -504,8 +505,13 @@ __global__ __launch_bounds__(4 * BM) void cpe_head_fused_kernel(HeadP p) {
       float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + 4 * cg);
       const float4 b = *reinterpret_cast<const float4*>(p.bqkv + j * C + 4 * cg);
       uint2 u;
-      u.x = pack_bf16x2(v.x + b.x, v.y + b.y);
-      u.y = pack_bf16x2(v.z + b.z, v.w + b.w);
+      if (LP_IS_F16 && j == 2 && p.v_bf16) {  // the attention's P V product is bfloat16 in both builds (attention.hip)
+        u.x = pack_truebf16x2(v.x + b.x, v.y + b.y);
+        u.y = pack_truebf16x2(v.z + b.z, v.w + b.w);
+      } else {
+        u.x = pack_bf16x2(v.x + b.x, v.y + b.y);
+        u.y = pack_bf16x2(v.z + b.z, v.w + b.w);
+      }
       *reinterpret_cast<uint2*>(p.qkv + m * p.ldqkv + j * C + 4 * cg) = u;
     }
   }
@@ -517,9 +523,10 @@ __global__ __launch_bounds__(4 * BM) void cpe_head_fused_kernel(HeadP p) {
 extern "C" int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, const float* bl, const float* lnp_g,
                                     const float* lnp_b, float* x, int ldx, const float* colbias, const float* ln1_g,
                                     const float* ln1_b, float eps, const void* wqkv, const float* bqkv, void* qkv,
-                                    int ldqkv, long n, int channels, int dtype, void* stream) {
+                                    int ldqkv, long n, int channels, int dtype, int qkv_flags, void* stream) {
   if (n <= 0) return CDSEG_OK;
   if (!y || !wl || !bl || !lnp_g || !lnp_b || !x || !ln1_g || !ln1_b || !wqkv || !bqkv || !qkv) return CDSEG_ERR_ARG;
+  if (qkv_flags & ~CDSEG_ATTN_V_BF16) return CDSEG_ERR_ARG;
   if (dtype != CDSEG_BF16 || (channels != 32 && channels != 64)) return CDSEG_ERR_UNSUPPORTED;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   if ((ldy & 7) || (ldx & 3) || (ldqkv & 3) || !al16(y) || !al16(wl) || !al16(wqkv) || !al16(x) || !al16(bl) ||
@@ -530,6 +537,7 @@ extern "C" int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, cons
   p.y = (const bf16_t*)y; p.wl = (const bf16_t*)wl; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.wqkv = (const bf16_t*)wqkv; p.bqkv = bqkv;
   p.qkv = (bf16_t*)qkv; p.n = n; p.ldy = ldy; p.ldx = ldx; p.ldqkv = ldqkv; p.eps = eps;
+  p.v_bf16 = (qkv_flags & CDSEG_ATTN_V_BF16) ? 1 : 0;
   static const int bm = cdseg_knob("CDSEG_HEAD_BM", 128);
   if (bm == 128 && n >= 128 * 512) {  // enough 128-row workgroups to fill the chip twice
     const dim3 grid((unsigned)((n + 127) / 128));

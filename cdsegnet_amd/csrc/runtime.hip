@@ -90,6 +90,10 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
   if (!io->scratch || io->scratch_bytes < L.total) return CDSEG_ERR_WORKSPACE;
   const bool fuse = C <= FUSE_LN_MAX_C;
   int rc;
+  // what the qkv producer of this Block has already done for the attention kernel (cdseg_attention_ex): the engine folds
+  // scale * log2(e) into the q rows of the weights (desc), the fused heads write v as bfloat16
+  int attn_flags = d->attn_flags & CDSEG_ATTN_Q_PRESCALED;
+  if (T != CDSEG_BF16) attn_flags = 0;
 
   // ---- CPE: x += LN(Linear(SubMConv3d(xc)))  [+ t bias];  h = LN1(x)      (ptv3.py:401-413)
   // (the weight-stationary kernel addresses its buffers with 32-bit offsets: inputs past those limits - 16.7 M rows at
@@ -115,15 +119,17 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
     if ((rc = cdseg_cpe_head_rr(L.y, C, d->head_img, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
                                 (const float*)d->cpe_ln_b, (float*)io->x, C, (const float*)io->tbias,
                                 (const float*)d->norm1_g, (const float*)d->norm1_b, d->ln_eps, (const float*)d->qkv_b, L.qkv,
-                                3 * C, n, C, stream)) != CDSEG_OK)
+                                3 * C, n, C, deep ? CDSEG_ATTN_V_BF16 : 0, stream)) != CDSEG_OK)
       return rc;
+    if (deep) attn_flags |= CDSEG_ATTN_V_BF16;
   } else if (head) {
     // big stages: cpe linear + LN + residual (+ t bias) + LN1 + qkv in one launch (mlp.hip); h never leaves the CU
     if ((rc = cdseg_cpe_head_fused(L.y, C, d->cpe_lin_w, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
                                    (const float*)d->cpe_ln_b, (float*)io->x, C, (const float*)io->tbias,
                                    (const float*)d->norm1_g, (const float*)d->norm1_b, d->ln_eps, d->qkv_w,
-                                   (const float*)d->qkv_b, L.qkv, 3 * C, n, C, T, stream)) != CDSEG_OK)
+                                   (const float*)d->qkv_b, L.qkv, 3 * C, n, C, T, CDSEG_ATTN_V_BF16, stream)) != CDSEG_OK)
       return rc;
+    attn_flags |= CDSEG_ATTN_V_BF16;
   } else if (fuse) {
     cdseg_gemm_args a = base_args(d, L, n);
     a.A = L.y; a.lda = C; a.W = d->cpe_lin_w; a.bias = d->cpe_lin_b; a.N = C; a.K = C;
@@ -153,9 +159,9 @@ extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_
   {
     const size_t e = esz(T);
     const char* q = (const char*)L.qkv;
-    if ((rc = cdseg_attention(q, q + (size_t)C * e, q + (size_t)2 * C * e, 3 * C, 3 * C, 3 * C, io->gidx, io->gidx,
-                              io->widx, io->patch_start, io->num_patches, d->heads, io->max_len, d->attn_scale, L.o, C,
-                              T, stream)) != CDSEG_OK)
+    if ((rc = cdseg_attention_ex(q, q + (size_t)C * e, q + (size_t)2 * C * e, 3 * C, 3 * C, 3 * C, io->gidx, io->gidx,
+                                 io->widx, io->patch_start, io->num_patches, d->heads, io->max_len, d->attn_scale, L.o, C,
+                                 T, attn_flags, stream)) != CDSEG_OK)
       return rc;
   }
   static const bool fused_tail = cdseg_knob("CDSEG_FUSED_TAIL", 1) != 0 && cdseg_knob("CDSEG_FUSED_MLP", 1) != 0;

@@ -213,8 +213,10 @@ struct LevelsP {
   long n;
 };
 
-__global__ void levels_flag_kernel(const int64_t* __restrict__ zc, LevelsP p, int32_t* __restrict__ flag) {
+__global__ void levels_flag_kernel(const int64_t* __restrict__ zc, LevelsP p, int32_t* __restrict__ flag,
+                                   int32_t* __restrict__ meta) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) meta[p.nlev * (1 + p.nb)] = 0;  // duplicate-voxel counter, filled by levels_finish_kernel
   if (t >= p.n * p.nlev) return;
   const int l = (int)(t / p.n);
   const long i = t - (long)l * p.n;
@@ -222,14 +224,19 @@ __global__ void levels_flag_kernel(const int64_t* __restrict__ zc, LevelsP p, in
   flag[t] = (i == 0 || (zc[i] >> sh) != (zc[i - 1] >> sh)) ? 1 : 0;
 }
 
-// cluster (L,n), seg_start (L,n+1), meta (L, 1+nb): [count, cluster id of the last point of every batch element]
-__global__ void levels_finish_kernel(const int32_t* __restrict__ incl, const int32_t* __restrict__ flag, LevelsP p,
+// cluster (L,n), seg_start (L,n+1), meta (L, 1+nb): [count, cluster id of the last point of every batch element], then ONE
+// trailing int: the number of points whose (batch, voxel) code equals their predecessor's - the model's input contract is
+// one point per voxel (GridSample; SURVEY 7: the kernel maps and the derived coarse orders assume it), so the host turns a
+// non-zero count into an error with the read it already does for the pooled sizes
+__global__ void levels_finish_kernel(const int64_t* __restrict__ zc, const int32_t* __restrict__ incl,
+                                     const int32_t* __restrict__ flag, LevelsP p,
                                      const int32_t* __restrict__ last_idx, int32_t* __restrict__ cluster,
                                      int32_t* __restrict__ seg_start, int32_t* __restrict__ meta) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.n * p.nlev) return;
   const int l = (int)(t / p.n);
   const long i = t - (long)l * p.n;
+  if (l == 0 && i > 0 && zc[i] == zc[i - 1]) atomicAdd(&meta[p.nlev * (1 + p.nb)], 1);
   const int base = l ? incl[(long)l * p.n - 1] : 0;
   const int c = incl[t] - base - 1;
   cluster[t] = c;
@@ -732,7 +739,8 @@ size_t cdseg_pool_levels_ws_bytes(long n, int nlev) {
 
 // All pooling levels over the z-sorted level-0 codes in one pass.  shifts (host, nlev <= 8): 3 * cumulative pooling
 // depth per level; last_idx (nb, device): index of the last point of every batch element.
-// cluster (nlev, n), seg_start (nlev, n + 1), meta (nlev, 1 + nb) int32 = [count, cluster of last_idx[b] ...].
+// cluster (nlev, n), seg_start (nlev, n + 1), meta nlev * (1 + nb) + 1 int32 = [count, cluster of last_idx[b] ...] per
+// level, then the number of duplicate (batch, voxel) codes.
 int cdseg_pool_levels(const int64_t* zcode_sorted, long n, const int* shifts, int nlev, const int32_t* last_idx, int nb,
                       int32_t* cluster, int32_t* seg_start, int32_t* meta, void* ws, size_t ws_bytes, void* stream) {
   if (n <= 0 || nlev <= 0) return CDSEG_ERR_ARG;
@@ -748,12 +756,12 @@ int cdseg_pool_levels(const int64_t* zcode_sorted, long n, const int* shifts, in
   int32_t* flag = (int32_t*)w;
   int32_t* incl = (int32_t*)(w + arr);
   size_t scan_bytes = ws_bytes - 2 * arr;
-  hipLaunchKernelGGL(levels_flag_kernel, grid1d(total), dim3(256), 0, s, zcode_sorted, p, flag);
+  hipLaunchKernelGGL(levels_flag_kernel, grid1d(total), dim3(256), 0, s, zcode_sorted, p, flag, meta);
   hipError_t e = rocprim::inclusive_scan((void*)(w + 2 * arr), scan_bytes, (const int32_t*)flag, incl, (size_t)total,
                                          rocprim::plus<int32_t>(), s, false);
   if (e != hipSuccess) return CDSEG_ERR_LAUNCH;
-  hipLaunchKernelGGL(levels_finish_kernel, grid1d(total), dim3(256), 0, s, incl, flag, p, last_idx, cluster, seg_start,
-                     meta);
+  hipLaunchKernelGGL(levels_finish_kernel, grid1d(total), dim3(256), 0, s, zcode_sorted, incl, flag, p, last_idx, cluster,
+                     seg_start, meta);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

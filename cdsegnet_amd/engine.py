@@ -201,6 +201,7 @@ class Engine:
         self.rng_offset = 0
         self._rng_seed = None  # torch.initial_seed() the device-RNG cursor belongs to
         self.use_native_blocks = True  # one library call per Block instead of ~8 binding calls
+        self.fold_attn_scale = True  # 16-bit engines: softmax scale * log2(e) folded into Wq / bq at prepare (tools A/B: False)
         self.exact_attention_core = False  # budget tool only: fp32 attention core inside a 16-bit trunk (binding path)
         self._pad_keys = None
         self._side = {}
@@ -238,6 +239,27 @@ class Engine:
             w[pre + ".w"] = mod.weight.detach().to(device=device, dtype=T).contiguous()
             w[pre + ".b"] = f32(mod.bias) if mod.bias is not None else None
 
+        # 16-bit engines: the attention kernel is VALU-issue bound, so what can be done once per weight is not done once per
+        # (head, query slice): softmax scale * log2(e) is folded into the q rows of the projection (weights and bias, in
+        # fp32, before the cast) and the kernel is told so (ops.ATTN_Q_PRESCALED).  The exact-fp32 mode keeps the
+        # reference's order of operations (scale applied to the scores).
+        self.q_prescaled = T != torch.float32 and self.fold_attn_scale
+
+        def lin_q(mod, pre, scale, rows):
+            """Linear whose first `rows` output rows are the attention's q projection."""
+            if not self.q_prescaled:
+                return lin(mod, pre)
+            f = float(scale) * 1.4426950408889634
+            wt = mod.weight.detach().to(device=device, dtype=torch.float32).clone()
+            wt[:rows] *= f
+            w[pre + ".w"] = wt.to(T).contiguous()
+            if mod.bias is not None:
+                b = f32(mod.bias).clone()
+                b[:rows] *= f
+                w[pre + ".b"] = b
+            else:
+                w[pre + ".b"] = None
+
         def conv(mod, pre):
             w[pre + ".w"] = mod.weight.detach().reshape(mod.weight.shape[0], -1).to(device=device, dtype=T).contiguous()
             w[pre + ".b"] = f32(mod.bias) if mod.bias is not None else None
@@ -263,7 +285,7 @@ class Engine:
             lin(mod.cpe[1], pre + ".cpe1")
             ln(mod.cpe[2], pre + ".cpe2")
             ln(mod.norm1[0], pre + ".norm1")
-            lin(mod.attn.qkv, pre + ".qkv")
+            lin_q(mod.attn.qkv, pre + ".qkv", mod.attn.scale, mod.channels)
             lin(mod.attn.proj, pre + ".proj")
             ln(mod.norm2[0], pre + ".norm2")
             lin(mod.mlp[0].fc1, pre + ".fc1")
@@ -361,7 +383,7 @@ class Engine:
             conv(cb.q_cpe[0], "x.q_cpe0"); lin(cb.q_cpe[1], "x.q_cpe1"); ln(cb.q_cpe[2], "x.q_cpe2")
             conv(cb.kv_cpe[0], "x.kv_cpe0"); lin(cb.kv_cpe[1], "x.kv_cpe1"); ln(cb.kv_cpe[2], "x.kv_cpe2")
             ln(cb.q_norm1[0], "x.q_norm1"); ln(cb.kv_norm1[0], "x.kv_norm1"); ln(cb.q_norm2[0], "x.q_norm2")
-            lin(cb.attn.q, "x.q"); lin(cb.attn.kv, "x.kv"); lin(cb.attn.proj, "x.proj")
+            lin_q(cb.attn.q, "x.q", cb.attn.scale, cb.q_channels); lin(cb.attn.kv, "x.kv"); lin(cb.attn.proj, "x.proj")
             lin(cb.mlp[0].fc1, "x.fc1"); lin(cb.mlp[0].fc2, "x.fc2")
             if cb.tm_feat != 1.0:
                 c = cb.q_channels
@@ -400,7 +422,8 @@ class Engine:
                 if (pre + ".head_img") in w:
                     t["head_img"] = w[pre + ".head_img"]
                 self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
-                                                           mod.attn.scale, 1e-5, t)
+                                                           mod.attn.scale, 1e-5, t,
+                                                           attn_flags=ops.ATTN_Q_PRESCALED if self.q_prescaled else 0)
         self._scratch = {}
         self._scratch_bytes = {}
 
@@ -490,7 +513,13 @@ class Engine:
             last_idx = torch.tensor([v - 1 for v in offset_host], dtype=torch.int32, device=dev)
             cl_all, seg_all, meta = ops.pool_levels(zs, [3 * cum for cum in coarse], last_idx)
             tmp = [(cl_all[i], seg_all[i]) for i in range(len(coarse))]
-            meta_h = meta.cpu().tolist()  # the one sync for all pooled sizes
+            flat = meta.cpu().tolist()  # the one sync for all pooled sizes (+ the duplicate-voxel count)
+            if flat[-1]:
+                # the model's input contract (GridSample upstream, structure.py:39-102 downstream): one point per voxel.
+                # The kernel maps and the derived coarse orders assume it - refuse instead of computing something else
+                raise CdsegError(f"input has {flat[-1]} duplicate voxels (points sharing (batch, grid_coord) with another "
+                                 f"point): the model expects one point per voxel - voxelise first (GridSample)")
+            meta_h = [flat[i * (1 + nb):(i + 1) * (1 + nb)] for i in range(len(coarse))]
             host = [r[0] for r in meta_h] + [v for r in meta_h for v in r[1:]]
             for i, cum in enumerate(coarse):
                 m = host[i]
@@ -632,11 +661,14 @@ class Engine:
             st.xc = xc_out
             return
         qkv = self._buf(n, 3 * c, self.T)
+        aflags = ops.ATTN_Q_PRESCALED if self.q_prescaled else 0  # what the qkv producer has done for the attention kernel
         if (pre + ".head_img") in w and not ops.cpe_head_fused_ok(st.xc):  # deep stages (C = 128 / 256): csrc/deep.hip
             y = self._buf(n, c, self.T)
             self._conv3(st.xc, pre + ".cpe0", lv, y)
             ops.cpe_head_rr(y, w[pre + ".head_img"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
-                            tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.b"], qkv)
+                            tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.b"], qkv,
+                            qkv_flags=ops.ATTN_V_BF16)
+            aflags |= ops.ATTN_V_BF16
         elif ops.cpe_head_fused_ok(st.xc):  # big stages: cpe linear + LN + residual + LN1 + qkv in one launch
             y = self._buf(n, c, self.T)
             self._conv3(st.xc, pre + ".cpe0", lv, y)
@@ -645,7 +677,9 @@ class Engine:
                                 tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.b"], qkv)
             else:
                 ops.cpe_head_fused(y, w[pre + ".cpe1.w"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
-                                   tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.w"], w[pre + ".qkv.b"], qkv)
+                                   tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.w"], w[pre + ".qkv.b"], qkv,
+                                   qkv_flags=ops.ATTN_V_BF16)
+                aflags |= ops.ATTN_V_BF16
         else:
             h = self._cpe(st, pre + ".cpe", st.xc, tbias, next_norm=pre + ".norm1")
             ops.gemm(h, w[pre + ".qkv.w"], qkv, bias=w[pre + ".qkv.b"])
@@ -659,12 +693,14 @@ class Engine:
             # error-budget tool only (tools/bf16_budget.py): the attention core in fp32 on the 16-bit q k v
             q32 = qkv.float()
             o32 = self._buf(n, c, torch.float32)
+            if aflags & ops.ATTN_V_BF16 and self.T == torch.float16:
+                q32[:, 2 * c:] = qkv[:, 2 * c:].view(torch.bfloat16).float()
             ops.attention(q32[:, :c], q32[:, c:2 * c], q32[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads,
-                          max_len, att.scale, o32, work=0.0)
+                          max_len, att.scale, o32, work=0.0, flags=aflags & ops.ATTN_Q_PRESCALED)
             o.copy_(o32)
         else:
             ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads,
-                          max_len, att.scale, o, work=64.0 * att.num_heads * sum_l2)
+                          max_len, att.scale, o, work=64.0 * att.num_heads * sum_l2, flags=aflags)
         hid = w[pre + ".fc1.w"].shape[0]
         if (pre + ".tail_img") in w and not ops.attn_tail_fused_ok(o, hid):  # deep stages: proj + LN2 + MLP, one launch
             st.xc = self._buf(n, c, self.T)
@@ -803,7 +839,7 @@ class Engine:
         self._add_work(64.0 * att.num_heads * sum_l2, 4.0 * n * cq * q.element_size())
         o = self._buf(n, cq, self.T)
         ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o,
-                      work=64.0 * att.num_heads * sum_l2)
+                      work=64.0 * att.num_heads * sum_l2, flags=ops.ATTN_Q_PRESCALED if self.q_prescaled else 0)
         if cb.tm_feat == 1.0:
             ops.gemm(o, w["x.proj.w"], nst.x, bias=w["x.proj.b"], res=nst.x)
         else:  # q_shortcut + feat_scale * attn

@@ -333,13 +333,14 @@ def pool_level(zcode_sorted, shift_bits, count_out=None):
 
 
 def pool_levels(zcode_sorted, shifts, last_idx):
-    """All pooling levels at once -> (cluster (L,n), seg_start (L,n+1), meta (L,1+nb)) int32 on the device."""
+    """All pooling levels at once -> (cluster (L,n), seg_start (L,n+1), meta) int32 on the device; meta is FLAT:
+    L x (1+nb) ints [pooled count, cluster of each batch element's last point] then one int = duplicate-voxel count."""
     lib = _lib.load()
     n, L, nb = zcode_sorted.numel(), len(shifts), last_idx.numel()
     dev = zcode_sorted.device
     cluster = torch.empty((L, n), dtype=torch.int32, device=dev)
     seg = torch.empty((L, n + 1), dtype=torch.int32, device=dev)
-    meta = torch.empty((L, 1 + nb), dtype=torch.int32, device=dev)
+    meta = torch.empty(L * (1 + nb) + 1, dtype=torch.int32, device=dev)
     ws = workspace(lib.cdseg_pool_levels_ws_bytes(n, L), dev)
     sh = (ctypes.c_int * L)(*[int(v) for v in shifts])
     check(lib.cdseg_pool_levels(_ptr(zcode_sorted), n, sh, L, _ptr(last_idx), nb, _ptr(cluster), _ptr(seg), _ptr(meta),
@@ -557,13 +558,13 @@ def cpe_head_fused_ok(y):
     return is_lp(y.dtype) and y.shape[1] in (32, 64)
 
 
-def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
-    """x += LN_cpe(y Wl^T + bl) [+ colbias]; h = LN1(x); qkv = h Wqkv^T + bqkv."""
+def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5, qkv_flags=0):
+    """x += LN_cpe(y Wl^T + bl) [+ colbias]; h = LN1(x); qkv = h Wqkv^T + bqkv.  qkv_flags: ATTN_V_BF16 = v third as bfloat16."""
     _need_gpu(y, x)
     check(_lib.load().cdseg_cpe_head_fused(_ptr(y), y.stride(0), _ptr(wl), _ptr(bl), _ptr(lnp[0]), _ptr(lnp[1]), _ptr(x),
                                             x.stride(0), _ptr(colbias), _ptr(ln1[0]), _ptr(ln1[1]), float(eps), _ptr(wqkv),
                                             _ptr(bqkv), _ptr(qkv), qkv.stride(0), y.shape[0], y.shape[1], _DT[y.dtype],
-                                            _stream()), "cpe_head_fused")
+                                            int(qkv_flags), _stream()), "cpe_head_fused")
     return qkv
 
 
@@ -610,10 +611,11 @@ def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
     return head, tail
 
 
-def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5):
+def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5, qkv_flags=0):
     check(_lib.load().cdseg_cpe_head_rr(_ptr(y), y.stride(0), _ptr(head_img), _ptr(bl), _ptr(lnp[0]), _ptr(lnp[1]), _ptr(x),
                                         x.stride(0), _ptr(colbias), _ptr(ln1[0]), _ptr(ln1[1]), float(eps), _ptr(bqkv),
-                                        _ptr(qkv), qkv.stride(0), y.shape[0], y.shape[1], _stream()), "cpe_head_rr")
+                                        _ptr(qkv), qkv.stride(0), y.shape[0], y.shape[1], int(qkv_flags), _stream()),
+          "cpe_head_rr")
     return qkv
 
 
@@ -629,12 +631,14 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
-def make_block_desc(dtype, channels, heads, hidden, attn_scale, ln_eps, tensors):
+def make_block_desc(dtype, channels, heads, hidden, attn_scale, ln_eps, tensors, attn_flags=0):
     """Describe one Block's weights once (tensors: dict field -> tensor); returns an object to pass to
-    block_forward.  The tensors are kept alive by the returned handle."""
+    block_forward.  The tensors are kept alive by the returned handle.  attn_flags: ATTN_Q_PRESCALED when the q rows of
+    qkv_w / qkv_b (and the images packed from them) carry attn_scale * log2(e)."""
     d = _lib.BlockDesc()
     d.dtype, d.channels, d.heads, d.hidden = _DT[dtype], int(channels), int(heads), int(hidden)
     d.attn_scale, d.ln_eps = float(attn_scale), float(ln_eps)
+    d.attn_flags = int(attn_flags)
     for k, t in tensors.items():
         setattr(d, k, t.data_ptr())
     return (d, ctypes.byref(d), dict(tensors))
@@ -723,16 +727,20 @@ def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=Non
     return out
 
 
-def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out, work=0.0):
+ATTN_Q_PRESCALED, ATTN_V_BF16 = 1, 2  # include/cdseg.h: producer-side preprocessing declared to cdseg_attention_ex
+
+
+def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out, work=0.0, flags=0):
     """q/k/v: 2-D views (rows, H*16) of the projection buffers (any row stride); out (rows, H*16).
+    flags: ATTN_Q_PRESCALED (q carries scale * log2 e: `scale` ignored) | ATTN_V_BF16 (v is bfloat16 in the half build too).
     work: algorithmic FLOPs of this launch (4 * 16 * H * sum_p L_p^2), only used by the bench timer."""
     num_patches = patch_start.numel() - 1
-    if not (q.dtype == k.dtype == v.dtype == out.dtype):
+    if not (q.dtype == k.dtype == out.dtype) or (v.dtype != q.dtype and not (flags & ATTN_V_BF16)):
         raise _lib.CdsegError("attention: q, k, v, out must share a dtype")
     tok = TIMER.begin("attention") if TIMER is not None else None
-    check(_lib.load().cdseg_attention(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),
-                                      _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads),
-                                      int(max_len), float(scale), _ptr(out), out.stride(0), dt(q), _stream()),
+    check(_lib.load().cdseg_attention_ex(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),
+                                         _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads),
+                                         int(max_len), float(scale), _ptr(out), out.stride(0), dt(q), int(flags), _stream()),
           "attention")
     if tok is not None:
         TIMER.end(tok, work)

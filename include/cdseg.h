@@ -100,7 +100,9 @@ int cdseg_pool_level(const int64_t* zcode_sorted, long n, int shift_bits, int32_
                      int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
 /* All pooling levels of a scene in one flag / scan / finish pass (replaces one cdseg_pool_level per level).
  * shifts (host, nlev <= 8) = 3 * cumulative pooling depth; last_idx (nb, device) = last point of each batch element.
- * cluster (nlev, n), seg_start (nlev, n + 1), meta (nlev, 1 + nb) = [count, cluster of last_idx[b] ...] int32. */
+ * cluster (nlev, n), seg_start (nlev, n + 1) int32; meta: nlev * (1 + nb) + 1 int32 = per level [count, cluster of
+ * last_idx[b] ...], then ONE trailing int = the number of points whose (batch, voxel) code repeats their predecessor's
+ * (0 for a valid model input: one point per voxel - the host raises on anything else with the read it does anyway). */
 size_t cdseg_pool_levels_ws_bytes(long n, int nlev);
 int cdseg_pool_levels(const int64_t* zcode_sorted, long n, const int* shifts, int nlev, const int32_t* last_idx, int nb,
                       int32_t* cluster, int32_t* seg_start, int32_t* meta, void* ws, size_t ws_bytes, void* stream);
@@ -216,6 +218,23 @@ int cdseg_layernorm(const void* x, int x_dtype, int ldx, const float* gamma, con
 int cdseg_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const int32_t* q_gidx,
                     const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
                     int num_heads, int max_len, float scale, void* out, int ldo, int dtype, void* stream);
+/* The same with producer-side preprocessing declared in `flags` (what the fused qkv epilogues of this library emit, so the
+ * kernel - VALU-issue bound - does not redo per (head, query slice) what a producer does once per row):
+ *   CDSEG_ATTN_Q_PRESCALED  q already carries softmax scale * log2(e) (folded into Wq / bq at load time); `scale` is ignored
+ *   CDSEG_ATTN_V_BF16       v holds bfloat16 whatever the build's 16-bit type is (the IEEE-half build runs P V in bfloat16:
+ *                           P = exp2(s - bound) needs fp32's exponent range); CDSEG_BF16 dtype only
+ * q, k, v, out and every row (ld * element size) must be 16-byte aligned (CDSEG_ERR_ARG otherwise). */
+#define CDSEG_ATTN_Q_PRESCALED 1
+#define CDSEG_ATTN_V_BF16 2
+int cdseg_attention_ex(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const int32_t* q_gidx,
+                       const int32_t* kv_gidx, const int32_t* widx, const int32_t* patch_start, int num_patches,
+                       int num_heads, int max_len, float scale, void* out, int ldo, int dtype, int flags, void* stream);
+
+/* Diagnostic, host only: the block id -> (patch, head, query slice, slices of that patch-head) table of the launch
+ * cdseg_attention_ex issues for this shape (the graded schedule of csrc/attention.hip: the last blocks an XCD runs cover a
+ * half / a quarter of a patch-head's queries).  4 ints per block id, -1 x 4 for ids that exit at once.  Returns the number
+ * of block ids (may exceed `capacity`; at most `capacity` rows are written), or a negative status. */
+long cdseg_attention_schedule(int num_patches, int num_heads, int max_len, int dtype, int32_t* table, long capacity);
 
 /* HIP-event timing of the attention launches on their own stream (bench.py's live roofline measurement):
  * enable(1) starts recording, summary() (after a device sync) returns the summed durations. */
@@ -322,11 +341,13 @@ int cdseg_attn_tail_fused(const void* o, int ldo, const void* wp, const float* b
 
 /* Block head after the sparse conv in ONE launch (ptv3.py:401-414): x += LN_cpe(y Wl^T + bl) [+ colbias];
  * h = LN1(x); qkv (n, ldqkv) = h Wqkv^T + bqkv.  y (n, ldy) = conv output; h never exists in HBM.
+ * qkv_flags: 0, or CDSEG_ATTN_V_BF16 = write the v third of qkv as bfloat16 whatever the build's 16-bit type is (pass the
+ * same flag to cdseg_attention_ex; a no-op in the bfloat16 build).
  * Supported: bf16, channels 32 or 64; else CDSEG_ERR_UNSUPPORTED. */
 int cdseg_cpe_head_fused(const void* y, int ldy, const void* wl, const float* bl, const float* lnp_g, const float* lnp_b,
                          float* x, int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps,
                          const void* wqkv, const float* bqkv, void* qkv, int ldqkv, long n, int channels, int dtype,
-                         void* stream);
+                         int qkv_flags, void* stream);
 
 /* ------------------------------------------------------------------ 3x3x3 submanifold conv, wide stages
  * ref: spconv.SubMConv3d call sites ptv3.py:356-362 (the CPE conv of every Block).  y (n, ldy) bf16 =
@@ -369,7 +390,8 @@ int cdseg_block_rr_pack(int channels, const void* wl, const void* wqkv, void* he
                         const void* w2, void* tail_img, void* stream);
 int cdseg_cpe_head_rr(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b,
                       float* x, int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps,
-                      const float* bqkv, void* qkv, int ldqkv, long n, int channels, void* stream);
+                      const float* bqkv, void* qkv, int ldqkv, long n, int channels, int qkv_flags /* as above; deep stages only */,
+                      void* stream);
 int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b,
                        float eps, const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n,
                        int channels, void* stream);
@@ -410,6 +432,8 @@ typedef struct cdseg_block_desc {
   const void* cpe_conv_wimg; /* cdseg_subm_conv3_pack image of cpe_conv_w, or NULL: the conv runs on cdseg_gemm */
   const void* head_img;      /* cdseg_block_rr_pack images (C = 32 / 64 / 128 / 256), or NULL: the unfused / tile-fused launches */
   const void* tail_img;
+  int attn_flags;            /* CDSEG_ATTN_Q_PRESCALED when qkv_w / qkv_b (and the images built from them) carry
+                                attn_scale * log2(e) in their q rows (the engine folds it at load time) */
 } cdseg_block_desc;
 
 typedef struct cdseg_block_io {

@@ -2,6 +2,8 @@
 cdsegnet_amd.ops), used ONLY to exercise the engine's HOST logic (plan building, curve/slot
 bookkeeping, buffer plumbing, quirks) in the GPU-less build container.  It is never imported by
 the product; tests monkeypatch ``cdsegnet_amd.engine.ops`` with this module."""
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -102,7 +104,8 @@ def pool_levels(zs, shifts, last_idx):
         cl.append(c)
         sg.append(s_)
         meta.append(torch.cat([cnt.int(), c[last_idx.long()].int()]))
-    return torch.stack(cl), torch.stack(sg), torch.stack(meta)
+    dup = (zs[1:] == zs[:-1]).sum().int().reshape(1)
+    return torch.stack(cl), torch.stack(sg), torch.cat(meta + [dup])
 
 
 def link_derive(cl0a, seg0a, ma, cl0b, seg0b, mb):
@@ -313,8 +316,8 @@ def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
     return (wl, wqkv), (wp, w1, w2)  # the emulation multiplies by the plain weights
 
 
-def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5):
-    return cpe_head_fused(y, head_img[0], bl, lnp, x, colbias, ln1, head_img[1], bqkv, qkv, eps)
+def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5, qkv_flags=0):
+    return cpe_head_fused(y, head_img[0], bl, lnp, x, colbias, ln1, head_img[1], bqkv, qkv, eps, qkv_flags)
 
 
 def attn_tail_rr(o, tail_img, bp, ln_g, ln_b, b1, b2, x, xc=None, eps=1e-5):
@@ -325,7 +328,8 @@ def cpe_head_fused_ok(y):
     return y.dtype == torch.bfloat16 and y.shape[1] in (32, 64)
 
 
-def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5):
+def cpe_head_fused(y, wl, bl, lnp, x, colbias, ln1, wqkv, bqkv, qkv, eps=1e-5, qkv_flags=0):
+    # (qkv_flags = ATTN_V_BF16 only matters in the IEEE-half build; the emulation's 16-bit type is bfloat16)
     c = x.shape[1]
     v = F.layer_norm(y.float() @ wl.float().t() + bl, (c,), lnp[0], lnp[1], eps)
     x += v
@@ -372,10 +376,15 @@ def layernorm(x, gamma, beta, out, *, eps=1e-5, res=None, colbias=None, out2=Non
     return out
 
 
-def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out, work=0.0):
+ATTN_Q_PRESCALED, ATTN_V_BF16 = 1, 2
+
+
+def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, scale, out, work=0.0, flags=0):
     ps = patch_start.numpy().astype(np.int64)
     assert int(np.diff(ps).max()) == max_len
     qq, kk, vv = q.float()[q_gidx.long()], k.float()[kv_gidx.long()], v.float()[kv_gidx.long()]
+    if flags & ATTN_Q_PRESCALED:  # q carries scale * log2(e): softmax over 2^s instead of e^(scale s)
+        scale = math.log(2.0)
     o = OM._patch_attention(qq, kk, vv, ps, num_heads, scale)
     m = widx >= 0
     out[widx[m].long()] = o[m].to(out.dtype)

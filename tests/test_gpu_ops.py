@@ -825,6 +825,8 @@ def test_batched_plan_kernels_equal_single_calls(ops, name):
     shifts = [3, 6, 9]
     cl, seg, meta = ops.pool_levels(zs, shifts, last)
     meta = meta.cpu().numpy()
+    assert meta[-1] == 0  # no duplicate (batch, voxel) codes in the fixture
+    meta = meta[:-1].reshape(len(shifts), 1 + nb)
     singles = []
     for l, sh in enumerate(shifts):
         c1, s1, cnt = ops.pool_level(zs, sh)
@@ -888,6 +890,125 @@ def test_attention_bf16_loose_score_bound_falls_back_to_exact_max(ops, lp):
     want = torch.cat([ref[:1024], ref[1024 + (2048 - n):]])
     assert torch.isfinite(got).all()
     assert (got - want).abs().max().item() < 0.03 * (1 + want.abs().max().item())
+
+
+@LPS
+@pytest.mark.parametrize("lens,H,flags", [([2500], 2, 1), ([2500], 2, 2), ([1500, 1100], 4, 3), ([991], 32, 3), ([26], 4, 3)])
+def test_attention_ex_producer_side_flags_vs_oracle(ops, lp, lens, H, flags):
+    """cdseg_attention_ex with the preprocessing a producer epilogue does (round 5): q already multiplied by
+    softmax scale * log2(e) (CDSEG_ATTN_Q_PRESCALED) and v stored as bfloat16 inside the build's 16-bit buffer
+    (CDSEG_ATTN_V_BF16: matters in the IEEE-half build).  Oracle: oracle/model.py's patch attention on the SAME rounded
+    operands (the scaled q rounded to the build's type, v rounded to bfloat16)."""
+    g = torch.Generator().manual_seed(sum(lens) + H + flags)
+    C = 16 * H
+    offset = np.cumsum(lens)
+    n = int(offset[-1])
+    scale = 16 ** -0.5
+    c = scale * 1.4426950408889634
+    lpt = LP()
+    q = torch.randn(n, C, generator=g) * 2.0
+    k = torch.randn(n, C, generator=g).to(lpt).float()
+    v = torch.randn(n, C, generator=g)
+    if flags & ops.ATTN_Q_PRESCALED:
+        q_dev = (q * c).to(lpt)                  # what a producer with folded weights writes
+        q_ref = q_dev.float() / c                # the oracle applies `scale` itself: exp(scale q k) = 2^(q' k)
+    else:
+        q_dev = q.to(lpt)
+        q_ref = q_dev.float()
+    if flags & ops.ATTN_V_BF16:
+        v_ref = v.to(torch.bfloat16).float()
+        v_dev = v.to(torch.bfloat16).view(torch.int16).view(lpt) if lpt == torch.float16 else v.to(torch.bfloat16)
+    else:
+        v_ref = v.to(lpt).float()
+        v_dev = v.to(lpt)
+    order = np.concatenate([s0 + torch.randperm(int(cn), generator=g).numpy() for s0, cn in
+                            zip(np.concatenate([[0], offset[:-1]]), lens)]).astype(np.int64)
+    inverse = np.empty(n, dtype=np.int64)
+    inverse[order] = np.arange(n)
+    K = 1024
+    pad, unpad, cu = S.padding_plan(offset, K)
+    t = torch.from_numpy(order[pad])
+    ref = OM._patch_attention(q_ref[t], k[t], v_ref[t], cu, H, scale)[torch.from_numpy(unpad[inverse])]
+    offs = np.concatenate([[0], offset]).astype(np.int32)
+    counts = np.diff(offs)
+    pc = np.where(counts > K, (counts + K - 1) // K * K, counts)
+    offs_pad = np.concatenate([[0], np.cumsum(pc)]).astype(np.int32)
+    gq, wq = ops.pad_plan(dev(order.astype(np.int32)), dev(offs), dev(offs_pad), K, int(offs_pad[-1]))
+    d_qkv = torch.cat([q_dev, k.to(lpt), v_dev], 1).cuda().contiguous()
+    out = torch.full((n, C), float("nan"), dtype=lpt, device="cuda")
+    ops.attention(d_qkv[:, :C], d_qkv[:, C:2 * C], d_qkv[:, 2 * C:], gq, gq, wq, dev(cu.astype(np.int32)), H,
+                  int(np.diff(cu).max()), scale, out, flags=flags)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    err, mag = (got - ref).abs().max().item(), ref.abs().max().item()
+    report(f"attn_ex {lp} lens={lens} H={H} flags={flags}", max_err=err, ref_max=mag)
+    assert err < 0.02 * (1 + mag)
+
+
+def test_attention_ex_rejects_bad_arguments(ops):
+    """Unknown flag bits, a v-is-bfloat16 claim on the fp32 path, and misaligned output rows are CDSEG_ERR_ARG, not UB."""
+    from cdsegnet_amd import _lib
+    n, H = 64, 1
+    qkv = torch.zeros(n, 48, dtype=torch.float32, device="cuda")
+    out = torch.zeros(n, 16, dtype=torch.float32, device="cuda")
+    idx = torch.arange(n, dtype=torch.int32, device="cuda")
+    ps = torch.tensor([0, n], dtype=torch.int32, device="cuda")
+    for flags in (4, 2):
+        with pytest.raises(_lib.CdsegError):
+            ops.attention(qkv[:, :16], qkv[:, 16:32], qkv[:, 32:], idx, idx, idx, ps, H, n, 0.25, out, flags=flags)
+    wide = torch.zeros(n, 18, dtype=torch.float32, device="cuda")  # 72-byte rows
+    with pytest.raises(_lib.CdsegError):
+        ops.attention(qkv[:, :16], qkv[:, 16:32], qkv[:, 32:], idx, idx, idx, ps, H, n, 0.25, wide[:, :16])
+
+
+@LPS
+@pytest.mark.parametrize("n,H,scenes", [(330000, 2, 3), (150000, 4, 1), (70000, 8, 2)])
+def test_attention_large_launch_graded_schedule_vs_fp32_kernel(ops, lp, n, H, scenes):
+    """A launch with hundreds of (patch, head) units per XCD - where cdseg_attention's graded schedule (lead / tail zones of
+    sliced patch-heads, csrc/attention.hip decode_block) is active - against the exact-fp32 kernel, which runs the uniform
+    schedule: every output row written exactly once, same values up to the 16-bit rounding of P and O.  Patches are cut
+    from the Hilbert order of real (synthetic-room) scenes, ragged last patches included."""
+    from cdsegnet_amd import synth
+    grids, batches = [], []
+    for i in range(scenes):
+        sc = synth.room_scene(100 + i, n // scenes)
+        grids.append(torch.as_tensor(sc["grid_coord"]))
+        batches.append(torch.full((len(sc["grid_coord"]),), i, dtype=torch.int64))
+    grid, batch = torch.cat(grids).cuda(), torch.cat(batches).cuda()
+    n = grid.shape[0]
+    counts = torch.bincount(batch.cpu(), minlength=scenes).numpy()
+    depth = int(ops.grid_max(grid).item()).bit_length()
+    zs, perm0 = ops.sort_pairs(ops.encode(grid, batch, depth, "z"))
+    g0, b0 = ops.plan_gather_grid(grid, perm0, zs, depth)
+    code4 = ops.encode4(g0, b0, depth)
+    _, order = ops.sort_pairs(code4[2].contiguous())
+    K = 1024
+    pads = [(c + K - 1) // K * K if c > K else c for c in counts]
+    offs = dev(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+    offs_pad = dev(np.concatenate([[0], np.cumsum(pads)]).astype(np.int32))
+    npad = int(sum(pads))
+    gidx, widx = ops.pad_plan(order, offs, offs_pad, K, npad)
+    starts = []
+    for s0, p in zip(np.concatenate([[0], np.cumsum(pads)])[:-1], pads):
+        starts += list(range(int(s0), int(s0 + p), K))
+    ps = dev(np.array(starts + [npad], dtype=np.int32))
+    C = 16 * H
+    g = torch.Generator().manual_seed(n + H)
+    qkv = torch.randn(n, 3 * C, generator=g).to(LP())
+    d16 = qkv.cuda()
+    d32 = qkv.float().cuda()
+    o16 = torch.full((n, C), float("nan"), dtype=LP(), device="cuda")
+    o32 = torch.full((n, C), float("nan"), dtype=torch.float32, device="cuda")
+    ops.attention(d16[:, :C], d16[:, C:2 * C], d16[:, 2 * C:], gidx, gidx, widx, ps, H, K, 0.25, o16)
+    ops.attention(d32[:, :C], d32[:, C:2 * C], d32[:, 2 * C:], gidx, gidx, widx, ps, H, K, 0.25, o32)
+    assert torch.isfinite(o16.float()).all() and torch.isfinite(o32).all()
+    err = (o16.float() - o32).abs().max().item()
+    report(f"attn large {lp} n={n} H={H}", max_err=err, units=(ps.numel() - 1) * H)
+    assert err < 0.02 * (1 + o32.abs().max().item())
+    # run-to-run bit determinism of the sliced schedule (slices of a patch-head write disjoint rows)
+    o16b = torch.full_like(o16, float("nan"))
+    ops.attention(d16[:, :C], d16[:, C:2 * C], d16[:, 2 * C:], gidx, gidx, widx, ps, H, K, 0.25, o16b)
+    assert torch.equal(o16.view(torch.int16), o16b.view(torch.int16))
 
 
 @pytest.mark.parametrize("name", ["room1500", "batch2", "lidar5000", "rand16", "lidar8", "tiny64"])
