@@ -58,6 +58,7 @@ class BlockIO(Structure):
         ("n", c_long), ("x", c_void_p), ("xc_in", c_void_p), ("xc_out", c_void_p), ("tbias", c_void_p),
         ("nbr", c_void_p), ("gidx", c_void_p), ("widx", c_void_p), ("patch_start", c_void_p),
         ("num_patches", c_int), ("max_len", c_int), ("scratch", c_void_p), ("scratch_bytes", c_size_t),
+        ("sat_counter", c_void_p),
     ]
 
 
@@ -170,6 +171,7 @@ SIGNATURES = {
     "cdseg_ddim_update": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p, c_long,
                                   c_void_p]),
     "cdseg_axpy": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
+    "cdseg_count_saturated": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _libs = {}

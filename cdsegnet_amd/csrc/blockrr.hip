@@ -20,6 +20,8 @@
 // polynomial form of common.h now (the hidden activation is rounded to 16 bits right after).
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
 #include "deep.h"
 
@@ -420,7 +422,7 @@ extern "C" int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, 
     hipLaunchKernelGGL(tail_rr_kernel<32>, dim3(rr_grid(n, lds)), dim3(RR_WAVES * 64), lds, s, p);
   } else {
     constexpr int lds = RRCfg<64>::TAIL_W + RRCfg<64>::TAIL_P;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
     if (!attr_done) {
       if (hipFuncSetAttribute((const void*)tail_rr_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return CDSEG_ERR_LAUNCH;

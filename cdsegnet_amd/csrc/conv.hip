@@ -26,6 +26,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 #include "prof.h"
 
@@ -291,7 +293,7 @@ int launch_conv_ll(const ConvP& p0, int per_cu, const void* wimg, hipStream_t s)
   p.tiles = (int)((p.n + WAVES * K::ROWS_PER_WAVE - 1) / (WAVES * K::ROWS_PER_WAVE));
   int grid = 256 * per_cu;
   if (grid > p.tiles) grid = (p.tiles + 7) / 8 * 8;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)conv_ll_kernel<C, WAVES, NB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K::LDS_BYTES) != hipSuccess)

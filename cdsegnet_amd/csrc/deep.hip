@@ -24,6 +24,8 @@
 //     accumulators that were initialised with the residual row.
 // Per workgroup and weight byte the tile does BM (128) FLOP pairs instead of the 64 of a 128 x 128 GEMM tile, the
 // weight stream of all workgroups is the same sequence (L2 hits), and the launches per Block drop from 8 to 2.
+#include <atomic>
+
 #include "deep.h"
 
 namespace {
@@ -469,7 +471,7 @@ inline int pick_bm(long n) { return (n + 127) / 128 >= 160 ? 128 : 32; }
 template <int C, int BM>
 int launch_head(const DeepHeadP& p, hipStream_t s) {
   constexpr int lds = DeepCfg<C, BM>::HEAD_LDS;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)deep_head_kernel<C, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return CDSEG_ERR_LAUNCH;
@@ -483,7 +485,7 @@ int launch_head(const DeepHeadP& p, hipStream_t s) {
 template <int C, int BM>
 int launch_tail(const DeepTailP& p, hipStream_t s) {
   constexpr int lds = DeepCfg<C, BM>::TAIL_LDS;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)deep_tail_kernel<C, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return CDSEG_ERR_LAUNCH;

@@ -231,6 +231,28 @@ __global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict
 
 }  // namespace
 
+// Diagnostic of the IEEE-half build: how many elements of a 16-bit activation buffer sit exactly at +-65504, the value every
+// float -> half conversion of that build clamps to (common.h).  A trained checkpoint whose activations leave half's range
+// shows up as a non-zero count instead of silently clamped logits.  (The bfloat16 build never clamps: counts nothing.)
+__global__ void count_saturated_kernel(const uint16_t* __restrict__ x, long rows, int cols, int ld,
+                                       unsigned long long* __restrict__ counter) {
+  unsigned local = 0;
+  if (LP_IS_F16) {
+    const long total = rows * (long)cols;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+      const long r = t / cols;
+      const int c = (int)(t - r * cols);
+      local += (x[r * ld + c] & 0x7FFFu) == 0x7BFFu;
+    }
+  }
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(local != 0);
+  if (m) {  // rare: one atomic per wave that saw any
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned long long)local);
+  }
+}
+
 extern "C" {
 
 int cdseg_layernorm(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, float eps,
@@ -327,6 +349,17 @@ int cdseg_ddim_update(const float* xt, const float* eps, float sqrt_ab_prev, flo
   if (n <= 0) return CDSEG_OK;
   hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xt, eps,
                      sqrt_ab_prev, sqrt_1m_ab, sqrt_ab, sqrt_1m_ab_prev, final_step, out, n);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+int cdseg_count_saturated(const void* x, long rows, int cols, int ld, unsigned long long* counter, void* stream) {
+  if (rows <= 0 || cols <= 0) return CDSEG_OK;
+  if (!x || !counter || ld < cols) return CDSEG_ERR_ARG;
+  const long total = rows * (long)cols;
+  const unsigned blocks = (unsigned)((total + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(count_saturated_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, rows, cols, ld, counter);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

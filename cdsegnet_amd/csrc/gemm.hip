@@ -27,6 +27,8 @@
 // float4 groups and every store is a full 16-byte (8-byte for bf16) coalesced access.
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
 #include "prof.h"
 
@@ -1308,7 +1310,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     if (deep && !launched) {
       launched = true;
       constexpr int smem = gemm_smem_bytes<CT, 128, 16, 256>();  // 97 KB: 1 block / CU, 4 waves / SIMD
-      static bool attr_done256 = false;
+      static std::atomic<bool> attr_done256{false};  // (a concurrent first call sets the attribute twice: harmless)
       if (!attr_done256) {
         if (hipFuncSetAttribute((const void*)gemm_kernel<CT, 128, 16, GATHER, 256>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1327,7 +1329,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
         hipLaunchKernelGGL((gemm_kernel<CT, 64, 16, GATHER, 128>), grid, dim3(512), 0, s, p);
       } else {
         constexpr int smem = gemm_smem_bytes<CT, 128, 16, 128>();  // 65 KB: above the static LDS limit
-        static bool attr_done = false;
+        static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
         if (!attr_done) {
           if (hipFuncSetAttribute((const void*)gemm_kernel<CT, 128, 16, GATHER, 128>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)

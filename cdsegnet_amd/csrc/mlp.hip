@@ -7,6 +7,8 @@
 // h, the residual and the two outputs touch HBM.  bf16 only (the fp32 parity mode keeps the two-GEMM form).
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -270,7 +272,7 @@ template <int C, int HT, bool PROJ, int BM>
 int launch_mlp(const MlpP& p, hipStream_t s) {
   constexpr int CLD = C + 4;
   constexpr int LDS = BM * C * 2 + HT * C * 2 + BM * HT * 2 + C * HT * 2 + (PROJ ? BM * CLD * 4 : 0);
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
   if (!attr_done) {
     if (LDS > 64 * 1024 && hipFuncSetAttribute((const void*)mlp_fused_kernel<C, HT, PROJ, BM>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)

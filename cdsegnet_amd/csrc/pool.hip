@@ -17,6 +17,8 @@
 //     rows, no cross-lane traffic, clusters that straddle two strips just continue in the next one;
 //   * epilogue per pooled row: folded BatchNorm, GELU (erf), fp32 row + its 16-bit copy, 64 - 128 contiguous bytes per lane.
 // HBM traffic = the fine rows once + the pooled rows once.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -189,7 +191,7 @@ __global__ void pool_pack_kernel(const bf16_t* __restrict__ w, uint4* __restrict
 template <int CIN, int COUT>
 int launch_pool(const PoolP& p, hipStream_t s) {
   using K = PoolCfg<CIN, COUT>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)pool_fused_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS) != hipSuccess)
       return CDSEG_ERR_LAUNCH;

@@ -79,7 +79,26 @@ extern "C" size_t cdseg_block_scratch_bytes(const cdseg_block_desc* d, long n) {
   return carve(d, n, nullptr).total;
 }
 
+static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* io, void* stream);
+
 extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_io* io, void* stream) {
+  const int rc = block_forward_impl(d, io, stream);
+  if (rc != CDSEG_OK || !io->sat_counter || io->n <= 0 || d->dtype != CDSEG_BF16) return rc;
+  // diagnostic (IEEE-half build): clamped values in the Block's 16-bit buffers that reach memory - conv output, q and k
+  // (v may be bfloat16), attention output, shadow copy of the residual stream.  LayerNorm outputs and the MLP's hidden
+  // units live inside the fused kernels and are not seen.
+  const Layout L = carve(d, io->n, io->scratch);
+  const int C = d->channels;
+  int r;
+  if ((r = cdseg_count_saturated(L.y, io->n, C, C, io->sat_counter, stream)) != CDSEG_OK) return r;
+  if ((r = cdseg_count_saturated(L.qkv, io->n, 2 * C, 3 * C, io->sat_counter, stream)) != CDSEG_OK) return r;
+  if ((r = cdseg_count_saturated(L.o, io->n, C, C, io->sat_counter, stream)) != CDSEG_OK) return r;
+  if ((const void*)io->xc_out != (const void*)io->x)
+    if ((r = cdseg_count_saturated(io->xc_out, io->n, C, C, io->sat_counter, stream)) != CDSEG_OK) return r;
+  return CDSEG_OK;
+}
+
+static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* io, void* stream) {
   if (!d || !io || !io->x || !io->xc_in || !io->xc_out || !io->nbr || !io->gidx || !io->widx || !io->patch_start)
     return CDSEG_ERR_ARG;
   const long n = io->n;

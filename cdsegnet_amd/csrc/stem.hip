@@ -25,6 +25,8 @@
 // Prefetching the next tile's walk inputs during the MFMA batches did not help: 197 us).
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -218,7 +220,7 @@ extern "C" int cdseg_stem5(const void* x8, const void* wimg, const float* scale,
   if (!x8 || !wimg || !scale || !shift || !grid || !cluster || !parent_nbr3 || !child_info || !out) return CDSEG_ERR_ARG;
   if (n <= 0) return CDSEG_OK;
   if (n >= (1l << 31) || m <= 0) return CDSEG_ERR_UNSUPPORTED;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};  // (a concurrent first call sets the attribute twice: harmless)
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)stem5_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS) != hipSuccess)
       return CDSEG_ERR_LAUNCH;

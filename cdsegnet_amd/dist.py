@@ -137,14 +137,20 @@ def gather_predictions(items, group=None):
     ids of every shipped config, 2 bytes per point: a 312-scene ScanNet split is ~75 MB in total).  Single process:
     returns the items as a dict."""
     items = [(int(i), t.reshape(-1)) for i, t in items]
-    for _, t in items:
-        if t.numel() and (int(t.max()) > 32767 or int(t.min()) < -32768):
+    nonempty = [t for _, t in items if t.numel()]
+    if nonempty:  # range check once, on the concatenated labels (one host read, not two per scene)
+        lo, hi = torch.aminmax(torch.cat([t.to(torch.int64) for t in nonempty]))
+        if int(hi) > 32767 or int(lo) < -32768:
             raise ValueError("labels do not fit int16")
     if not is_dist():
         return {i: t.to(torch.int16) for i, t in items}
     world = dist.get_world_size(group)
-    dev = items[0][1].device if items else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and \
-        dist.get_backend(group) == "nccl" else torch.device("cpu")
+    # the buffers live where the BACKEND communicates, whatever device the labels came from (and the same on a rank that
+    # holds no scene): nccl (= RCCL) -> this process's GPU, gloo -> host memory
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
     k = torch.tensor([len(items), sum(t.numel() for _, t in items)], dtype=torch.int64, device=dev)
     ks = [torch.zeros_like(k) for _ in range(world)]
     dist.all_gather(ks, k, group=group)
@@ -273,6 +279,12 @@ class GradSync:
         def hook(p):
             if self.bucketer is None:
                 self.bucketer = GradBucketer(**self.kw)
+                self._seen, self._order = set(), []
+            if name in self._seen:  # a second backward() before finish(): its collectives would pair up wrongly
+                raise RuntimeError(f"GradSync: gradient of {name} became ready twice before finish() - call finish() after "
+                                   f"every backward() (gradient accumulation over several backwards is not supported)")
+            self._seen.add(name)
+            self._order.append((name, p.grad.numel()))
             self.bucketer.add(name, p.grad)
         return hook
 
@@ -281,6 +293,17 @@ class GradSync:
         b, self.bucketer = self.bucketer, None
         if b is None:
             return
+        if is_dist():
+            # the bucket layout is the order in which gradients became ready: it must be the same on every rank, or the
+            # all-reduces above summed unrelated parameters.  One tiny MIN / MAX all-reduce of a digest of that order
+            import zlib
+            h = zlib.crc32(repr(self._order).encode()) & 0x7FFFFFFF
+            dev = self.named[0][1].grad.device if dist.get_backend(self.kw["group"]) == "nccl" else torch.device("cpu")
+            t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.kw["group"])
+            if int(t[0]) != -int(t[1]):
+                raise RuntimeError("GradSync: the ranks produced their gradients in different orders / sizes (different graphs "
+                                   "per rank?) - the bucketed all-reduces do not line up")
         avg = b.finish()
         self.buckets_reduced = b.buckets_reduced
         for n, p in self.named:

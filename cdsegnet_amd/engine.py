@@ -202,6 +202,14 @@ class Engine:
         self._rng_seed = None  # torch.initial_seed() the device-RNG cursor belongs to
         self.use_native_blocks = True  # one library call per Block instead of ~8 binding calls
         self.fold_attn_scale = True  # 16-bit engines: softmax scale * log2(e) folded into Wq / bq at prepare (tools A/B: False)
+        # diagnostic of the IEEE-half trunk: count the 16-bit activations that reach memory at +-65504, the clamp value of the
+        # half build's conversions (a checkpoint whose activations leave half's range is then noticed, not silently clamped).
+        # Off in the timed path (a few extra launches per Block and one host read per forward); smoke and bench run one
+        # forward with it.  Result of the last forward: saturation_count / saturation_checked (elements looked at)
+        self.count_saturation = False
+        self.saturation_count = None
+        self.saturation_checked = 0
+        self._sat = None
         self.exact_attention_core = False  # budget tool only: fp32 attention core inside a 16-bit trunk (binding path)
         self._pad_keys = None
         self._side = {}
@@ -657,7 +665,9 @@ class Engine:
                     self._scratch_bytes.clear()
                 sb = self._scratch_bytes[(pre, n)] = ops.block_scratch_bytes(desc, n)
             ops.block_forward(desc, n, st.x, st.xc, xc_out, tbias, lv.nbr(3, True), gidx, widx, patch_start,
-                              patch_start.numel() - 1, max_len, self.scratch(sb))
+                              patch_start.numel() - 1, max_len, self.scratch(sb), sat_counter=self._sat)
+            if self._sat is not None:
+                self.saturation_checked += n * c * (5 if xc_out is not st.x else 4)
             st.xc = xc_out
             return
         qkv = self._buf(n, 3 * c, self.T)
@@ -740,6 +750,7 @@ class Engine:
         else:
             ops.gemm(a, w[pre + ".w"], x, scale=w[pre + ".bn.scale"], shift=w[pre + ".bn.shift"], act=ops.ACT_GELU,
                      nbr=lv.nbr(5, True), nbr_kmajor=True, kvol=125, out2=None if xc is x else xc)
+        self._sat_note(xc)
         return State(lv, x, xc, curves)
 
     def run_pooling(self, plan, st, pre, cum_to, perm):
@@ -761,6 +772,7 @@ class Engine:
             ops.gemm(st.xc, w[pre + ".proj.w"], y, bias=w[pre + ".proj.b"])
             ops.segment_max(y, seg, coarse.n, w[pre + ".bn.scale"], w[pre + ".bn.shift"], ops.ACT_GELU, x,
                             None if xc is x else xc)
+        self._sat_note(xc)
         curves = st.curves if perm is None else [st.curves[int(j)] for j in perm]
         out = State(coarse, x, xc, curves)
         out.parent = st
@@ -799,6 +811,7 @@ class Engine:
             ops.gemm(parent.xc, w[pre + ".skip.w"], xc, bias=w[pre + ".skip.b"], scale=w[pre + ".skip_bn.scale"],
                      shift=w[pre + ".skip_bn.shift"], act=ops.ACT_GELU)
             ops.gemm(xc, w[pre + ".cat_a.w"], x, bias=w[pre + ".cat.b"], add_src=z, add_idx=cluster)
+        self._sat_note(xc)
         out = State(fine, x, xc, parent.curves)
         out.parent = parent.parent
         return out
@@ -1030,6 +1043,24 @@ class Engine:
         tall = ops.gemv(w["t.mlp.w"], w["t.mlp.b"], v, ops.ACT_NONE)
         return {k: tall[a:b] for k, (a, b) in self.t_slices.items()}
 
+    def _sat_begin(self, dev):
+        """Start of a forward: arm the saturation diagnostic (IEEE-half trunks only)."""
+        self._sat = None
+        self.saturation_count, self.saturation_checked = None, 0
+        if self.count_saturation and self.T == torch.float16:
+            self._sat = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def _sat_note(self, t):
+        """A 16-bit activation outside the Blocks (stem / pooling / un-pooling outputs)."""
+        if self._sat is not None and t is not None and t.dtype == torch.float16:
+            ops.count_saturated(t, self._sat)
+            self.saturation_checked += t.numel()
+
+    def _sat_end(self):
+        if self._sat is not None:
+            self.saturation_count = int(self._sat.item())  # (diagnostic mode: one host read)
+            self._sat = None
+
     def _inference(self, input_dict, noise_level=None, draws=None):
         m, bb = self.model, self.model.backbone
         feat, draws, perms, plan, _ = self._setup(input_dict, noise_level, draws, 1)
@@ -1048,7 +1079,9 @@ class Engine:
             else:
                 c_feat = feat if c_ch == feat.shape[1] else input_dict["coord"].float().contiguous()
                 c_perm = plan.perm0
+        self._sat_begin(dev)
         logits, _ = self.backbone(plan, feat, c_feat, c_perm, t, perms, want_c=False)
+        self._sat_end()
         return logits
 
     def _inference_ddim(self, input_dict, step, mode, noise_level, draws):

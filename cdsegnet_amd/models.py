@@ -429,6 +429,9 @@ class DefaultSegmentorV2(nn.Module):
         # noise_level jitter: "torch_cpu" = the CPU-run reference's draw order (golden vectors) | "device" = device
         # Philox, leaves the CPU generator alone like a GPU run of the reference does (engine.draw)
         self.feat_noise_source = "torch_cpu"
+        # diagnostic (IEEE-half trunk): count clamped activations during `inference` (a few extra launches and one host
+        # read per call; off by default) -> engine().saturation_count / .saturation_checked after the call
+        self.count_saturation = False
         self._engine = None
 
     # -- engine cache management -------------------------------------------------------------
@@ -448,6 +451,7 @@ class DefaultSegmentorV2(nn.Module):
         from .engine import Engine
         if self._engine is None or self._engine.precision != self.precision:
             self._engine = Engine(self, self.precision)
+        self._engine.count_saturation = bool(self.count_saturation)
         return self._engine
 
     # -- reference API -----------------------------------------------------------------------

@@ -462,15 +462,17 @@ def pad_plan_batch(items, nb):
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
          nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
          nbr_kmajor=False,
-         ln_post=None, ln_out=None, ln_eps=1e-5):
+         ln_post=None, ln_out=None, ln_eps=1e-5, cache=True):
     """out = epilogue(A @ W^T) (or the gathered-A sparse-conv form when nbr is given).
-    A (M,K) [or the gather source], W (N, kvol*K), both of the compute dtype."""
+    A (M,K) [or the gather source], W (N, kvol*K), both of the compute dtype.
+    cache=False: W is a temporary (a transposed / mirrored copy made for this call, as the training backward does): the
+    argument block is built on the spot and nothing keeps W alive afterwards."""
     if not A.is_cuda:
         _need_gpu(A, W, out)
     # the weight-side half of the argument block is static per layer: cache it keyed by the weight tensor
     key = (W.data_ptr(), _dp(bias), _dp(scale), _dp(shift), int(kvol), int(act))
-    cache = _TLS.gemm_cache
-    ent = cache.get(key)
+    cache_d = _TLS.gemm_cache
+    ent = cache_d.get(key) if cache else None
     if ent is None:
         for t in (bias, scale, shift):
             if t is not None and t.dtype != torch.float32:
@@ -483,9 +485,10 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
         a.compute_dtype = dt(W)
         a.act = int(act)
         ent = (a, ctypes.byref(a), W)  # keep W alive with the cache entry
-        if len(cache) > 4096:
-            cache.clear()
-        cache[key] = ent
+        if cache:
+            if len(cache_d) > 4096:
+                cache_d.clear()
+            cache_d[key] = ent
     a = ent[0]
     if (res is not None and res.dtype != torch.float32) or (add_src is not None and add_src.dtype != torch.float32):
         raise _lib.CdsegError("gemm residuals are float32")
@@ -648,8 +651,18 @@ def block_scratch_bytes(desc, n):
     return _lib.load().cdseg_block_scratch_bytes(desc[1], int(n))
 
 
-def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start, num_patches, max_len, scratch):
-    """One PTv3 Block on the native executor (all launches issued by the library, one host call)."""
+def count_saturated(x, counter):
+    """Diagnostic of the IEEE-half build: counter (1-element int64 device tensor) += elements of the 16-bit matrix x that
+    sit at +-65504, the clamp value of that build's float -> half conversions."""
+    _need_gpu(x, counter)
+    check(_lib.load().cdseg_count_saturated(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(counter), _stream()),
+          "count_saturated")
+
+
+def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start, num_patches, max_len, scratch,
+                  sat_counter=None):
+    """One PTv3 Block on the native executor (all launches issued by the library, one host call).  sat_counter: 1-element
+    int64 device tensor that collects the Block's clamped half values (diagnostic, see count_saturated)."""
     if _TLS.block_io is None:
         io = _lib.BlockIO()
         _TLS.block_io = (io, ctypes.byref(io))
@@ -659,6 +672,7 @@ def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start
     io.nbr, io.gidx, io.widx, io.patch_start = nbr.data_ptr(), gidx.data_ptr(), widx.data_ptr(), patch_start.data_ptr()
     io.num_patches, io.max_len = int(num_patches), int(max_len)
     io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
+    io.sat_counter = sat_counter.data_ptr() if sat_counter is not None else None
     check(_lib.load().cdseg_block_forward(desc[1], ref, _stream()), "block_forward")
 
 

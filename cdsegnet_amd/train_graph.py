@@ -55,7 +55,8 @@ class _SubMConv(torch.autograd.Function):
         x = _c(x)
         w = _c(w3).reshape(cout, kvol * cp)
         y = _f32((x.shape[0], cout), x)
-        ops.gemm(x, w, y, bias=b, nbr=nbr, kvol=kvol, nbr_kmajor=True)
+        # (a padded stem weight is a fresh tensor every step: no cache entry may pin it - ADVICE r4)
+        ops.gemm(x, w, y, bias=b, nbr=nbr, kvol=kvol, nbr_kmajor=True, cache=cp == cin)
         ctx.save_for_backward(x, w, nbr)
         ctx.meta = (cin, cp, kvol, b is not None, tuple(w5.shape))
         return y
@@ -76,7 +77,7 @@ class _SubMConv(torch.autograd.Function):
             # W'[ci][o][co] = W[co][kvol - 1 - o][ci]
             wt = _c(w.view(cout, kvol, cp).flip(1).permute(2, 1, 0)).view(cp, kvol * cout)
             dxp = _f32((x.shape[0], cp), dy)
-            ops.gemm(dy, wt, dxp, nbr=nbr, kvol=kvol, nbr_kmajor=True)
+            ops.gemm(dy, wt, dxp, nbr=nbr, kvol=kvol, nbr_kmajor=True, cache=False)  # wt: a per-call temporary
             dx = dxp[:, :cin]
         return dx, dw5, db, None
 
@@ -98,7 +99,7 @@ class _Linear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _f32(x.shape, dy)
-            ops.gemm(dy, _c(w.t()), dx)
+            ops.gemm(dy, _c(w.t()), dx, cache=False)  # the transposed copy is a per-call temporary
         dw = torch.zeros_like(w)
         db = torch.zeros(w.shape[0], dtype=torch.float32, device=dy.device) if ctx.has_b else None
         ops.linear_wgrad(x, dy, dw, db)
@@ -208,7 +209,10 @@ def _swish(x):  # ptv3.py:30-31
 
 
 def _bn_gelu(x, bn):
-    """nn.BatchNorm1d in train mode (batch statistics, running buffers updated like the module would) -> GELU."""
+    """nn.BatchNorm1d -> GELU, in the module's own mode: training = batch statistics, running buffers updated like the
+    module would; eval (`model.eval(); model(batch)`, e.g. a validation-loss hook) = running statistics, buffers untouched."""
+    if not bn.training:
+        return F.gelu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, bn.momentum, bn.eps))
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return F.gelu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps))
@@ -248,7 +252,7 @@ class TrainGraph:
             out = torch.empty_like(m)
             out[st.ref_order.long()] = m
             return out
-        if rate <= 0.0:
+        if rate <= 0.0 or not self.model.training:  # DropPath is the identity in eval mode (timm; ptv3.py:393)
             return None
         keep = 1.0 - rate
         return torch.empty((st.x.shape[0], 1), dtype=torch.float32, device=st.x.device).bernoulli_(keep) / keep

@@ -279,6 +279,11 @@ int cdseg_gather_pad_cast(const float* src, int ld_src, const int32_t* idx, long
  * x0 = (xt - sqrt(1-ab_t) eps) / sqrt(ab_t); out = final ? x0 : sqrt(ab_{t-1}) x0 + sqrt(1-ab_{t-1}) eps */
 int cdseg_ddim_update(const float* xt, const float* eps, float sqrt_ab_prev, float sqrt_1m_ab, float sqrt_ab,
                       float sqrt_1m_ab_prev, int final_step, float* out, long n, void* stream);
+/* Diagnostic of the IEEE-half build: *counter += the number of elements of the 16-bit buffer x (rows x cols, row stride ld
+ * elements) that sit exactly at +-65504 - the value every float -> half conversion of that build clamps to.  The bfloat16
+ * build never clamps and adds nothing.  cdseg_block_forward runs it over a Block's conv output, q / k, attention output and
+ * shadow copy when cdseg_block_io.sat_counter is set. */
+int cdseg_count_saturated(const void* x, long rows, int cols, int ld, unsigned long long* counter, void* stream);
 /* out = a + alpha * b (fp32).  ref: default.py:228-236 (add_gaussian_noise) */
 int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, void* stream);
 
@@ -450,6 +455,8 @@ typedef struct cdseg_block_io {
   int max_len;
   void* scratch;           /* >= cdseg_block_scratch_bytes(desc, n) */
   size_t scratch_bytes;
+  unsigned long long* sat_counter; /* NULL, or (diagnostic, IEEE-half build): += clamped values seen in this Block's 16-bit
+                                      buffers that reach memory (cdseg_count_saturated); costs a few extra launches */
 } cdseg_block_io;
 
 size_t cdseg_block_scratch_bytes(const cdseg_block_desc* desc, long n);

@@ -202,7 +202,7 @@ def _act(v, act):
 
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
          nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
-         ln_post=None, ln_out=None, ln_eps=1e-5, nbr_kmajor=False):
+         ln_post=None, ln_out=None, ln_eps=1e-5, nbr_kmajor=False, cache=True):
     assert A.dtype == W.dtype
     Af, Wf = A.float(), W.float()
     if nbr is not None and nbr_kmajor:

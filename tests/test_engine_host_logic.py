@@ -558,3 +558,55 @@ def test_segment_max_backward_sends_the_gradient_to_the_first_maximum(monkeypatc
     out.backward(g)
     want = torch.tensor([[0., 2., 3.], [1., 0., 0.], [0., 0., 0.], [4., 5., 6.], [7., 8., 9.], [0., 0., 0.]])
     assert torch.equal(y.grad, want)
+
+
+def test_duplicate_voxels_raise_on_the_host_read(emulated):
+    """Round 5 input guard: two points in one voxel (same batch element) -> CdsegError out of the pooled-size read."""
+    from cdsegnet_amd._lib import CdsegError
+    fx = load_fixture("mini_e2e_room.npz")
+    model = build_model(fixture_cfg(fx))
+    model.load_state_dict(fixture_state_dict(fx))
+    model.eval()
+    model.precision = "fp32"
+    inp = {k: torch.as_tensor(np.array(v, copy=True)) for k, v in fixture_input(fx).items()}
+    inp["grid_coord"][5] = inp["grid_coord"][900]
+    with pytest.raises(CdsegError, match="duplicate voxels"):
+        model.inference(inp, eval=False, draws=fixture_draws(fx))
+
+
+def test_training_forward_in_eval_mode_leaves_the_model_untouched(monkeypatch):
+    """`model.eval(); model(batch)` (a validation-loss hook, ref: hooks/evaluator.py:29-35) must use the BatchNorm
+    running statistics, leave the buffers alone and make DropPath the identity - as the reference's modules do in eval mode -
+    instead of updating `num_batches_tracked` / the running stats and returning a noisy loss."""
+    import cdsegnet_amd.engine as engine
+    import cdsegnet_amd.train_graph as tg
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    monkeypatch.setattr(engine, "ops", emu_ops)
+    monkeypatch.setattr(tg, "ops", emu_ops)
+    cfg = configs.mini_config()
+    cfg["backbone"]["enable_flash"] = False
+    cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+                       dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]
+    cfg["loss_type"] = "EW"
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=9))
+    sc = synth.room_scene(6, 500, num_classes=cfg["num_classes"])
+    inp = {k: torch.as_tensor(sc[k]) for k in ("coord", "grid_coord", "feat", "offset")}
+    inp["segment"] = torch.as_tensor(np.asarray(sc["segment"]).astype(np.int64))
+    draws = dict(ts=np.array([[17]]), noise=np.random.default_rng(0).standard_normal((len(sc["coord"]), cfg["c_in_channels"])).astype(np.float32),
+                 perms=[[0, 1, 2, 3]] * 8)
+    model.eval()
+    buffers = {k: v.clone() for k, v in model.named_buffers()}
+    with torch.no_grad():
+        a = float(model(dict(inp), draws=dict(draws))["loss"])
+        b = float(model(dict(inp), draws=dict(draws))["loss"])
+    assert a == b  # no stochastic depth, no batch statistics: the eval-mode loss is a function of the inputs alone
+    for k, v in model.named_buffers():
+        assert torch.equal(v, buffers[k]), k  # running_mean / running_var / num_batches_tracked untouched
+    model.train()
+    with torch.no_grad():
+        model(dict(inp), draws=dict(draws))
+    changed = [k for k, v in model.named_buffers() if not torch.equal(v, buffers[k])]
+    assert any(k.endswith("num_batches_tracked") for k in changed)  # ... while train mode does update them

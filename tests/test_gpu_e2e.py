@@ -736,3 +736,102 @@ def test_half_build_rejects_weights_outside_its_range():
         run(build(cfg, sd, "fp16+head", enable_flash=False), inp, draws)
     out = run(build(cfg, sd, "bf16+head", enable_flash=False), inp, draws)
     assert np.isfinite(out).all()
+
+
+# ------------------------------------------------------------------ input / range guards (round 5)
+def test_duplicate_voxels_are_rejected_loudly():
+    """The model's input contract is one point per voxel (GridSample upstream): the kernel maps and the derived
+    coarse orders assume it.  A scene with two points in one voxel must raise - detected on the device (adjacent equal
+    sorted codes, counted in the pooled-size read the forward does anyway), not silently computed."""
+    from cdsegnet_amd._lib import CdsegError
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = fixture_cfg(fx), dict(fixture_state_dict(fx))
+    inp, draws = fixture_input(fx), fixture_draws(fx)
+    model = build(cfg, sd, "fp32", enable_flash=False)
+    assert np.isfinite(run(model, inp, draws)).all()  # the fixture itself is fine
+    bad = {k: np.array(v, copy=True) for k, v in inp.items()}
+    bad["grid_coord"][7] = bad["grid_coord"][1234]  # two points, one voxel
+    with pytest.raises(CdsegError, match="duplicate voxels"):
+        run(model, bad, draws)
+    # same voxel in DIFFERENT batch elements is legal (the batch id is part of the code)
+    fx2 = load_fixture("mini_e2e_batch2.npz")
+    cfg2, sd2 = fixture_cfg(fx2), dict(fixture_state_dict(fx2))
+    inp2, draws2 = fixture_input(fx2), fixture_draws(fx2)
+    first = int(np.asarray(inp2["offset"])[0])
+    ok = {k: np.array(v, copy=True) for k, v in inp2.items()}
+    ok["grid_coord"][first] = ok["grid_coord"][0]
+    if len(np.unique(ok["grid_coord"][first:], axis=0)) == len(ok["grid_coord"]) - first:  # still unique inside element 2
+        assert np.isfinite(run(build(cfg2, sd2, "fp32", enable_flash=False), ok, draws2)).all()
+
+
+def test_half_trunk_saturation_counter():
+    """precision "fp16+head" clamps float -> half conversions at +-65504.  With `model.count_saturation` the forward counts
+    the 16-bit activations that reach memory at the clamp value: 0 for a well-scaled model, > 0 when every weight is scaled
+    x10 (the case DESIGN.md 2 describes: finite, but wrong) - a checkpoint that leaves half's range is noticed."""
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = fixture_cfg(fx), dict(fixture_state_dict(fx))
+    inp, draws = fixture_input(fx), fixture_draws(fx)
+    model = build(cfg, sd, "fp16+head", enable_flash=False)
+    model.count_saturation = True
+    base = run(model, inp, draws)
+    eng = model.engine()
+    assert eng.saturation_count == 0 and eng.saturation_checked > 10 * len(base)
+    model.count_saturation = False
+    plain = run(model, inp, draws)
+    assert model.engine().saturation_count is None and np.array_equal(plain, base)  # the diagnostic changes nothing
+    big = dict(sd)
+    for k in list(big):
+        v = big[k]
+        if k.endswith(".weight") and v.dim() >= 2 and "seg_head" not in k:
+            big[k] = v * 10.0
+    m2 = build(cfg, big, "fp16+head", enable_flash=False)
+    m2.count_saturation = True
+    out = run(m2, inp, draws)
+    print(f"[measure] half saturation counter, weights x10: {m2.engine().saturation_count} of {m2.engine().saturation_checked}")
+    assert np.isfinite(out).all() and m2.engine().saturation_count > 0
+    # the bfloat16 trunk never clamps: the diagnostic stays silent there
+    m3 = build(cfg, big, "bf16+head", enable_flash=False)
+    m3.count_saturation = True
+    run(m3, inp, draws)
+    assert m3.engine().saturation_count is None
+
+
+_BIG = {}
+
+
+def _big_collated_case():
+    """Two collated synthetic rooms of ~110 k voxels, full-width model, CPU-oracle logits (computed once per session)."""
+    if not _BIG:
+        cfg = configs.cdsegnet_config("scannet")
+        model = build_model(cfg)
+        sd = fill_state_dict(model.state_dict(), seed=23)
+        scs = [synth.room_scene(71, 110000), synth.room_scene(72, 110000)]
+        inp = {k: np.concatenate([sc[k] for sc in scs]) for k in ("coord", "grid_coord", "feat")}
+        inp["offset"] = np.cumsum([len(sc["coord"]) for sc in scs]).astype(np.int64)
+        n = len(inp["coord"])
+        draws = OM.draw_rng(5, n, cfg["c_in_channels"])
+        ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"]).numpy()
+        _BIG.update(cfg=cfg, sd=sd, inp=inp, draws=draws, ref=ref, n=n)
+    return _BIG
+
+
+@pytest.mark.parametrize("precision", ["fp16+head", "bf16+head"])
+def test_deep_conv_256_tile_on_a_real_kernel_map_vs_oracle(precision):
+    """the 8-wave 256 x 256 gathered-conv tile (gemm.hip, C >= 256 at >= 5000 rows) was oracle-checked on
+    random kernel maps only - every oracle end-to-end case stayed on the 128-row tile.  Two collated scenes of 110 k voxels
+    put > 5000 rows on stage 3 (C = 256), so the conv of its eight Blocks runs that tile on a REAL z-ordered kernel map;
+    the logits are compared with oracle.model.inference on the same weights, inputs and draws, in both 16-bit builds."""
+    case = _big_collated_case()
+    model = build_model(case["cfg"])
+    model.load_state_dict(case["sd"], strict=True)
+    model = model.cuda().eval()
+    model.precision = precision
+    logits = run(model, case["inp"], case["draws"])
+    plan = model.engine().last_plan
+    rows3 = plan.levels[plan.n_cum[3]].n
+    assert rows3 >= 5000, rows3  # the dispatch threshold of the 256-row tile (gemm.hip)
+    err, agree = report(f"220k collated, full width, {precision} vs oracle (stage-3 rows {rows3})", logits, case["ref"])
+    if precision.startswith("fp16"):
+        assert err < 8e-3 and agree > 0.998
+    else:
+        assert err < 0.08 and agree > 0.98
