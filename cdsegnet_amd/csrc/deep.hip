@@ -137,7 +137,13 @@ __device__ __forceinline__ void row_stats(const f32x4_t (&v)[PTS][2], float* st1
                                           float inv_c, float eps, float (&mean)[PTS], float (&rstd)[PTS]) {
   auto across = [&](float* st, int pt) {
     float t = 0.f;
-    if constexpr (NW == 8) {
+    if constexpr (NW == 16) {
+      const float* s0 = st + (16 * pt + p) * NW;
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(s0), b = *reinterpret_cast<const f32x4_t*>(s0 + 4);
+      const f32x4_t c = *reinterpret_cast<const f32x4_t*>(s0 + 8), d = *reinterpret_cast<const f32x4_t*>(s0 + 12);
+      t = (((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]))) +
+          (((c[0] + c[1]) + (c[2] + c[3])) + ((d[0] + d[1]) + (d[2] + d[3])));
+    } else if constexpr (NW == 8) {
       const f32x4_t a = *reinterpret_cast<const f32x4_t*>(st + (16 * pt + p) * NW);
       const f32x4_t b = *reinterpret_cast<const f32x4_t*>(st + (16 * pt + p) * NW + 4);
       t = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
@@ -504,7 +510,10 @@ extern "C" int cdseg_debug_deep_timing(unsigned long long* host_dst, size_t coun
 }
 #endif
 
-bool deep_supported(int channels) { return channels == 128 || channels == 256; }
+// C = 512 (round 5: the deepest stage, 16 waves per workgroup, 32-row tiles only - the 1024-thread workgroup has 128 VGPRs
+// per wave): a tile streams 2 / 4.7 MB of head / tail weights from L2, which 6 k rows (8 collated scenes: 194 tiles) or 800
+// rows (one scene) amortise better than the 13 GEMM / split-K / row-finish launches per Block they replace
+bool deep_supported(int channels) { return channels == 128 || channels == 256 || channels == 512; }
 
 int deep_pack(int C, const void* wl, const void* wqkv, void* head_img, const void* wp, const void* w1, const void* w2,
               void* tail_img, hipStream_t s) {
@@ -539,6 +548,7 @@ int deep_head(const void* y, int ldy, const void* head_img, const float* bl, con
   const int bm = cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
   if (channels == 128) return bm == 128 ? launch_head<128, 128>(p, s) : launch_head<128, 32>(p, s);
   if (channels == 256) return bm == 128 ? launch_head<256, 128>(p, s) : launch_head<256, 32>(p, s);
+  if (channels == 512) return launch_head<512, 32>(p, s);
   return CDSEG_ERR_UNSUPPORTED;
 }
 
@@ -550,5 +560,6 @@ int deep_tail(const void* o, int ldo, const void* tail_img, const float* bp, con
   const int bm = cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
   if (channels == 128) return bm == 128 ? launch_tail<128, 128>(p, s) : launch_tail<128, 32>(p, s);
   if (channels == 256) return bm == 128 ? launch_tail<256, 128>(p, s) : launch_tail<256, 32>(p, s);
+  if (channels == 512) return launch_tail<512, 32>(p, s);
   return CDSEG_ERR_UNSUPPORTED;
 }

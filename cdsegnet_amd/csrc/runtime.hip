@@ -131,7 +131,12 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
   static const bool fused_head = cdseg_knob("CDSEG_FUSED_HEAD", 1) != 0;
   // deep stages (C = 128 / 256) with weight-stream images: head and tail are one launch each (deep.hip)
   static const bool deep_on = cdseg_knob("CDSEG_DEEP_FUSED", 1) != 0;
-  const bool deep = deep_on && T == CDSEG_BF16 && (C == 128 || C == 256) && d->hidden == 4 * C;
+  // C = 512: a workgroup streams the Block's whole weight set (2 + 4.7 MB) through ONE CU at ~85 GB/s, ~58 us whatever the
+  // row count - a win from ~2.5 k rows (8 collated scenes: 6.2 k rows, head 51 -> 35 us, tail 85 -> 61 us), a loss on a single
+  // scene's 800 rows (tail 42 -> 56 us), which keeps the separate launches (profiles/r05_deep512.txt)
+  static const long deep512_min = cdseg_knob("CDSEG_DEEP512_MIN_ROWS", CDSEG_DEEP512_MIN_ROWS);
+  const bool deep = deep_on && T == CDSEG_BF16 && (C == 128 || C == 256 || (C == 512 && n >= deep512_min)) &&
+                    d->hidden == 4 * C;
   const bool head = (fused_head && T == CDSEG_BF16 && (C == 32 || C == 64)) || (deep && d->head_img);
   if (head && d->head_img) {
     // wide stages: weights resident in LDS, activations in registers (blockrr.hip)

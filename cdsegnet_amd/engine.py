@@ -397,6 +397,11 @@ class Engine:
                 c = cb.q_channels
                 w["x.feat_scale"] = torch.full((c,), cb.tm_feat, dtype=torch.float32, device=device)
                 w["x.feat_zero"] = torch.zeros(c, dtype=torch.float32, device=device)
+            elif (hasattr(ops, "block_rr_pack") and ops.block_rr_ok(cb.q_channels, T) and ops.block_rr_head_on(cb.q_channels)
+                  and w["x.fc1.w"].shape[0] == 4 * cb.q_channels):
+                # the cross block's tail (x += proj(attn); h = LN(x); x += MLP(h), ptv3.py:1205-1222) has a Block tail's
+                # shape: one launch on the streamed-weight kernel (csrc/deep.hip) instead of three GEMMs + their second passes
+                _, w["x.tail_img"] = ops.block_rr_pack(cb.q_channels, None, None, w["x.proj.w"], w["x.fc1.w"], w["x.fc2.w"])
         self.w = w
         if T == torch.float16:
             # IEEE half ends at 65504 and torch's cast does not saturate (the kernels' own float -> half conversions do): a weight
@@ -672,7 +677,8 @@ class Engine:
             return
         qkv = self._buf(n, 3 * c, self.T)
         aflags = ops.ATTN_Q_PRESCALED if self.q_prescaled else 0  # what the qkv producer has done for the attention kernel
-        if (pre + ".head_img") in w and not ops.cpe_head_fused_ok(st.xc):  # deep stages (C = 128 / 256): csrc/deep.hip
+        deep_ok = c != 512 or n >= ops.DEEP512_MIN_ROWS  # (as the native executor decides, csrc/runtime.hip)
+        if (pre + ".head_img") in w and deep_ok and not ops.cpe_head_fused_ok(st.xc):  # deep stages (C = 128 / 256 / 512): csrc/deep.hip
             y = self._buf(n, c, self.T)
             self._conv3(st.xc, pre + ".cpe0", lv, y)
             ops.cpe_head_rr(y, w[pre + ".head_img"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
@@ -712,7 +718,7 @@ class Engine:
             ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads,
                           max_len, att.scale, o, work=64.0 * att.num_heads * sum_l2, flags=aflags)
         hid = w[pre + ".fc1.w"].shape[0]
-        if (pre + ".tail_img") in w and not ops.attn_tail_fused_ok(o, hid):  # deep stages: proj + LN2 + MLP, one launch
+        if (pre + ".tail_img") in w and deep_ok and not ops.attn_tail_fused_ok(o, hid):  # deep stages: proj + LN2 + MLP, one launch
             st.xc = self._buf(n, c, self.T)
             ops.attn_tail_rr(o, w[pre + ".tail_img"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
                              w[pre + ".fc1.b"], w[pre + ".fc2.b"], st.x, st.xc)
@@ -853,6 +859,11 @@ class Engine:
         o = self._buf(n, cq, self.T)
         ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o,
                       work=64.0 * att.num_heads * sum_l2, flags=ops.ATTN_Q_PRESCALED if self.q_prescaled else 0)
+        if "x.tail_img" in w and n >= ops.DEEP512_MIN_ROWS:  # (fewer rows: the separate launches are faster, csrc/runtime.hip)
+            nst.xc = self._buf(n, cq, self.T)
+            ops.attn_tail_rr(o, w["x.tail_img"], w["x.proj.b"], w["x.q_norm2.g"], w["x.q_norm2.b"], w["x.fc1.b"], w["x.fc2.b"],
+                             nst.x, nst.xc)
+            return
         if cb.tm_feat == 1.0:
             ops.gemm(o, w["x.proj.w"], nst.x, bias=w["x.proj.b"], res=nst.x)
         else:  # q_shortcut + feat_scale * attn

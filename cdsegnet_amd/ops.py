@@ -587,12 +587,13 @@ def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5)
     return x
 
 
-DEEP_CHANNELS = (128, 256)  # deep-stage head / tail kernels (csrc/deep.hip): weights streamed L2 -> registers
+DEEP512_MIN_ROWS = 2560  # include/cdseg.h CDSEG_DEEP512_MIN_ROWS: below, a C = 512 Block keeps the separate GEMM launches
+DEEP_CHANNELS = (128, 256, 512)  # deep-stage head / tail kernels (csrc/deep.hip): weights streamed L2 -> registers
 
 
 def block_rr_ok(channels, dtype):
     """Fused Block head / tail kernels on weight images: C = 32 / 64 (csrc/blockrr.hip: weights resident in LDS,
-    activations in registers) and C = 128 / 256 (csrc/deep.hip: activations resident in LDS, weights streamed), 16-bit."""
+    activations in registers) and C = 128 / 256 / 512 (csrc/deep.hip: activations resident in LDS, weights streamed), 16-bit."""
     return is_lp(dtype) and (channels in (32, 64) or channels in DEEP_CHANNELS)
 
 
@@ -603,11 +604,12 @@ def block_rr_head_on(channels=32):
 
 
 def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
-    """Fragment images of a Block's head (cpe linear, qkv) and tail (proj, fc1, fc2) weights -> (head_img, tail_img)."""
+    """Fragment images of a Block's head (cpe linear, qkv) and tail (proj, fc1, fc2) weights -> (head_img, tail_img).
+    wl = wqkv = None: the tail image alone (head_img None) - the cross block's tail has the Block's shape, its head not."""
     _need_gpu(wl, wqkv, wp, w1, w2)
     lib = _lib.load()
-    dev = wl.device
-    head = torch.empty(lib.cdseg_block_rr_img_bytes(channels, 0), dtype=torch.uint8, device=dev)
+    dev = wp.device
+    head = torch.empty(lib.cdseg_block_rr_img_bytes(channels, 0), dtype=torch.uint8, device=dev) if wl is not None else None
     tail = torch.empty(lib.cdseg_block_rr_img_bytes(channels, 1), dtype=torch.uint8, device=dev)
     check(lib.cdseg_block_rr_pack(int(channels), _ptr(wl), _ptr(wqkv), _ptr(head), _ptr(wp), _ptr(w1), _ptr(w2), _ptr(tail),
                                   _stream()), "block_rr_pack")

@@ -48,6 +48,9 @@ extern "C" {
 #define CDSEG_ACT_SWISH 2 /* x * sigmoid(x), ref: models/point_transformer_v3/point_transformer_v3m1_base.py:30-31 */
 
 #define CDSEG_HEAD_DIM 16
+#ifndef CDSEG_DEEP512_MIN_ROWS
+#define CDSEG_DEEP512_MIN_ROWS 2560 /* C = 512 Blocks with fewer rows keep the separate GEMM launches (csrc/runtime.hip) */
+#endif
 #define CDSEG_MAX_PATCH 1024
 
 /* library / device identification (host-only helpers) */

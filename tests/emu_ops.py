@@ -301,7 +301,8 @@ def subm_conv3(x, wimg, bias, nbr_kmajor, out):
     return gemm(x, wimg, out, bias=bias, nbr=nbr_kmajor, nbr_kmajor=True, kvol=27)
 
 
-DEEP_CHANNELS = (128, 256)
+DEEP512_MIN_ROWS = 2560
+DEEP_CHANNELS = (128, 256, 512)
 
 
 def block_rr_ok(channels, dtype):
@@ -313,7 +314,7 @@ def block_rr_head_on(channels=32):
 
 
 def block_rr_pack(channels, wl, wqkv, wp, w1, w2):
-    return (wl, wqkv), (wp, w1, w2)  # the emulation multiplies by the plain weights
+    return ((wl, wqkv) if wl is not None else None), (wp, w1, w2)  # the emulation multiplies by the plain weights
 
 
 def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5, qkv_flags=0):

@@ -1255,7 +1255,8 @@ def _deep_case(M, C, seed, with_t):
 
 @LPS
 @pytest.mark.parametrize("M,C,tb", [(1000, 128, True), (4097, 256, False), (33, 256, True), (20480, 128, False),
-                                    (20481, 256, True), (130000, 128, True)])
+                                    (20481, 256, True), (130000, 128, True), (6200, 512, True), (779, 512, False),
+                                    (31, 512, True)])
 def test_deep_head_and_tail_vs_oracle_and_unfused_sequence(ops, lp, M, C, tb):
     """csrc/deep.hip (C = 128 / 256: activations of a row tile resident in LDS, weights streamed L2 -> registers, 128- and
     32-row workgroups, ragged last tile) against (i) the oracle's Block pieces in fp64 torch with the kernel's 16-bit
@@ -1393,14 +1394,19 @@ def test_pool_fused_equals_gemm_then_segment_max(ops, lp, cin, cout, m, maxrun, 
 
 
 @LPS
-@pytest.mark.parametrize("npts,C,tb", [(900, 32, True), (2300, 64, False), (2300, 128, True), (5300, 256, False), (40, 256, True)])
-def test_native_block_executor_vs_oracle_block(ops, lp, npts, C, tb):
+@pytest.mark.parametrize("npts,C,tb,fold", [(900, 32, True, False), (2300, 64, False, True), (2300, 128, True, False),
+                                            (5300, 256, False, True), (40, 256, True, False), (3200, 512, True, True),
+                                            (790, 512, False, False)])
+def test_native_block_executor_vs_oracle_block(ops, lp, npts, C, tb, fold):
     """cdseg_block_forward - ONE host call per Block: sparse conv, fused head, attention, fused tail, the kernels the
     timed configuration runs at C = 32 / 64 (conv.hip, mlp.hip, blockrr.hip) and C = 128 / 256 (gemm.hip, deep.hip) -
     against oracle/model.py's Block (ref: ptv3.py:399-428) in fp32 on the SAME 16-bit-rounded weights and input, on the
     real kernel map of a synthetic scene and the real padded patch plan (K = 1024, last patch borrowed), ragged row
     counts.  What differs is the 16-bit rounding of the intermediate activations (conv output, LN output, q k v,
-    attention output, hidden units): bounds per build below, measured values in profiles/*_parity_measured.txt."""
+    attention output, hidden units): bounds per build below, measured values in profiles/*_parity_measured.txt.
+    Round 5: C = 512 (deep.hip's 16-wave form) and `fold` = the engine's producer-side preprocessing - the q rows of the
+    qkv weight / bias handed to the library carry softmax scale * log2(e) and the descriptor says so
+    (CDSEG_ATTN_Q_PRESCALED); the oracle keeps the original weights."""
     from cdsegnet_amd import synth
     from oracle import train as OT
     rng = np.random.default_rng(npts + C)
@@ -1445,11 +1451,18 @@ def test_native_block_executor_vs_oracle_block(ops, lp, npts, C, tb):
              fc1_b=f32(".mlp.0.fc1.bias"), fc2_w=w16(".mlp.0.fc2.weight"), fc2_b=f32(".mlp.0.fc2.bias"))
     if ops.subm_conv3_ok(torch.empty((1, C), dtype=bf, device="meta")):
         t["cpe_conv_wimg"] = ops.subm_conv3_pack(t["cpe_conv_w"])
+    if fold:  # what Engine._prepare does: scale the q rows in fp32, then round to the 16-bit type
+        f = 16 ** -0.5 * 1.4426950408889634
+        wq = torch.as_tensor(sd[pre + ".attn.qkv.weight"]).clone()
+        bq = torch.as_tensor(sd[pre + ".attn.qkv.bias"]).clone()
+        wq[:C] *= f
+        bq[:C] *= f
+        t["qkv_w"], t["qkv_b"] = dev(wq, bf), dev(bq)
     assert ops.block_rr_ok(C, bf)
     himg, t["tail_img"] = ops.block_rr_pack(C, t["cpe_lin_w"], t["qkv_w"], t["proj_w"], t["fc1_w"], t["fc2_w"])
     if ops.block_rr_head_on(C):
         t["head_img"] = himg
-    desc = ops.make_block_desc(bf, C, H, 4 * C, 16 ** -0.5, 1e-5, t)
+    desc = ops.make_block_desc(bf, C, H, 4 * C, 16 ** -0.5, 1e-5, t, attn_flags=ops.ATTN_Q_PRESCALED if fold else 0)
     gidx = dev(order.astype(np.int32))
     wi = np.full(len(order), -1, dtype=np.int32)
     wi[inverse] = np.arange(n, dtype=np.int32)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Deep-stage Block head / tail (csrc/deep.hip, C = 128 / 256) against the separate GEMM launches they replace, on
+"""Deep-stage Block head / tail (csrc/deep.hip, C = 128 / 256 / 512) against the separate GEMM launches they replace, on
 stage-shaped problems.  usage: python tools/bench_deep.py [scenes=8] [f16|bf16]"""
 import os, sys
 import torch
@@ -12,7 +12,7 @@ variant = sys.argv[2] if len(sys.argv) > 2 else "f16"
 _lib.activate(variant)
 dev = torch.device("cuda")
 bf = torch.float16 if variant == "f16" else torch.bfloat16
-for n, C in ((14293 * scenes, 128), (3364 * scenes, 256), (778 * scenes, 128)):
+for n, C in ((14293 * scenes, 128), (3364 * scenes, 256), (778 * scenes, 128), (778 * scenes, 512), (778, 512)):
     r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
     y, o = r(n, C).to(bf), r(n, C).to(bf)
     wl, wq, wp = (r(C, C) / C ** 0.5).to(bf), (r(3 * C, C) / C ** 0.5).to(bf), (r(C, C) / C ** 0.5).to(bf)

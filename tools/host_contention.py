@@ -3,7 +3,8 @@
 N processes - one per would-be GPU rank - each build the full-width model and issue collated forwards concurrently, all on
 the ONE GPU of the box (they time-share it: wall time per forward is meaningless here and not the point).  What an 8-GPU
 node shares between its ranks is the host: this measures the CPU time of the issuing Python thread per forward
-(time.thread_time: scheduler-independent) and its wall time from call to return with the GPU queue never empty, alone
+(time.thread_time: scheduler-independent; host reads block instead of spinning - hipDeviceScheduleBlockingSync - so the
+time the thread sleeps waiting for the time-shared GPU is not counted) and its wall time from call to return, alone
 (N = 1) and contended (N ranks), plus the node's core count.  There is no collective in the step, so nothing else couples
 the ranks."""
 import json
@@ -19,7 +20,14 @@ sys.path.insert(0, ROOT)
 
 
 def worker(rank, world, points, spf, forwards, barrier, q):
+    import ctypes
     import numpy as np
+    # host reads BLOCK instead of spinning (hipDeviceScheduleBlockingSync, set before the first HIP call of the process):
+    # with the default policy the thread burns CPU inside the forward's two device->host reads for as long as the
+    # (time-shared) GPU makes it wait, and thread_time would measure the GPU's queue, not the host's work
+    hip = ctypes.CDLL("libamdhip64.so")
+    rc = hip.hipSetDeviceFlags(ctypes.c_uint(0x4))
+    assert rc == 0, f"hipSetDeviceFlags failed: {rc}"
     from cdsegnet_amd import configs, synth
     from cdsegnet_amd.models import collate_device
     from cdsegnet_amd.param_init import fill_state_dict

@@ -13,6 +13,7 @@ python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections  # noqa: E401
 out = sys.argv[1]
 tot = {}
+by_grid = {}  # attention launches by grid size (= by stage shape): counter -> grid -> [sum, launches]
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     acc, cnt = collections.Counter(), collections.Counter()
     for f in glob.glob(f"/tmp/pmcb_{ctr}/**/*counter_collection.csv", recursive=True):
@@ -21,6 +22,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].strip()
             acc[k] += float(r["Counter_Value"]); cnt[k] += 1
+            if k.startswith("attn_bf16_kernel") and "Grid_Size" in r:
+                e = by_grid.setdefault(ctr, {}).setdefault(int(r["Grid_Size"]), [0.0, 0])
+                e[0] += float(r["Counter_Value"]); e[1] += 1
     tot[ctr] = (acc, cnt)
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0` "
                  "(3 forwards of 8 collated scenes); KB = 1024 B; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM)",
@@ -35,7 +39,14 @@ a = [v for k, v in res["kernels"].items() if k.startswith("attn_bf16_kernel")]
 if a:
     res["kernel"] = "attn_bf16_kernel"
     res.update({k: a[0][k] for k in a[0]})
+res["attention_by_grid"] = {
+    str(g): {"launches": by_grid["FETCH_SIZE"][g][1],
+             "read_MB_per_launch": 2 * by_grid["FETCH_SIZE"][g][0] / by_grid["FETCH_SIZE"][g][1] * 1024 / 1e6,
+             "write_MB_per_launch": by_grid.get("WRITE_SIZE", {}).get(g, [0.0, 1])[0] / max(1, by_grid.get("WRITE_SIZE", {}).get(g, [0.0, 1])[1]) * 1024 / 1e6}
+    for g in sorted(by_grid.get("FETCH_SIZE", {}))}
 json.dump(res, open(out, "w"), indent=1)
+for g, v in res["attention_by_grid"].items():
+    print(f"attention grid {g:>9s} threads: launches {v['launches']:3d}  read {v['read_MB_per_launch']:8.2f} MB  write {v['write_MB_per_launch']:8.2f} MB per launch")
 big = sorted(res["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
 for k, v in big:
     print(f"{k[:60]:60s} launches {v['launches']:5d}  MB/launch {v['hbm_bytes_per_launch'] / 1e6:9.2f}")
