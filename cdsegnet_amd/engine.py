@@ -206,6 +206,8 @@ class Engine:
         # half build's conversions (a checkpoint whose activations leave half's range is then noticed, not silently clamped).
         # Off in the timed path (a few extra launches per Block and one host read per forward); smoke and bench run one
         # forward with it.  Result of the last forward: saturation_count / saturation_checked (elements looked at)
+        self.speculate_depth = True  # serialization depth from the previous plan, verified behind the pooled-size read
+        self._depth_hint = {}
         self.count_saturation = False
         self.saturation_count = None
         self.saturation_checked = 0
@@ -489,10 +491,26 @@ class Engine:
         return out, done
 
     # ------------------------------------------------------------------ plan
-    def build_plan(self, grid, offset_dev, offset_host, n):
+    def build_plan(self, grid, offset_dev, offset_host, n, _exact_depth=None):
+        """Serialization, pooled levels, kernel-map sources, padding / slot plans of one forward.
+        Host reads: ONE in steady state (round 5) - the pooled sizes.  The serialization depth (`int(grid_coord.max())
+        .bit_length()`, structure.py:66: the reference's first host sync) is taken from the previous call's plan, the grid
+        maximum of THIS call travels to the host behind the pooled-size read, and a mismatch (a scene on a coarser / finer
+        grid than the last one) rebuilds the plan with the right depth - results never depend on the guess."""
         bb = self.model.backbone
         nb = len(offset_host)
-        depth = int(ops.grid_max(grid).item()).bit_length()
+        gmax_dev = ops.grid_max(grid)
+        hint = self._depth_hint.get(grid.device) if _exact_depth is None else None
+        gmax_host = None
+        if _exact_depth is not None:
+            depth = _exact_depth
+        elif hint is not None and grid.is_cuda and self.speculate_depth:
+            depth = hint
+            gmax_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            gmax_host.copy_(gmax_dev, non_blocking=True)  # complete once the pooled-size read below has returned
+        else:
+            depth = int(gmax_dev.item()).bit_length()
+            self._depth_hint[grid.device] = depth
         # same guards as the reference (structure.py:69,74)
         assert depth * 3 + nb.bit_length() <= 63, "serialization code does not fit int64"
         assert depth <= 16, "grid extent exceeds 2^16 voxels per axis"
@@ -527,6 +545,12 @@ class Engine:
             cl_all, seg_all, meta = ops.pool_levels(zs, [3 * cum for cum in coarse], last_idx)
             tmp = [(cl_all[i], seg_all[i]) for i in range(len(coarse))]
             flat = meta.cpu().tolist()  # the one sync for all pooled sizes (+ the duplicate-voxel count)
+            if gmax_host is not None:
+                true_depth = int(gmax_host.item()).bit_length()
+                self._depth_hint[grid.device] = true_depth
+                if true_depth != depth:  # the guess was wrong: everything built so far used the wrong code width
+                    return self.build_plan(grid, offset_dev, offset_host, n, _exact_depth=true_depth)
+                gmax_host = None
             if flat[-1]:
                 # the model's input contract (GridSample upstream, structure.py:39-102 downstream): one point per voxel.
                 # The kernel maps and the derived coarse orders assume it - refuse instead of computing something else
@@ -558,6 +582,11 @@ class Engine:
                 for i, cum in enumerate(coarse):
                     for k, c in enumerate(used):
                         plan.levels[cum]._order[c] = (derived[i][k], ops.current_stream_id(), None)
+        if gmax_host is not None:  # no pooled level, so no read has happened yet: verify the guessed depth now
+            true_depth = int(gmax_dev.item()).bit_length()
+            self._depth_hint[grid.device] = true_depth
+            if true_depth != depth:
+                return self.build_plan(grid, offset_dev, offset_host, n, _exact_depth=true_depth)
         # every padding plan the model will ask for, uploaded with ONE host->device copy
         if self._pad_keys is None:  # static per model: walk the module tree once
             self._pad_keys = sorted({(int(m_.patch_size), bool(m_.enable_flash)) for m_ in bb.modules()

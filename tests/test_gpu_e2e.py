@@ -835,3 +835,29 @@ def test_deep_conv_256_tile_on_a_real_kernel_map_vs_oracle(precision):
         assert err < 8e-3 and agree > 0.998
     else:
         assert err < 0.08 and agree > 0.98
+
+
+def test_speculated_serialization_depth_is_verified():
+    """Round 5: the serialization depth of a forward (structure.py:66: int(grid_coord.max()).bit_length(), the reference's
+    first host sync) is guessed from the previous call's plan and checked behind the pooled-size read.  Scenes of different
+    depth back to back through ONE model - a wrong guess rebuilds the plan - must give bit for bit what a model that never
+    guesses gives."""
+    fx = load_fixture("mini_e2e_room.npz")
+    cfg, sd = fixture_cfg(fx), dict(fixture_state_dict(fx))
+    base, draws = fixture_input(fx), fixture_draws(fx)
+    scenes = []
+    for scale in (1, 4, 1, 2, 2, 1):  # grid extents x1 / x4 / x2: depths differ by up to two bits, in both directions
+        inp = {k: np.array(v, copy=True) for k, v in base.items()}
+        inp["grid_coord"] = inp["grid_coord"] * scale
+        scenes.append(inp)
+    spec = build(cfg, sd, "fp32", enable_flash=False)
+    plain = build(cfg, sd, "fp32", enable_flash=False)
+    plain.engine().speculate_depth = False
+    depths = []
+    for inp in scenes:
+        a = run(spec, inp, draws)
+        depths.append(spec.engine().last_plan.depth)
+        b = run(plain, inp, draws)
+        assert plain.engine().last_plan.depth == depths[-1]
+        assert np.array_equal(a, b)
+    assert len(set(depths)) == 3, depths
