@@ -506,7 +506,9 @@ class Engine:
             depth = _exact_depth
         elif hint is not None and grid.is_cuda and self.speculate_depth:
             depth = hint
-            gmax_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            gmax_host = getattr(self._tls, "gmax_pin", None)  # one pinned word per issuing host thread (build_plan does not
+            if gmax_host is None:                               # return before it has read it)
+                gmax_host = self._tls.gmax_pin = torch.empty(1, dtype=torch.int64, pin_memory=True)
             gmax_host.copy_(gmax_dev, non_blocking=True)  # complete once the pooled-size read below has returned
         else:
             depth = int(gmax_dev.item()).bit_length()
