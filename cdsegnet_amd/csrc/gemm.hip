@@ -32,6 +32,11 @@
 #include "common.h"
 #include "prof.h"
 
+// smallest row count at which a C = 128 sparse conv takes the 8-wave 256 x 128 tile (0 = never; tools/bench_conv.py A/B)
+#ifndef CDSEG_CONV_SQ128_MIN_M
+#define CDSEG_CONV_SQ128_MIN_M 0
+#endif
+
 namespace {
 
 struct GemmP {
@@ -1171,12 +1176,21 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   }
   // deep sparse convs (C >= 256) at 8+ scenes: 256 x 256 tiles, 8 waves as 4 x 2, split-K (gemm_dma_kernel<256, true, 256, 2, true>)
   bool sq = false;
+  int sq_bn = 256;
   if constexpr (GATHER && NCH == 16 && sizeof(CT) == 2) {
     static const int sq_on = cdseg_knob("CDSEG_CONV_SQ", 1);
     static const int sq_min_m = cdseg_knob("CDSEG_CONV_SQ_MIN_M", 5000);
     static const int sq_min_n = cdseg_knob("CDSEG_CONV_SQ_MIN_N", 256);
     sq = sq_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= sq_min_n && (p.N % 256) == 0 && !ln && p.kshift >= 6 &&
          p.M >= sq_min_m && p.ws && p.vec_ok && !p.out_idx;
+    // C = 128 (round 5): the same 8-wave loop on a 256 x 128 tile (a wave owns 64 x 64: acc[4][4]) - 6 DMA pieces per 32
+    // MFMAs instead of the 128 x 128 tile's 4 per 16; needs enough rows for a round of 256-row tiles without split-K
+    static const int sq128_min_m = cdseg_knob("CDSEG_CONV_SQ128_MIN_M", CDSEG_CONV_SQ128_MIN_M);
+    if (!sq && sq_on && sq128_min_m > 0 && dma_use_bm == 128 && p.kvol == 27 && p.N == 128 && !ln && p.kshift >= 6 &&
+        p.M >= sq128_min_m && p.vec_ok && !p.out_idx) {
+      sq = true;
+      sq_bn = 128;
+    }
     if (sq) {
       bm = 256;
       p.alt = cdseg_knob("CDSEG_CONV_SQ_ALT", 1);
@@ -1190,7 +1204,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     wide = !sq && wide_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= 256 && (p.N % 256) == 0 && !ln;
   }
   // wide tiles (better FLOP/byte against L2); few-tile problems get their parallelism from split-K instead
-  const int bn = (wide || sq) ? 256 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
+  const int bn = wide ? 256 : (sq ? sq_bn : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128)));
   const int gn = (p.N + bn - 1) / bn;
   // split-K when the output tiles alone cannot fill the chip (deep stages: few points, long reductions)
   int splits = 1;
@@ -1244,7 +1258,19 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     static const int dma_bm = cdseg_knob("CDSEG_GEMM_DMA_BM", 0);
     const bool fused_ln_here = ln && gn == 1 && splits == 1;  // complete rows in one 64-row block: stays on the old loop
     if constexpr (GATHER) {
-      if (sq && dma_on) {
+      if (sq && dma_on && sq_bn == 128) {
+        launched = true;
+        using Q = DmaCfg<256, true, 128, 2, true>;
+        static std::atomic<bool> aq128{false};
+        if (!aq128) {
+          if (hipFuncSetAttribute((const void*)gemm_dma_kernel<256, true, 128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Q::LDS) != hipSuccess)
+            return CDSEG_ERR_LAUNCH;
+          aq128 = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<256, true, 128, 2, true>), grid, dim3(Q::NT), Q::LDS, s, p);
+      }
+      if (!launched && sq && dma_on) {
         launched = true;
         using Q = DmaCfg<256, true, 256, 2, true>;
         static bool aq = false;

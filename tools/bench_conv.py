@@ -15,6 +15,7 @@ level = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda")
+torch.manual_seed(0)
 sc = synth.collate([synth.room_scene(i, 120000) for i in range(scenes)])
 grid = torch.as_tensor(sc["grid_coord"]).to(dev).int().contiguous()
 offs = np.concatenate([[0], sc["offset"]])
@@ -50,6 +51,16 @@ if ops.subm_conv3_ok(x) and os.environ.get("CDSEG_BENCH_OLD_ONLY") is None:
           f"{comp / us2:.2f} TB/s)" +
           ("" if us is None else f", max |new - gathered GEMM| = {(o2.float() - o.float()).abs().max().item():.3e}"))
 if us is not None:  # (PMC passes run only the kernel under study: no gathered-GEMM line, no comparison against it)
+    # spot check against a plain fp32 gather + matmul on 4096 sampled rows (same 16-bit operands)
+    rows = torch.randperm(n, device=dev)[:4096]
+    ref = b.repeat(len(rows), 1)
+    wf = w.float().view(c, 27, c)
+    for k in range(27):
+        idx = nbr[k][rows].long()
+        ref += torch.where((idx >= 0)[:, None], x.float()[idx.clamp(min=0)], torch.zeros(1, device=dev)) @ wf[:, k].t()
+    err = (o[rows].float() - ref).abs().max().item()
+    print(f"   spot check vs fp32 gather + matmul on 4096 rows: max |diff| {err:.3e} (outputs of magnitude {ref.abs().max().item():.2f}), "
+          f"checksum {o.float().abs().sum().item():.6e}")
     print(f"conv level {level}: n={n} C={c} occupied neighbours/point={occ:.2f}: {us:.1f} us/launch, "
           f"{2.0 * n * occ * c * c / us / 1e6:.1f} TFLOP/s (occupied), gathered bytes {n * occ * c * 2 / 1e6:.1f} MB, "
           f"index bytes {n * 27 * 4 / 1e6:.1f} MB")
