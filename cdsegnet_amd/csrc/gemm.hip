@@ -32,9 +32,14 @@
 #include "common.h"
 #include "prof.h"
 
-// smallest row count at which a C = 128 sparse conv takes the 8-wave 256 x 128 tile (0 = never; tools/bench_conv.py A/B)
+// row-count window in which a C = 128 sparse conv takes the 8-wave 256 x 128 tile (MIN 0 = never).  Measured
+// (tools/bench_conv.py 2 <scenes>, profiles/r05_conv128.txt): 14 k rows (one scene) 42.2 -> 37.2 us, but 114 k rows (8 scenes)
+// 118 -> 141 us and 342 k rows 315 -> 365 us - with enough 128 x 128 tiles to give every CU two blocks the smaller tile wins
 #ifndef CDSEG_CONV_SQ128_MIN_M
-#define CDSEG_CONV_SQ128_MIN_M 0
+#define CDSEG_CONV_SQ128_MIN_M 8000
+#endif
+#ifndef CDSEG_CONV_SQ128_MAX_M
+#define CDSEG_CONV_SQ128_MAX_M 32768
 #endif
 
 namespace {
@@ -1184,10 +1189,11 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     sq = sq_on && dma_use_bm == 128 && p.kvol == 27 && p.N >= sq_min_n && (p.N % 256) == 0 && !ln && p.kshift >= 6 &&
          p.M >= sq_min_m && p.ws && p.vec_ok && !p.out_idx;
     // C = 128 (round 5): the same 8-wave loop on a 256 x 128 tile (a wave owns 64 x 64: acc[4][4]) - 6 DMA pieces per 32
-    // MFMAs instead of the 128 x 128 tile's 4 per 16; needs enough rows for a round of 256-row tiles without split-K
+    // MFMAs instead of the 128 x 128 tile's 4 per 16.  Pays on single scenes only (see CDSEG_CONV_SQ128_MIN_M above)
     static const int sq128_min_m = cdseg_knob("CDSEG_CONV_SQ128_MIN_M", CDSEG_CONV_SQ128_MIN_M);
+    static const int sq128_max_m = cdseg_knob("CDSEG_CONV_SQ128_MAX_M", CDSEG_CONV_SQ128_MAX_M);
     if (!sq && sq_on && sq128_min_m > 0 && dma_use_bm == 128 && p.kvol == 27 && p.N == 128 && !ln && p.kshift >= 6 &&
-        p.M >= sq128_min_m && p.vec_ok && !p.out_idx) {
+        p.M >= sq128_min_m && p.M < sq128_max_m && p.vec_ok && !p.out_idx) {
       sq = true;
       sq_bn = 128;
     }

@@ -1311,7 +1311,8 @@ def test_deep_head_and_tail_vs_oracle_and_unfused_sequence(ops, lp, M, C, tb):
 
 @LPS
 @pytest.mark.parametrize("n,C", [(5000, 256), (2100, 512), (130, 256), (40000, 128), (30000, 256), (6100, 512),
-                                 (66000, 256)])  # 258 row tiles of 256: no split-K, the tile's own 16-bit epilogue
+                                 (66000, 256),   # 258 row tiles of 256: no split-K, the tile's own 16-bit epilogue
+                                 (12000, 128), (8001, 128)])  # C = 128 on the 8-wave 256 x 128 tile (8000 <= rows < 32768)
 def test_deep_conv_group_skipping_random_map(ops, lp, n, C):
     """The deep-stage gathered conv (gemm.hip: 16-row groups without a neighbour at an offset are neither fetched nor
     multiplied; C >= 256 at >= 5000 rows: 256 x 256 tiles on 8 waves with split-K over the live offsets - the (5000, 256),
