@@ -150,8 +150,22 @@ constexpr int SMEM_F32 = KS_BYTES_F32 + 16 * VT_STRIDE_F32;
 #ifndef ATTN_ZONE_MIN_UNITS
 #define ATTN_ZONE_MIN_UNITS 96
 #endif
-constexpr int ATTN_THREADS = 512;  // 8 waves: 2 per SIMD per block, 2 blocks per CU (LDS 66 KB each)
+constexpr int ATTN_THREADS = 512;  // fp32 kernel: 8 waves, one block per CU (LDS 130 KB)
 constexpr int ATTN_WAVES = ATTN_THREADS / 64;
+constexpr int ATTN_RUN = 8;        // query tiles per run: the unit slices of a patch-head are dealt in, and the number of
+                                   // waves that get a pre-assigned first tile
+// 16-bit kernel: waves per block (2 blocks per CU, LDS 66 KB each) and score tiles in flight per wave.  8 x 2: four waves
+// per SIMD, 116 VGPRs.  10 x 1 (round 5): five waves per SIMD on 96 VGPRs - when one wave of a SIMD stages, normalises or
+// claims, four are still in their key loops, and one tile in flight per wave is all the instruction mix needs from four
+// waves up (tools/ubench/pipes.hip: 128 cycles per tile and SIMD with the real dependences at W = 4)
+#ifndef ATTN_BF16_WAVES
+#define ATTN_BF16_WAVES 8
+#endif
+#ifndef ATTN_TILES_IN_FLIGHT
+#define ATTN_TILES_IN_FLIGHT 2
+#endif
+constexpr int BF_WAVES = ATTN_BF16_WAVES, BF_THREADS = 64 * BF_WAVES;
+static_assert(BF_WAVES >= ATTN_RUN && BF_WAVES <= 12, "the first run of a block's tiles is pre-assigned to waves 0 .. 7");
 constexpr int KV_STAGE = 1024 * 32;  // K (or V) of one patch-head
 constexpr int ONES_BYTES = 2048;     // 8-byte words {1.0bf16, 0, 0, 0}: covers every immediate offset of a tile pair
 constexpr int SMEM_BF16 = 2 * KV_STAGE + ONES_BYTES + 64 + 4096;  // + slot -> query row table
@@ -220,11 +234,11 @@ __device__ __forceinline__ float sq8_bf16(const uint4& a) {
   return dot2_bf16(a.w, a.w, t);
 }
 
-__global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
+__global__ __launch_bounds__(BF_THREADS, (2 * BF_WAVES) / 4) void attn_bf16_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   float* s_kn2 = reinterpret_cast<float*>(smem + 2 * KV_STAGE + ONES_BYTES);  // per-wave max |k|^2
-  unsigned* s_next = reinterpret_cast<unsigned*>(smem + 2 * KV_STAGE + ONES_BYTES + 32);  // query tiles handed out so far
+  unsigned* s_next = reinterpret_cast<unsigned*>(smem + 2 * KV_STAGE + ONES_BYTES + 48);  // query tiles handed out so far
   int* s_qidx = reinterpret_cast<int*>(smem + 2 * KV_STAGE + ONES_BYTES + 64);           // slot -> query row
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
       }
       // a slice takes every qsplit-th run of 8 query tiles; the tiles of its first run are pre-assigned (run base + wave,
       // below: the counter starts at 8)
-      const int base = (qslice + (int)(i >> 3) * qsplit) * ATTN_WAVES;
+      const int base = (qslice + (int)(i >> 3) * qsplit) * ATTN_RUN;
       if (base >= nqt) return -1;
       const int t = base + (int)(i & 7);
       if (t < nqt) return t;
@@ -285,18 +299,20 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     int gk[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int s = (wave + ATTN_WAVES * i) * 32 + kip;
+      const int s = (wave + BF_WAVES * i) * 32 + kip;
       gk[i] = s < L ? p.kv_gidx[ps + s] : -1;
     }
     // slot -> query row table (this wave's 128 slots), for the query-row fetches of the tile loop
-    int gq[2];
+    int gq[2] = {0, 0};
+    if (wave < ATTN_RUN) {  // (1024 slots: 128 per wave of the first eight)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) gq[i] = p.q_gidx[ps + min(wave * 128 + i * 64 + lane, L - 1)];
+      for (int i = 0; i < 2; ++i) gq[i] = p.q_gidx[ps + min(wave * 128 + i * 64 + lane, L - 1)];
+    }
     // the wave's FIRST query tile is fixed: tile 4 w of an unsliced patch-head (its rows are the first 32 of the indices
     // just loaded), tile `first run of the slice` + w of a slice (its row indices are fetched here, with the others)
-    const int qt_slice0 = qslice * ATTN_WAVES + wave;
+    const int qt_slice0 = qslice * ATTN_RUN + wave;
     int gfirst = 0;
-    if (ATTN_FIRST_STATIC && qsplit > 1) gfirst = p.q_gidx[ps + min(qt_slice0 * 32 + ql, L - 1)];
+    if (ATTN_FIRST_STATIC && qsplit > 1 && wave < ATTN_RUN) gfirst = p.q_gidx[ps + min(qt_slice0 * 32 + ql, L - 1)];
     if (tid == 0) *s_next = (ATTN_FIRST_STATIC && qsplit > 1) ? 8u : 0u;
     // (the compiler waits for its own loads above; the DMAs are invisible to it and are waited for by hand below)
     // all source addresses first (pinned by the empty asm): the compiler's vmcnt(0) for an index load must not sit
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     const void* vsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int s = (wave + ATTN_WAVES * i) * 32 + kip;
+      const int s = (wave + BF_WAVES * i) * 32 + kip;
       ksrc[i] = vsrc[i] = (const char*)g_attn_zero + hs * 16;
       if (gk[i] >= 0) {
         ksrc[i] = kb + (long)gk[i] * p.ldk + ((hs ^ ((s >> 3) & 1)) << 3);
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int pc = wave + ATTN_WAVES * i;
+      const int pc = wave + BF_WAVES * i;
       if (pc < nkt) {
         dma16(ksrc[i], lds_base + pc * 1024);
         dma16(vsrc[i], lds_base + KV_STAGE + pc * 1024);
@@ -329,13 +345,15 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
       qt_first = 4 * wave;
       const int g = __shfl(gq[0], lane & 31, 64);
       q_first = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + (long)g * p.ldq + head * 16 + h * 8);
-    } else if (ATTN_FIRST_STATIC && qsplit > 1 && qt_slice0 < nqt) {
+    } else if (ATTN_FIRST_STATIC && qsplit > 1 && wave < ATTN_RUN && qt_slice0 < nqt) {
       qt_first = qt_slice0;
       q_first = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + (long)gfirst * p.ldq + head * 16 + h * 8);
     }
+    if (wave < ATTN_RUN) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) s_qidx[wave * 128 + i * 64 + lane] = gq[i];
-    for (int w = tid; w < ONES_BYTES / 8; w += ATTN_THREADS)
+      for (int i = 0; i < 2; ++i) s_qidx[wave * 128 + i * 64 + lane] = gq[i];
+    }
+    for (int w = tid; w < ONES_BYTES / 8; w += BF_THREADS)
       *reinterpret_cast<uint2*>(smem + 2 * KV_STAGE + w * 8) = make_uint2(0x3F80u, 0u);
     // largest squared key norm of the patch-head (for the score bound of the single-pass softmax below), from the
     // wave's own pieces: its own vmcnt(0) is all the ordering they need
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
     float kn2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int pc = wave + ATTN_WAVES * i;
+      const int pc = wave + BF_WAVES * i;
       if (pc < nkt) {
         if (LP_IS_F16 && !(p.flags & CDSEG_ATTN_V_BF16)) {
           // half build, V in half (a producer that writes V as bfloat16 sets CDSEG_ATTN_V_BF16 and this pass is skipped): Q and K stay half (the scores keep 11-bit operands), the P V product runs in bfloat16 - P =
@@ -373,6 +391,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
   {
     const float4 a = *reinterpret_cast<const float4*>(s_kn2), b = *reinterpret_cast<const float4*>(s_kn2 + 4);
     kmax2 = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+#pragma unroll
+    for (int w8 = 8; w8 < BF_WAVES; ++w8) kmax2 = fmaxf(kmax2, s_kn2[w8]);
   }
 
   // lane constants of the key loop
@@ -431,7 +451,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void attn_bf16_kernel(AttnP p) {
       const char* kp = k_lane;
       unsigned va = va0;
       int kt = 0;
-      for (; kt + 1 < nfull; kt += 2) {  // two independent tiles in flight
+      for (; ATTN_TILES_IN_FLIGHT == 2 && kt + 1 < nfull; kt += 2) {  // two independent tiles in flight
         const f32x16_t sa = qk_tile(kp, qf, negm);
         const f32x16_t sb = qk_tile(kp + 1024, qf, negm);
         pv_tile<false>(sa, kt, h, L, va, acc);
@@ -696,7 +716,7 @@ static unsigned make_schedule(AttnP& p, int num_patches, int num_heads, int max_
   // slices; 112 and fewer want 2 - 4 slices)
   int qsplit = ph >= 192 ? 1 : (ph >= 96 ? 2 : 4);
   qsplit = cdseg_knob("CDSEG_ATTN_QSPLIT", qsplit);  // (power of two)
-  const int max_split = (nqt + ATTN_WAVES - 1) / ATTN_WAVES;
+  const int max_split = (nqt + ATTN_RUN - 1) / ATTN_RUN;
   while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
   p.num_patches = num_patches;
   for (int z = 0; z < ATTN_ZONES; ++z) p.zcnt[z] = p.zsplit[z] = 0;
@@ -730,7 +750,7 @@ extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, i
   p.flags = flags;
   hipStream_t s = (hipStream_t)stream;
   const unsigned nblocks = make_schedule(p, num_patches, num_heads, max_len, dtype);
-  dim3 grid(nblocks), block(ATTN_THREADS);
+  dim3 grid(nblocks), block(dtype == CDSEG_BF16 ? BF_THREADS : ATTN_THREADS);
   static std::once_flag attr_once;
   static bool attr_ok = false;
   std::call_once(attr_once, [] {
