@@ -93,10 +93,10 @@ def test_mini_bf16_close_to_reference_golden(name, precision):
         assert agree > 0.985
     else:
         # IEEE half trunk (11-bit mantissa, the reference's own attention dtype): 8x less rounding per operand.
-        # Measured (profiles/r04_parity_measured.txt): 1.6e-3 .. 2.0e-3 / 99.69 .. 100 % (the 2600-point fixtures have 8 points
+        # Measured (profiles/r05_parity_measured.txt): 1.4e-3 .. 2.0e-3 / 99.69 .. 100 % (the 2600-point fixtures have 8 points
         # whose two best reference logits are closer than the error: arg-max agreement moves in steps of 0.04 %)
-        assert err < 4e-3
-        assert agree > 0.995  # (measured minimum 99.69 % = 8 of 2600 points; one point = 0.04 %)
+        assert err < 3e-3
+        assert agree > 0.9965  # (measured minimum 99.69 % = 8 of 2600 points; the bound allows ONE more point to flip)
 
 
 def test_seeded_default_draws_replay_the_reference():
