@@ -33,6 +33,9 @@
 // the same with progress-ranked s_setprio (in step, but 216 instead of ~140 cycles per tile and SIMD), and a
 // barrier-free dataflow form (tasks claimed by LDS compare-and-swap, stage recycled by the last finisher: 261 us
 // against 233 us for this form at 960k points x 2 heads).
+// Round 5: the producer-side flags of cdseg_attention_ex (q pre-scaled by folded weights, v written as bfloat16 by the fused
+// qkv epilogues), one 16-byte output store per lane, the graded launch schedule (decode_block / plan_zones below), and the
+// block shapes that lost to this one (10 / 12 waves, one score tile in flight: profiles/r05_attention_waves.txt).
 #include <cstdlib>
 #include <mutex>
 

@@ -1,5 +1,6 @@
 """Micro-benchmark of the serialized-attention kernel alone on a stage-shaped problem.
-usage: python tools/bench_attention.py [n_points] [heads] [dtype] [iters] [curve] [scenes]
+usage: python tools/bench_attention.py [n_points] [heads] [dtype] [iters] [curve] [scenes] [flags]
+  flags: cdseg_attention_ex flags (1: q pre-scaled, 2: v bfloat16 - what the engine's fused qkv producers declare)
   CDSEG_AB_LIB=path/to/other/libcdseg_hip.so  benchmark another build of the library (A/B runs; tools only)
   curve: 0 z, 1 z-trans, 2 hilbert (default), 3 hilbert-trans - the curve the patches are cut from
 Prints min / median over `rounds` timed groups (the chip re-clocks between launches: quote the median)."""
@@ -21,6 +22,7 @@ C = 16 * H
 dev = torch.device("cuda")
 # realistic gather pattern: physical z order, attention along another curve
 scenes = int(sys.argv[6]) if len(sys.argv) > 6 else 1  # > 1: that many collated scenes of n / scenes points
+flags = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 grids, batches = [], []
 for i in range(scenes):
     sc = synth.room_scene(i, n // scenes)
@@ -51,7 +53,7 @@ P = ps.numel() - 1
 lens = (ps[1:] - ps[:-1]).double()
 flops = 64.0 * H * float((lens * lens).sum())
 def run():
-    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], gidx, gidx, widx, ps, H, K, 0.25, out)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], gidx, gidx, widx, ps, H, K, 0.25, out, flags=flags)
 for _ in range(5): run()
 torch.cuda.synchronize()
 rounds = 7

@@ -50,3 +50,10 @@ other --precision fp32 --scenes-per-forward 4
 other --protocol paper
 other --dataset nuscenes --points 40000 --shard 64
 cat gpurun_out/r05g_other_configs.txt
+# attention counters (separate --pmc passes) with and without the producer-side preprocessing flag, and the CPU baseline's
+# thread sweep at the baseline's own scene size
+bash tools/pmc_r02.sh r05_attn attn_bf16 python tools/bench_attention.py 960000 2 bf16 10 2 1 1 > /dev/null 2>&1
+bash tools/pmc_r02.sh r05_attn_noflags attn_bf16 python tools/bench_attention.py 960000 2 bf16 10 2 1 0 > /dev/null 2>&1
+cat gpurun_out/pmc_r05_attn.txt | head -30
+( timeout 400 python tools/cpu_sweep.py 120000 8 16 32 ) > gpurun_out/r05g_cpu_sweep.txt 2>&1
+cat gpurun_out/r05g_cpu_sweep.txt
