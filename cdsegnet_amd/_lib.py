@@ -108,6 +108,8 @@ SIGNATURES = {
     "cdseg_fragment_select": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "cdseg_softmax_vote": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
     "cdseg_argmax_rows": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
+    "cdseg_knn": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, POINTER(c_float), c_float,
+                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cdseg_knn1_ws_bytes": (c_size_t, [c_long]),
     "cdseg_knn1": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, POINTER(c_float), c_float,
                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -303,6 +303,85 @@ __global__ void knn1_kernel(KnnP p, int max_shell, int32_t* __restrict__ idx_out
   if (d2_out) d2_out[q] = best;
 }
 
+// ---- k nearest neighbours, k <= CDSEG_KNN_MAX_K (round 5)
+// ref: libs/pointops/functions/query.py:7-24 (KNNQuery: idx (m, nsample) int32, -1 = placeholder; distances = sqrt(dist2)),
+//      libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104 - one thread per query, a brute-force scan of the batch
+//      element's reference points into a max-heap of nsample entries (strict '<': among equal distances the lower index
+//      stays), heap-sorted to ascending distance at the end.
+// Same uniform grid and shell walk as knn1_kernel; the candidate list is kept sorted by (distance, index) - insertion into
+// at most k entries of private memory - and the walk stops once the k-th best is closer than anything an unvisited cell can
+// hold.  Results equal the reference's as sets and in their distances; WITHIN a group of exactly equal distances the
+// reference's order is its heap's (not index order), this one's is ascending index.
+constexpr int KNN_MAX_K = 64;
+
+__device__ __forceinline__ void knnk_consider(const KnnP& p, int j, float qx, float qy, float qz, int k, int& cnt,
+                                              float* bd, int* bi) {
+  const float dx = qx - p.ref[3 * j], dy = qy - p.ref[3 * j + 1], dz = qz - p.ref[3 * j + 2];
+  const float d2 = dx * dx + dy * dy + dz * dz;
+  if (cnt == k && !(d2 < bd[k - 1] || (d2 == bd[k - 1] && j < bi[k - 1]))) return;
+  int pos = cnt < k ? cnt : k - 1;  // slot that opens up (the last one is dropped when the list is full)
+  while (pos > 0 && (bd[pos - 1] > d2 || (bd[pos - 1] == d2 && bi[pos - 1] > j))) {
+    bd[pos] = bd[pos - 1];
+    bi[pos] = bi[pos - 1];
+    --pos;
+  }
+  bd[pos] = d2;
+  bi[pos] = j;
+  if (cnt < k) ++cnt;
+}
+
+__global__ void knnk_kernel(KnnP p, int k, int max_shell, int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= p.m) return;
+  const int b = batch_of(p.qry_off, p.nb, q);
+  const int rs = b ? p.ref_off[b - 1] : 0, re = p.ref_off[b];
+  const float qx = p.qry[3 * q], qy = p.qry[3 * q + 1], qz = p.qry[3 * q + 2];
+  float bd[KNN_MAX_K];
+  int bi[KNN_MAX_K];
+  int cnt = 0;
+  const int avail = min(k, re - rs);  // a batch element with fewer than k points fills the rest with placeholders
+  if (avail > 0) {
+    const float fx = (qx - p.ox) / p.cell, fy = (qy - p.oy) / p.cell, fz = (qz - p.oz) / p.cell;
+    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    float edge = fminf(fminf(fx - cx, cx + 1 - fx), fminf(fminf(fy - cy, cy + 1 - fy), fminf(fz - cz, cz + 1 - fz)));
+    edge = fmaxf(edge, 0.f) * p.cell * 0.999f;
+    bool done = false;
+    for (int r = 0; r <= max_shell && !done; ++r) {
+      for (int dx = -r; dx <= r; ++dx) {
+        const int x = cx + dx;
+        if (x < 0 || x > p.gmax) continue;
+        for (int dy = -r; dy <= r; ++dy) {
+          const int y = cy + dy;
+          if (y < 0 || y > p.gmax) continue;
+          const bool face = dx == -r || dx == r || dy == -r || dy == r;
+          const int zstep = face ? 1 : (r == 0 ? 1 : 2 * r);
+          for (int dz = -r; dz <= r; dz += zstep) {
+            const int z = cz + dz;
+            if (z < 0 || z > p.gmax) continue;
+            const int64_t key = cell_key(b, x, y, z);
+            long lo = rs, hi = re;
+            while (lo < hi) {
+              const long mid = (lo + hi) >> 1;
+              if (p.key_sorted[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            for (; lo < re && p.key_sorted[lo] == key; ++lo) knnk_consider(p, p.perm[lo], qx, qy, qz, avail, cnt, bd, bi);
+          }
+        }
+      }
+      const float lb = r * p.cell * 0.99999f + edge;
+      done = cnt == avail && bd[avail - 1] < lb * lb;  // strict: an equal-distance, lower-index point may still be outside
+    }
+    if (!done) {  // sparse neighbourhood: the reference's brute-force scan
+      cnt = 0;
+      for (int j = rs; j < re; ++j) knnk_consider(p, j, qx, qy, qz, avail, cnt, bd, bi);
+    }
+  }
+  for (int i = 0; i < k; ++i) {
+    idx_out[q * k + i] = i < cnt ? bi[i] : -1;
+    if (d2_out) d2_out[q * k + i] = i < cnt ? bd[i] : 1e10f;  // the reference's initial heap entries
+  }
+}
+
 // per-class intersection / prediction / target counts; ignore_index rows are dropped.  ref: utils/misc.py:52-65
 // Counters are first accumulated per workgroup in LDS (3 k <= 768 bins: 32-bit LDS atomics), then added to the global
 // (3, k) table with ONE 64-bit atomic per non-empty bin and workgroup: with one global atomic per point the 137k points of
@@ -498,6 +577,37 @@ int cdseg_knn1(const float* ref_xyz, const int32_t* ref_offset, long n, const fl
   }
   p.key_sorted = key_sorted; p.perm = perm;
   hipLaunchKernelGGL(knn1_kernel, g1(m), dim3(256), 0, s, p, 6, idx, dist2);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// Exact k nearest reference points (same batch element) of every query, ascending by (squared distance, index):
+// idx (m, k) int32 with -1 placeholders, dist2 (m, k) float (SQUARED distances, 1e10 placeholders) or NULL.  k <= 64.
+// Workspace and the other arguments as cdseg_knn1.
+int cdseg_knn(const float* ref_xyz, const int32_t* ref_offset, long n, const float* qry_xyz, const int32_t* qry_offset,
+              long m, int nb, int k, const float* origin, float cell, int32_t* idx, float* dist2, void* ws, size_t ws_bytes,
+              void* stream) {
+  if (m <= 0) return CDSEG_OK;
+  if (k <= 0 || k > KNN_MAX_K) return CDSEG_ERR_UNSUPPORTED;
+  if (nb <= 0 || nb > 8 || !(cell > 0) || !origin || !idx) return CDSEG_ERR_ARG;
+  if (ws_bytes < cdseg_knn1_ws_bytes(n)) return CDSEG_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  KnnP p;
+  p.ref = ref_xyz; p.qry = qry_xyz; p.ref_off = ref_offset; p.qry_off = qry_offset;
+  p.ox = origin[0]; p.oy = origin[1]; p.oz = origin[2]; p.cell = cell; p.nb = nb; p.gmax = (1 << 20) - 1;
+  p.n = n; p.m = m;
+  char* w = (char*)ws;
+  const size_t a8 = (((size_t)n * 8) + 255) & ~(size_t)255, a4 = (((size_t)n * 4) + 255) & ~(size_t)255;
+  int64_t* key = (int64_t*)w;
+  int64_t* key_sorted = (int64_t*)(w + a8);
+  int32_t* perm = (int32_t*)(w + 2 * a8);
+  if (n > 0) {
+    hipLaunchKernelGGL(knn_cell_key_kernel, g1(n), dim3(256), 0, s, p, key);
+    const int rc = cdseg_sort_pairs(key, key_sorted, nullptr, perm, n, 63, w + 2 * a8 + a4, ws_bytes - 2 * a8 - a4, stream);
+    if (rc != CDSEG_OK) return rc;
+  }
+  p.key_sorted = key_sorted; p.perm = perm;
+  hipLaunchKernelGGL(knnk_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, p, k, 8, idx, dist2);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

@@ -968,6 +968,34 @@ def knn1(ref_xyz, ref_offset, qry_xyz, qry_offset, origin, cell, want_dist=False
     return (idx, d2) if want_dist else idx
 
 
+def knn(k, ref_xyz, ref_offset, qry_xyz=None, qry_offset=None, origin=None, cell=None):
+    """pointops.knn_query(k, xyz, offset, new_xyz, new_offset) (ref: libs/pointops/functions/query.py:7-24): the k nearest
+    reference points (same batch element) of every query -> (idx (m, k) int32 with -1 placeholders, dist (m, k) float32 =
+    EUCLIDEAN distances like the reference's wrapper, placeholders sqrt(1e10)).  Ascending by (distance, index).
+    origin / cell default to the reference points' minimum and a cell that holds ~2 points on average (one host read)."""
+    lib = _lib.load()
+    _need_gpu(ref_xyz)
+    if qry_xyz is None:
+        qry_xyz, qry_offset = ref_xyz, ref_offset
+    ref_xyz, qry_xyz = ref_xyz.float().contiguous(), qry_xyz.float().contiguous()
+    ref_offset, qry_offset = ref_offset.to(torch.int32).contiguous(), qry_offset.to(torch.int32).contiguous()
+    n, m = ref_xyz.shape[0], qry_xyz.shape[0]
+    if origin is None or cell is None:
+        lo, hi = ref_xyz.min(0).values, ref_xyz.max(0).values
+        ext = (hi - lo).clamp_min(1e-6).cpu().tolist()
+        origin = lo.cpu().tolist()
+        # surface-like clouds: cells of side s hold ~ n s^2 / area points; aim at ~2 per cell
+        area = max(ext[0] * ext[1], ext[0] * ext[2], ext[1] * ext[2])
+        cell = max((2.0 * area / max(n, 1)) ** 0.5, max(ext) / ((1 << 20) - 2))
+    idx = torch.empty((m, int(k)), dtype=torch.int32, device=qry_xyz.device)
+    d2 = torch.empty((m, int(k)), dtype=torch.float32, device=qry_xyz.device)
+    ws = workspace(lib.cdseg_knn1_ws_bytes(n), qry_xyz.device)
+    org = (ctypes.c_float * 3)(*[float(v) for v in origin])
+    check(lib.cdseg_knn(_ptr(ref_xyz), _ptr(ref_offset), n, _ptr(qry_xyz), _ptr(qry_offset), m, ref_offset.numel(), int(k), org,
+                        float(cell), _ptr(idx), _ptr(d2), _ptr(ws), ws.numel(), _stream()), "knn")
+    return idx, torch.sqrt(d2)
+
+
 def iou_counts(pred, target, num_classes, ignore_index=-1, pred_idx=None):
     """(3, K) int64: intersection, prediction and target counts (rows with target == ignore_index dropped)."""
     out = torch.empty((3, num_classes), dtype=torch.int64, device=pred.device)

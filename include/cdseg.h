@@ -324,6 +324,14 @@ int cdseg_argmax_rows(const float* x, int ldx, long n, int c, int32_t* out, void
  * reference's brute-force scan, libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104), found through a uniform
  * grid: origin (3 host floats) <= every reference coordinate, cell = grid cell size.  offsets: cumulative ends (nb).
  * idx (m) int32, dist2 (m) float or NULL. */
+/* k nearest neighbours (round 5; ref: libs/pointops/functions/query.py:7-24 KNNQuery, src/knn_query/knn_query_cuda_kernel.cu:
+ * 60-104 - the neighbourhood query of the reference's other backbones, off the CDSegNet path, SURVEY finding 2): idx (m, k)
+ * int32 ascending by (squared distance, index), -1 placeholders when the batch element has fewer than k points; dist2 (m, k)
+ * SQUARED distances (the reference's Python wrapper takes the square root), 1e10 placeholders, or NULL.  k <= 64
+ * (CDSEG_ERR_UNSUPPORTED beyond); workspace cdseg_knn1_ws_bytes(n); other arguments as cdseg_knn1. */
+int cdseg_knn(const float* ref_xyz, const int32_t* ref_offset, long n, const float* qry_xyz, const int32_t* qry_offset,
+              long m, int nb, int k, const float* origin, float cell, int32_t* idx, float* dist2, void* ws, size_t ws_bytes,
+              void* stream);
 size_t cdseg_knn1_ws_bytes(long n);
 int cdseg_knn1(const float* ref_xyz, const int32_t* ref_offset, long n, const float* qry_xyz, const int32_t* qry_offset,
                long m, int nb, const float* origin, float cell, int32_t* idx, float* dist2, void* ws, size_t ws_bytes,

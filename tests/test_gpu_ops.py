@@ -784,6 +784,58 @@ def test_knn1_vs_bruteforce_oracle(ops):
     assert np.all(got[:10] == -1) and np.all(got[10:] >= 0)
 
 
+@pytest.mark.parametrize("k", [1, 8, 16, 48, 64])
+def test_knn_k_vs_bruteforce_oracle(ops, k):
+    """cdseg_knn (round 5: pointops.knn_query for k > 1 - the neighbourhood query of the reference's other backbones,
+    libs/pointops/functions/query.py:7-24) against oracle/testtime.py::knn_bruteforce: two batch elements, self-query and
+    separate queries, a batch element with fewer than k points (placeholders), queries far outside the box (brute-force
+    fallback), an integer lattice with masses of exact ties (bit-exact, index order)."""
+    from oracle import testtime as OT
+    rng = np.random.default_rng(k)
+    raw = (rng.random((9000, 3)) * np.array([4.0, 3.0, 0.3])).astype(np.float32)
+    ref = raw[rng.random(9000) < 0.5]
+    nr0 = min(len(ref) - 1, 40)  # first batch element: 40 points (< k for the large k: placeholders)
+    qry = np.concatenate([raw[:3000], raw[:50] + np.float32(30.0)])
+    roff, qoff = [nr0, len(ref)], [300, len(qry)]
+
+    def check(ref, roff, qry, qoff, exact, **kw):
+        want, wd2 = OT.knn_bruteforce(k, ref, roff, qry, qoff)
+        idx, dist = ops.knn(k, dev(ref), dev(np.asarray(roff, dtype=np.int32)), dev(qry), dev(np.asarray(qoff, dtype=np.int32)), **kw)
+        idx, d2 = idx.cpu().numpy().astype(np.int64), dist.cpu().numpy().astype(np.float64) ** 2
+        assert idx.shape == (len(qry), k)
+        assert np.array_equal(idx < 0, want < 0)          # placeholders exactly where the element runs out of points
+        live = want >= 0
+        assert np.allclose(d2[live], wd2[live], rtol=2e-5, atol=1e-9)  # the k smallest distances, ascending
+        assert np.all(np.diff(d2, axis=1)[live[:, 1:]] >= -1e-12)
+        # every returned index realises its distance, lies in the query's batch element and appears once
+        bq = np.searchsorted(np.asarray(qoff), np.arange(len(qry)), side="right")
+        lo = np.concatenate([[0], roff])[bq][:, None]
+        hi = np.asarray(roff)[bq][:, None]
+        assert np.all((idx >= lo)[live]) and np.all((idx < hi)[live])
+        true = ((qry[:, None, :].astype(np.float32) - ref[np.clip(idx, 0, None)].astype(np.float32)) ** 2).sum(-1)
+        assert np.allclose(true[live], d2[live], rtol=2e-5, atol=1e-9)
+        srt = np.sort(np.where(live, idx, -1 - np.arange(k)[None, :]), axis=1)
+        assert np.all(np.diff(srt, axis=1) != 0)
+        if exact:
+            assert np.array_equal(idx, want)
+
+    check(ref, roff, qry, qoff, exact=False)
+    check(ref, roff, ref, roff, exact=False)                                # self-query (pointops' default)
+    check(ref, roff, qry, qoff, exact=False, origin=ref.min(0).tolist(), cell=0.01)   # tiny cells
+    check(ref, roff, qry, qoff, exact=False, origin=ref.min(0).tolist(), cell=4.0)    # one cell holds everything
+    lat = rng.integers(0, 7, size=(3000, 3)).astype(np.float32)
+    q = rng.integers(0, 7, size=(1500, 3)).astype(np.float32) + np.float32(0.5)
+    check(lat, [3000], q, [1500], exact=True, origin=[0.0, 0.0, 0.0], cell=1.0)
+
+
+def test_knn_rejects_k_above_its_limit(ops):
+    from cdsegnet_amd import _lib
+    x = torch.rand(100, 3, device="cuda")
+    off = torch.tensor([100], dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.CdsegError):
+        ops.knn(65, x, off)
+
+
 def test_iou_counts_vs_reference_fixture(ops):
     fx = load_fixture("iou_counts.npz")
     for tag in ("a", "b", "c"):

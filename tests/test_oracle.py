@@ -371,3 +371,19 @@ def test_philox_oracle_reproduces_the_random123_known_answers():
     z = P.randn(400001, 54421566, 3)
     assert z.dtype == np.float32 and z.shape == (400001,) and np.isfinite(z).all()
     assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+
+
+def test_knn_bruteforce_is_consistent_with_knn1_and_sorted():
+    """oracle/testtime.py::knn_bruteforce (k nearest, ascending, index order among ties, placeholders) - its first column is
+    knn1_bruteforce, rows are sorted, a batch element with fewer than k points ends in placeholders."""
+    from oracle import testtime as TT
+    rng = np.random.default_rng(5)
+    ref = rng.random((700, 3)).astype(np.float32)
+    qry = rng.random((300, 3)).astype(np.float32)
+    idx, d2 = TT.knn_bruteforce(6, ref, [4, 700], qry, [50, 300])
+    i1, d1 = TT.knn1_bruteforce(ref, [4, 700], qry, [50, 300])
+    assert np.array_equal(idx[:, 0], i1) and np.array_equal(d2[:, 0], d1)
+    assert np.all(idx[:50, 4:] == -1) and np.all(d2[:50, 4:] == np.float32(1e10)) and np.all(idx[:50, :4] >= 0)
+    assert np.all(idx[50:] >= 4) and np.all(np.diff(d2[50:], axis=1) >= 0)
+    for r in idx[50:60]:
+        assert len(set(r.tolist())) == 6
