@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"bf16": 2500.0, "bf16+head": 2500.0, "fp16": 2500.0, "fp16+head": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-CPU_THREADS = 16  # fastest of {8, 16, 32, 64, 128} torch threads on the GPU box host (tools/cpu_sweep.py, profiles/r02_cpu_sweep.txt)
+CPU_THREADS = 16  # fastest of {8, 16, 32} torch threads on the GPU box host at the baseline's own 120 k-voxel scene (tools/cpu_sweep.py, profiles/r05_cpu_sweep.txt; r02: 24 k voxels)
 
 
 def dtype_name(precision):
