@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=CPU_THREADS)
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the roofline pass after the timed region")
     ap.add_argument("--no-agreement", action="store_true", help="skip the 16-bit-vs-fp32 agreement leg")
+    ap.add_argument("--no-paper-pass", action="store_true",
+                    help="skip the separate `--protocol paper` process whose result the default line carries as paper_protocol.own_process")
     ap.add_argument("--scenes-per-forward", type=int, default=8,
                     help="scenes collated into one forward (the reference's collate_fn batching); one step = "
                          "scenes-per-forward x lanes scenes (one batch per lane)")
@@ -696,6 +698,19 @@ def main():
                             "tools/test_time.py; its published figure for the 312-scene ScanNet val split is 56 s on an RTX 3090 "
                             "(BASELINE.md; other hardware, real scans, data loading excluded there too)",
                 "points_per_scene_mean": pts_per_step / scenes_per_step}
+            if world == 1 and not args.no_paper_pass and args.dataset == "scannet" and not args.robust:
+                # the reference's protocol as its own process (312 DISTINCT scenes, nothing else run before): what
+                # `python bench.py --protocol paper` prints, here so that the driver's line carries it
+                try:
+                    pp = subprocess.run([sys.executable, os.path.abspath(__file__), "--protocol", "paper", "--precision", args.precision,
+                                         "--points", str(args.points)], capture_output=True, text=True, timeout=600)
+                    pj = json.loads(pp.stdout.strip().splitlines()[-1])
+                    res["paper_protocol"]["own_process"] = {"seconds_for_312_scenes": pj["value"], "ms_per_scene": pj["ms_per_step"],
+                                                            "points_per_s": pj["points_per_s"], "distinct_scenes": 312,
+                                                            "what": "python bench.py --protocol paper in a process of its own, run "
+                                                                    "from this one after the timed region"}
+                except Exception as e:  # noqa: BLE001 - the headline line must not depend on this leg
+                    res["paper_protocol"]["own_process"] = {"error": repr(e)[:200]}
             if "half_saturation" in iso:
                 res["half_saturation"] = dict(iso["half_saturation"], what="16-bit activations that reach memory at +-65504, "
                                               "the clamp value of the half build's conversions, in one forward of a bench scene "

@@ -25,7 +25,7 @@ DB=$(find /tmp/prof_final1 -name "*.db" | head -1); python tools/prof_summary.py
 cat gpurun_out/r05g_single.txt; head -30 gpurun_out/r05g_lanes1_kernel_stats.txt | cut -c1-150
 : > gpurun_out/r05g_other_configs.txt
 other() {
-  ( timeout 300 python bench.py --no-cpu-baseline --steps 8 "$@" ) > /tmp/other.json 2> /tmp/other.err
+  ( timeout 300 python bench.py --no-cpu-baseline --no-paper-pass --steps 8 "$@" ) > /tmp/other.json 2> /tmp/other.err
   python - "$*" >> gpurun_out/r05g_other_configs.txt <<'PY'
 import json, sys
 try:
