@@ -8,8 +8,8 @@
 // index -> row -> LDS round trips (PMC, profiles/r01l: VALU 11 %, matrix pipe 2 %, 60 % of the wave cycles idle).
 // This kernel turns the roles around:
 //   * W is STATIONARY: the whole 27 x C x C kernel lives in LDS for the lifetime of a persistent block (C = 32:
-//     55 KB, 2 blocks / CU; C = 64: the 19 face / edge / centre offsets = 152 KB, the 8 corner offsets are read from
-//     L2), laid out in MFMA A-fragment order (conflict-free b128 reads);
+//     55 KB, 2 blocks / CU; C = 64: the 19 face / edge / centre offsets and one corner offset = 160 KB, the other 7
+//     corner offsets are read from L2), laid out in MFMA A-fragment order (conflict-free b128 reads);
 //   * gathered rows go STRAIGHT into MFMA B-fragment registers: lane (j, c) of v_mfma_f32_16x16x32_bf16 holds
 //     channels 8c..8c+7 of point j, which is one 16-byte BUFFER load from row nbr[o, j] - no LDS round trip, no
 //     barrier; a missing neighbour (index -1) becomes an out-of-range buffer offset: zeros, no memory access;
@@ -47,7 +47,7 @@ struct ConvP {
                         // treated as dead, 2 = every neighbour replaced by the row itself (perfectly local gathers)
 };
 
-// offsets in LDS-residency priority order (C = 64 keeps the first 19 in LDS): centre, 6 faces, 12 edges, 8 corners
+// offsets in LDS-residency priority order (C = 64 keeps the first CONV64_LDS_OFFSETS = 20 in LDS): centre, 6 faces, 12 edges, 8 corners
 __device__ __constant__ int8_t c_slot_of_offset[27] = {
     // o = a*9 + b*3 + c, (a,b,c) in {0,1,2}^3; #ones = number of coordinates equal to 1 (centre = 3, face = 2, edge = 1)
     19, 7, 20, 8, 1, 9, 21, 10, 22,   // a = 0
@@ -60,14 +60,21 @@ struct SlotBits {
   static constexpr unsigned long long t0 = 0x6097655521450f3ull, t1 = 0x89a187ddc569003ull, t2 = 0x6a59ull;
 };
 
+// C = 64: how many of the 27 offsets' weights (8 KB each) stay in LDS; 19 = centre + faces + edges (152 KB), 20 = the whole
+// 160 KB of a CU: one corner offset fewer to fetch per tile (a third of the kernel's vector-memory instructions are corner
+// weights) - 125.3 -> 123.5 us at 446 k rows (profiles/r05_conv64_lds20.txt)
+#ifndef CONV64_LDS_OFFSETS
+#define CONV64_LDS_OFFSETS 20
+#endif
+
 template <int C>
 struct ConvCfg {
   static constexpr int CT = C / 16;       // 16-channel output tiles
   static constexpr int KS = C / 32;       // MFMA k steps per offset
   static constexpr int KC = C / 8;        // 16-byte channel chunks per row
   static constexpr int OFF_BYTES = C * C * 2;                // one offset's weights
-  static constexpr int LDS_OFFSETS = C <= 32 ? 27 : 19;      // offsets resident in LDS
-  static constexpr int LDS_BYTES = LDS_OFFSETS * OFF_BYTES;  // 55,296 / 155,648
+  static constexpr int LDS_OFFSETS = C <= 32 ? 27 : CONV64_LDS_OFFSETS;  // offsets resident in LDS
+  static constexpr int LDS_BYTES = LDS_OFFSETS * OFF_BYTES;  // 55,296 / 163,840 (= the CU's whole LDS)
   static constexpr int WAVES = 8;                            // pack kernel block size
   static constexpr int RG = 2;                               // 16-row groups per wave
   static constexpr int ROWS_PER_WAVE = RG * 16;
