@@ -298,7 +298,7 @@ class GradSync:
             # all-reduces above summed unrelated parameters.  One tiny MIN / MAX all-reduce of a digest of that order
             import zlib
             h = zlib.crc32(repr(self._order).encode()) & 0x7FFFFFFF
-            dev = self.named[0][1].grad.device if dist.get_backend(self.kw["group"]) == "nccl" else torch.device("cpu")
+            dev = self.named[0][1].device if dist.get_backend(self.kw["group"]) == "nccl" else torch.device("cpu")
             t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.kw["group"])
             if int(t[0]) != -int(t[1]):
