@@ -57,13 +57,19 @@ __device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) 
 
 // float -> half, round-to-nearest-even, saturating at +-65504 (v_med3_f32 + v_cvt_pk_f16_f32): an activation outlier
 // of a trained checkpoint clamps instead of turning the rest of the forward into inf / NaN
+// (CDSEG_F16_NO_CLAMP: tools-only A/B switch that measures what the two clamps per conversion cost - never in the product)
+#ifdef CDSEG_F16_NO_CLAMP
+#define CDSEG_SAT(x) (x)
+#else
+#define CDSEG_SAT(x) __builtin_amdgcn_fmed3f((x), -65504.f, 65504.f)
+#endif
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  const _Float16 b = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+  const _Float16 b = (_Float16)CDSEG_SAT(f);
   return __builtin_bit_cast(uint16_t, b);
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  const hw_f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+  const hw_f32x2_t v = {CDSEG_SAT(lo), CDSEG_SAT(hi)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_lpx2_t));
 }
 
