@@ -337,6 +337,9 @@ extern "C" int cdseg_attn_tail_fused(const void* o, int ldo, const void* wp, con
 // Block head after the sparse conv in one launch (ptv3.py:401-414):
 //     x += LN_cpe(y Wl^T + bl) [+ t bias] ;  h = LN1(x) ;  qkv = h Wqkv^T + bqkv
 // y = conv output (n, C).  h lives only in LDS; x is read and written once.
+#ifndef CPE_HEAD_PREFETCH
+#define CPE_HEAD_PREFETCH 1
+#endif
 namespace {
 
 struct HeadP {
@@ -412,13 +415,47 @@ __global__ __launch_bounds__(4 * BM) void cpe_head_fused_kernel(HeadP p) {
           Cs[(wm * 32 + i * 16 + fg * 4 + r) * CLD + wn * (C / 2) + t * 16 + fr] = acc[i][t][r];
   };
 
+  // Round 5: the loads whose latency sat exposed behind a barrier are requested a phase ahead, into registers - every weight
+  // tile (8 KB at C = 64 = one 16-byte piece per thread) while the previous product runs, and the residual rows of x at the
+  // very start instead of after the first product + LayerNorm (the compiler cannot move a load across __syncthreads)
+  constexpr int WPT = (C * NCA + NT - 1) / NT;  // 16-byte weight pieces per thread
+  uint4 wreg[WPT];
+  auto fetch_w = [&](const bf16_t* w) {
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+      const int id = tid + k * NT;
+      if (id < C * NCA) wreg[k] = *reinterpret_cast<const uint4*>(w + (long)(id / NCA) * C + (id % NCA) * 8);
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+      const int id = tid + k * NT;
+      if (id < C * NCA) *reinterpret_cast<uint4*>(Ws + mlp_lds_off<NCA>(id / NCA, id % NCA)) = wreg[k];
+    }
+  };
+  constexpr int MAXG0 = C / 16;
+  float4 xres[MAXG0];
+  if (CPE_HEAD_PREFETCH) {
+    fetch_w(p.wl);
+    const long mrow = m0 + (tid >> 2);
+#pragma unroll
+    for (int i = 0; i < MAXG0; ++i)
+      xres[i] = mrow < p.n ? *reinterpret_cast<const float4*>(p.x + mrow * p.ldx + 4 * ((tid & 3) + 4 * i))
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int id = tid; id < BM * NCA; id += NT) {
     const int row = id / NCA, ch = id % NCA;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (m0 + row < p.n) v = *reinterpret_cast<const uint4*>(p.y + (m0 + row) * p.ldy + ch * 8);
     *reinterpret_cast<uint4*>(As + mlp_lds_off<NCA>(row, ch)) = v;
   }
-  load_w(p.wl);
+  if (CPE_HEAD_PREFETCH) {
+    store_w();
+    fetch_w(p.wqkv);  // the q tile's weights travel behind the first product and the two LayerNorms
+  } else {
+    load_w(p.wl);
+  }
   __syncthreads();
   mma_to_cs();
   __syncthreads();
@@ -467,7 +504,7 @@ __global__ __launch_bounds__(4 * BM) void cpe_head_fused_kernel(HeadP p) {
       v[i].w = (v[i].w - mean) * rstd * ga.w + be.w;
       if (act) {
         float* xr = p.x + m * p.ldx + 4 * cg;
-        const float4 r = *reinterpret_cast<const float4*>(xr);
+        const float4 r = CPE_HEAD_PREFETCH ? xres[i] : *reinterpret_cast<const float4*>(xr);
         v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
         if (p.colbias) {
           const float4 t = *reinterpret_cast<const float4*>(p.colbias + 4 * cg);
@@ -496,7 +533,12 @@ __global__ __launch_bounds__(4 * BM) void cpe_head_fused_kernel(HeadP p) {
 #pragma unroll 1
   for (int j = 0; j < 3; ++j) {
     __syncthreads();  // As = h complete / previous tile's Cs and Ws consumed
-    load_w(p.wqkv + (long)j * C * C);
+    if (CPE_HEAD_PREFETCH) {
+      store_w();
+      if (j < 2) fetch_w(p.wqkv + (long)(j + 1) * C * C);
+    } else {
+      load_w(p.wqkv + (long)j * C * C);
+    }
     __syncthreads();
     mma_to_cs();
     __syncthreads();

@@ -4,6 +4,9 @@ usage: python tools/bench_block.py [scenes=8]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cdsegnet_amd import _lib
+if os.environ.get("CDSEG_AB_LIB"):  # A/B runs against another build of the library (tools only)
+    _lib.LIB_PATH = os.path.abspath(os.environ["CDSEG_AB_LIB"])
 from cdsegnet_amd import ops
 from tools.bench_gemm import time_op
 
