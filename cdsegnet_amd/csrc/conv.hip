@@ -67,6 +67,25 @@ struct SlotBits {
 #define CONV64_LDS_OFFSETS 20
 #endif
 
+// Lane -> address map of the gathered-row loads.  0: the MFMA operand layout itself (lane (j, c) reads chunk c of row j: the
+// four lanes of a quad read 16 bytes of four different rows).  1: quad-contiguous (lane 4 j + c reads chunk c of row j: a
+// quad = 64 contiguous bytes of one row) and a ds_bpermute per dword moves the data to the operand layout before the MFMAs
+// (tools/ubench/gather_map.hip times the two maps on bare loads).  A mask: bit 0 = the C = 32 kernel, bit 1 = the C = 64 kernel.
+#ifndef CONV_QUAD_GATHER
+#define CONV_QUAD_GATHER 0
+#endif
+#ifndef CONV_CORNER_FIRST
+#define CONV_CORNER_FIRST 0
+#endif
+
+// row buffers in rotation per wave (loads of NB - 1 list entries in flight behind the MFMAs of one)
+#ifndef CONV32_ROW_BUFFERS
+#define CONV32_ROW_BUFFERS 3
+#endif
+#ifndef CONV64_ROW_BUFFERS
+#define CONV64_ROW_BUFFERS 4
+#endif
+
 template <int C>
 struct ConvCfg {
   static constexpr int CT = C / 16;       // 16-channel output tiles
@@ -78,6 +97,7 @@ struct ConvCfg {
   static constexpr int WAVES = 8;                            // pack kernel block size
   static constexpr int RG = 2;                               // 16-row groups per wave
   static constexpr int ROWS_PER_WAVE = RG * 16;
+  static constexpr bool QUAD = ((CONV_QUAD_GATHER) >> (C == 64 ? 1 : 0)) & 1;  // lane map of the row loads
 };
 
 // Fragment-order weight image.  16-byte unit u = ((slot * CT + ct) * KC + kc) * 16 + i holds
@@ -143,6 +163,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
       __builtin_amdgcn_make_buffer_rsrc((void*)p.nbr, 0, (int)(p.n * 27 * 4), 0x00020000);
   const int prow = lane & 31, phalf = lane >> 5;
   const int plane_bytes = (int)(p.n * 4);
+  const int lrow = K::QUAD ? lane >> 2 : jrow, lchunk = K::QUAD ? lane & 3 : cgrp;  // load map: lane 4 j + c | the operand's
+  const int to_frag = (4 * jrow + cgrp) << 2;  // ds_bpermute address: operand lane (j, c) takes from load lane 4 j + c
 
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = (gridDim.x + 7 - xcd) >> 3;
   const int per = (p.tiles + 7) >> 3;
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
     auto perm = [&](int o, int (&id)[K::RG]) {
       const int v = I[__builtin_amdgcn_readfirstlane(o >> 1)];
 #pragma unroll
-      for (int g = 0; g < K::RG; ++g) id[g] = __builtin_amdgcn_ds_bpermute((((o & 1) << 5) + 16 * g + jrow) << 2, v);
+      for (int g = 0; g < K::RG; ++g) id[g] = __builtin_amdgcn_ds_bpermute((((o & 1) << 5) + 16 * g + lrow) << 2, v);
     };
     auto rows = [&](const int (&id)[K::RG], auto buf) {
       constexpr int B = decltype(buf)::value;
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
 #pragma unroll
         for (int ks = 0; ks < K::KS; ++ks) {
           // -1 << row_shift wraps beyond the end of x: zeros, no memory access
-          const unsigned off = ((unsigned)id[g] << p.row_shift) + (unsigned)((ks * 4 + cgrp) * 16);
+          const unsigned off = ((unsigned)id[g] << p.row_shift) + (unsigned)((ks * 4 + lchunk) * 16);
           xb[B][g][ks] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
         }
     };
@@ -241,14 +263,53 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
     auto mfmas = [&](int o, const bf16x8_t (&wf)[K::KS][K::CT], auto buf) {
       constexpr int B = decltype(buf)::value;
       if (o >= 27) return;
+      bf16x8_t xq[K::RG][K::KS];
+#pragma unroll
+      for (int g = 0; g < K::RG; ++g)
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks) {
+          if constexpr (K::QUAD) {
+            i32x4_t t = __builtin_bit_cast(i32x4_t, xb[B][g][ks]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_ds_bpermute(to_frag, t[e]);
+            xq[g][ks] = __builtin_bit_cast(bf16x8_t, t);
+          } else {
+            xq[g][ks] = xb[B][g][ks];
+          }
+        }
 #pragma unroll
       for (int ks = 0; ks < K::KS; ++ks)
 #pragma unroll
         for (int ct = 0; ct < K::CT; ++ct)
 #pragma unroll
           for (int g = 0; g < K::RG; ++g)
-            acc[g][ct] = mfma_16x16x32_bf16(wf[ks][ct], xb[B][g][ks], acc[g][ct]);
+            acc[g][ct] = mfma_16x16x32_bf16(wf[ks][ct], xq[g][ks], acc[g][ct]);
     };
+#if CONV_CORNER_FIRST
+    // (experiment) a corner offset's weights are requested BEFORE the step's row loads and waited for with vmcnt(row loads of
+    // the step): the newest rows stay in flight instead of being drained with everything else
+    auto slot_of = [&](int o) {
+      const unsigned long long tab = o < 12 ? SlotBits::t0 : (o < 24 ? SlotBits::t1 : SlotBits::t2);
+      const int sh = 5 * (o < 12 ? o : (o < 24 ? o - 12 : o - 24));
+      return (int)((tab >> sh) & 31ull);
+    };
+    auto wload_l2 = [&](int slot, bf16x8_t (&wf)[K::KS][K::CT]) {
+      const uint4* base = wimg + slot * (K::OFF_BYTES / 16) + lane_unit;
+#pragma unroll
+      for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < K::CT; ++ct)
+          wf[ks][ct] = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 16);
+    };
+    auto wload_lds = [&](int slot, bf16x8_t (&wf)[K::KS][K::CT]) {
+      const char* base = smem + slot * K::OFF_BYTES + lane_unit * 16;
+#pragma unroll
+      for (int ks = 0; ks < K::KS; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < K::CT; ++ct)
+          wf[ks][ct] = *reinterpret_cast<const bf16x8_t*>(base + (ct * K::KC + ks * 4) * 256);
+    };
+#endif
     int o[NB];
     static_for<0, NB - 1>([&](auto J) {
       o[J.value] = pop();
@@ -263,9 +324,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
         o[nb] = pop();
         int id[K::RG];
         perm(o[nb], id);
-        rows(id, std::integral_constant<int, nb>{});
         bf16x8_t wf[K::KS][K::CT];
+#if CONV_CORNER_FIRST
+        if constexpr (K::LDS_OFFSETS != 27) {
+          const int slot = o[j] < 27 ? slot_of(o[j]) : 0;
+          const bool from_l2 = slot >= K::LDS_OFFSETS;
+          if (from_l2) wload_l2(slot, wf);
+          rows(id, std::integral_constant<int, nb>{});
+          if (from_l2) __builtin_amdgcn_s_waitcnt(0x0F70 | (K::RG * K::KS));  // vmcnt(this step's row loads)
+          else if (o[j] < 27) wload_lds(slot, wf);
+        } else {
+          rows(id, std::integral_constant<int, nb>{});
+          wload(o[j], wf);
+        }
+#else
+        rows(id, std::integral_constant<int, nb>{});
         wload(o[j], wf);
+#endif
         mfmas(o[j], wf, J);
       });
     } while (o[0] < 27);
@@ -334,8 +409,8 @@ int launch_conv(const ConvP& p0, const void* wimg, hipStream_t s) {
   // C = 32: 8 waves, 3 row buffers, 4 waves / SIMD; C = 64: 8 waves on the 256-register budget of 2 waves / SIMD,
   // 4 row buffers (16 waves x 2 buffers spills and is 1.8x slower; 6 buffers, 12-wave blocks at 3 waves / SIMD and, at
   // C = 32, 12-wave blocks or 4 buffers: no gain - profiles/r02_conv_livelist_sweep.txt)
-  if constexpr (C == 32) return launch_conv_ll<32, 8, 3, 4>(p0, per_cu, wimg, s);
-  else return launch_conv_ll<64, 8, 4, 2>(p0, per_cu, wimg, s);
+  if constexpr (C == 32) return launch_conv_ll<32, 8, CONV32_ROW_BUFFERS, 4>(p0, per_cu, wimg, s);
+  else return launch_conv_ll<64, 8, CONV64_ROW_BUFFERS, 2>(p0, per_cu, wimg, s);
 }
 
 }  // namespace

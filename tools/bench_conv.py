@@ -48,7 +48,7 @@ if ops.subm_conv3_ok(x) and os.environ.get("CDSEG_BENCH_OLD_ONLY") is None:
     comp = (n * c * 2 * 2 + n * 27 * 4 + 27 * c * c * 2) / 1e6  # features in + out, dense kernel map, weights
     print(f"conv level {level}: weight-stationary live-list kernel {us2:.1f} us/launch "
           f"({2.0 * n * occ * c * c / us2 / 1e6:.1f} TFLOP/s occupied; compulsory HBM bytes {comp:.1f} MB -> "
-          f"{comp / us2:.2f} TB/s)" +
+          f"{comp / us2:.2f} TB/s), checksum {float(o2.float().abs().sum()):.9e}" +
           ("" if us is None else f", max |new - gathered GEMM| = {(o2.float() - o.float()).abs().max().item():.3e}"))
 if us is not None:  # (PMC passes run only the kernel under study: no gathered-GEMM line, no comparison against it)
     # spot check against a plain fp32 gather + matmul on 4096 sampled rows (same 16-bit operands)
