@@ -14,6 +14,40 @@
 #include <cstdio>
 #include <vector>
 
+// Second kernel (added after the round's last GPU call, not yet run): the conv's own access - raw BUFFER loads with a
+// per-lane offset, DEAD of 16 rows of a set absent (index -1 -> out-of-range offset -> zeros, no memory access), and a window
+// mix: a set comes from a 1 MB hot window (L2-resident) with probability HOT / 16, else from the whole buffer.
+template <int D, int MAP, int DEAD, int HOT>
+__global__ __launch_bounds__(512) void kb(const char* src, unsigned long long rows, int iters, unsigned* sink) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned long long state = (blockIdx.x * 64ull + wave) * 0x9E3779B97F4A7C15ull + 12345ull;
+  const int slot = MAP == 0 ? (lane & 15) : (lane >> 2);
+  const int chunk = MAP == 0 ? (lane >> 4) : (lane & 3);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(rows * 128), 0x00020000);
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  unsigned acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    unsigned off[D];
+#pragma unroll
+    for (int d = 0; d < D; d += 2) {
+      state = state * 6364136223846793005ull + 1442695040888963407ull;
+      const unsigned long long span = ((state >> 56) & 15) < (unsigned)HOT ? 8192ull : rows;  // 8192 rows = 1 MB
+      unsigned long long r = (state >> 24) & (span - 1);
+      r = (r > span - 16 ? r - 16 : r) + slot;
+      const bool dead = (((state >> 12) + slot * 7) & 15) < (unsigned)DEAD;  // exactly DEAD of the 16 rows of a set
+      off[d] = dead ? 0xFFFFFF80u + chunk * 16 : (unsigned)(r * 128 + chunk * 16);
+      off[d + 1] = off[d] + (dead ? 0u : 64u);
+      asm volatile("" : "+v"(off[d]), "+v"(off[d + 1]));
+    }
+    u4 v[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[d], 0, 0));
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc ^= v[d][0] ^ v[d][1] ^ v[d][2] ^ v[d][3];
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 template <int D, int MAP, int SCATTER, int PERMUTE>
 __global__ __launch_bounds__(512) void k(const char* src, unsigned long long rows /* 128-byte rows, a power of two */, int iters,
                                          unsigned* sink) {
@@ -76,6 +110,26 @@ static void run(const char* src, size_t span, const char* where, unsigned* sink)
          best * 1e6 / instr_per_cu, best * 1e6 / instr_per_cu * 2.1);
 }
 
+template <int D, int MAP, int DEAD, int HOT>
+static void runb(const char* src, size_t span, unsigned* sink) {
+  const int iters = 400, waves = 8;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kb<D, MAP, DEAD, HOT>), dim3(256), dim3(waves * 64), 0, 0, src, (unsigned long long)(span / 128), iters, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  const double instr_per_cu = (double)waves * D * iters;
+  printf("buffer loads, 64 MB buffer, %2d / 16 row sets from a 1 MB window, %2d / 16 rows dead, map %s D=%d: %6.1f ns per wave-instruction "
+         "and CU (%5.1f cycles at 2.1 GHz)\n", HOT, DEAD, MAP == 0 ? "M" : "Q", D, best * 1e6 / instr_per_cu, best * 1e6 / instr_per_cu * 2.1);
+}
+
 int main() {
   printf("gathered 16-byte-per-lane loads, 16 rows x 64 bytes per instruction: MFMA-operand lane map (M) vs quad-contiguous (Q)\n");
   const size_t spans[3] = {2ull << 20, 16ull << 20, 64ull << 20};
@@ -95,6 +149,19 @@ int main() {
     run<12, 1, 0, 1>(buf, spans[s], names[s], sink);
     run<12, 0, 1, 0>(buf, spans[s], names[s], sink);
     run<12, 1, 1, 0>(buf, spans[s], names[s], sink);
+    hipFree(buf);
+  }
+  {  // the conv's own access: buffer loads, dead lanes, a mostly-hot window
+    char* buf;
+    const size_t span = 64ull << 20;
+    if (hipMalloc(&buf, span) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(buf, 1, span);
+    hipDeviceSynchronize();
+    runb<12, 0, 0, 16>(buf, span, sink); runb<12, 1, 0, 16>(buf, span, sink);
+    runb<12, 0, 6, 16>(buf, span, sink); runb<12, 1, 6, 16>(buf, span, sink);
+    runb<12, 0, 0, 14>(buf, span, sink); runb<12, 1, 0, 14>(buf, span, sink);
+    runb<12, 0, 6, 14>(buf, span, sink); runb<12, 1, 6, 14>(buf, span, sink);
+    runb<12, 0, 6, 0>(buf, span, sink);  runb<12, 1, 6, 0>(buf, span, sink);
     hipFree(buf);
   }
   return 0;
