@@ -22,6 +22,14 @@ class CdsegError(RuntimeError):
     pass
 
 
+class DuplicateVoxelsError(CdsegError):
+    """Several input points share one (batch element, grid_coord) voxel.  `count` = the surplus points."""
+
+    def __init__(self, msg, count):
+        super().__init__(msg)
+        self.count = int(count)
+
+
 class GemmArgs(Structure):
     _fields_ = [
         ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("scale", c_void_p), ("shift", c_void_p),

@@ -45,6 +45,7 @@
 namespace {
 
 constexpr int ATTN_ZONES = 5;
+constexpr int ATTN_STORE8 = 1 << 30;  // internal flag (AttnP::flags): output rows are 8- but not 16-byte aligned
 
 struct AttnP {
   const void* q;
@@ -518,23 +519,21 @@ __global__ __launch_bounds__(BF_THREADS, (2 * BF_WAVES) / 4) void attn_bf16_kern
       a.y = pack_bf16x2(o[2] * inv, o[3] * inv);
       b.x = pack_bf16x2(o[4] * inv, o[5] * inv);
       b.y = pack_bf16x2(o[6] * inv, o[7] * inv);
-#if ATTN_STORE16
-      // one 16-byte store per lane instead of two 8-byte ones: lanes q and q + 32 hold the two halves of each 8-dim run
-      // of query q; v_permlane32_swap exchanges a[32..63] with b[0..31], after which lane q holds d = 0..7 and lane
-      // q + 32 holds d = 8..15 (a = first, b = second half of the run)
-      const auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
-      const auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
-      if (w >= 0) {
-        bf16_t* orow = (bf16_t*)p.out + (long)w * p.ldo + head * 16 + 8 * h;
-        *reinterpret_cast<uint4*>(orow) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-      }
-#else
-      if (w >= 0) {
+      if (ATTN_STORE16 && !(p.flags & ATTN_STORE8)) {
+        // one 16-byte store per lane instead of two 8-byte ones: lanes q and q + 32 hold the two halves of each 8-dim run
+        // of query q; v_permlane32_swap exchanges a[32..63] with b[0..31], after which lane q holds d = 0..7 and lane
+        // q + 32 holds d = 8..15 (a = first, b = second half of the run)
+        const auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+        if (w >= 0) {
+          bf16_t* orow = (bf16_t*)p.out + (long)w * p.ldo + head * 16 + 8 * h;
+          *reinterpret_cast<uint4*>(orow) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      } else if (w >= 0) {  // output rows that are only 8-byte aligned (ldo % 8 != 0): the two 8-byte pieces the lane holds
         bf16_t* orow = (bf16_t*)p.out + (long)w * p.ldo + head * 16 + 4 * h;
         *reinterpret_cast<uint2*>(orow) = a;      // d = 4h .. 4h+3
         *reinterpret_cast<uint2*>(orow + 8) = b;  // d = 8+4h .. 8+4h+3
       }
-#endif
     }
     qt = qt_nxt;
     q_cur = q_nxt;
@@ -742,15 +741,18 @@ extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, i
   if (flags & ~(CDSEG_ATTN_Q_PRESCALED | CDSEG_ATTN_V_BF16)) return CDSEG_ERR_ARG;
   if (dtype == CDSEG_F32 && (flags & CDSEG_ATTN_V_BF16)) return CDSEG_ERR_ARG;
   const int esz = dtype == CDSEG_F32 ? 4 : 2;
-  // 16-byte alignment of every gathered row slice and of every output piece
-  if (((long)ldq * esz) & 15 || ((long)ldk * esz) & 15 || ((long)ldv * esz) & 15 || ((long)ldo * esz) & 15) return CDSEG_ERR_ARG;
-  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return CDSEG_ERR_ARG;
+  // 16-byte alignment of every gathered row slice; output pieces: 16 bytes (fp32: always; 16-bit: the one-store epilogue),
+  // or 8 bytes for 16-bit outputs with ldo % 8 != 0 (such calls were valid before the 16-byte store existed)
+  if (((long)ldq * esz) & 15 || ((long)ldk * esz) & 15 || ((long)ldv * esz) & 15) return CDSEG_ERR_ARG;
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return CDSEG_ERR_ARG;
+  const bool out16 = !((((long)ldo * esz) | (long)(uintptr_t)out) & 15);
+  if (!out16 && (dtype == CDSEG_F32 || ((((long)ldo * esz) | (long)(uintptr_t)out) & 7))) return CDSEG_ERR_ARG;
   AttnP p;
   p.q = q; p.k = k; p.v = v; p.q_gidx = q_gidx; p.kv_gidx = kv_gidx; p.widx = widx; p.patch_start = patch_start;
   p.out = out; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.num_heads = num_heads;
   // Q pre-scaled: the producer's weights carry softmax scale * log2(e) (`scale` is then ignored)
   p.scale_log2e = (flags & CDSEG_ATTN_Q_PRESCALED) ? 1.0f : scale * 1.44269504088896340736f;
-  p.flags = flags;
+  p.flags = flags | (out16 ? 0 : ATTN_STORE8);
   hipStream_t s = (hipStream_t)stream;
   const unsigned nblocks = make_schedule(p, num_patches, num_heads, max_len, dtype);
   dim3 grid(nblocks), block(dtype == CDSEG_BF16 ? BF_THREADS : ATTN_THREADS);

@@ -111,8 +111,9 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
   int rc;
   // what the qkv producer of this Block has already done for the attention kernel (cdseg_attention_ex): the engine folds
   // scale * log2(e) into the q rows of the weights (desc), the fused heads write v as bfloat16
+  // (the fp32 attention kernel honours Q_PRESCALED too - ADVICE r5: dropping the flag here applied the softmax scale twice
+  // to a descriptor with folded q weights; V_BF16 is a 16-bit-build flag and is only ever set by the fused heads below)
   int attn_flags = d->attn_flags & CDSEG_ATTN_Q_PRESCALED;
-  if (T != CDSEG_BF16) attn_flags = 0;
 
   // ---- CPE: x += LN(Linear(SubMConv3d(xc)))  [+ t bias];  h = LN1(x)      (ptv3.py:401-413)
   // (the weight-stationary kernel addresses its buffers with 32-bit offsets: inputs past those limits - 16.7 M rows at

@@ -211,12 +211,17 @@ class GradBucketer:
         self.cur, self.cur_fill = [], 0
         self.pending = []  # (flat, [(name, shape, offset, numel)], work)
         self.world = dist.get_world_size(group) if is_dist() else 1
+        self.tail_len, self.tail_sum, self._dev = 0, None, torch.device("cpu")
 
-    def _flush(self):
-        if not self.cur:
+    def _flush(self, tail=None):
+        if not self.cur and not tail:
             return
-        dev = self.cur[0][1].device
-        flat = torch.empty(self.cur_fill, dtype=torch.float32, device=dev)
+        dev = self.cur[0][1].device if self.cur else self._dev
+        self._dev = dev
+        flat = torch.empty(self.cur_fill + (len(tail) if tail else 0), dtype=torch.float32, device=dev)
+        if tail:  # a few floats that ride behind the step's last bucket (GradSync's order digest): summed, never divided
+            flat[self.cur_fill:] = torch.tensor(tail, dtype=torch.float32)
+            self.tail_len = len(tail)
         meta, off = [], 0
         for name, g in self.cur:
             k = g.numel()
@@ -237,14 +242,20 @@ class GradBucketer:
         if self.cur_fill >= self.cap:
             self._flush()
 
-    def finish(self):
-        self._flush()
+    def finish(self, tail=None):
+        """tail: optional list of floats appended to the step's last bucket; their sums over the ranks come back as
+        `self.tail_sum` (a device tensor, no host read here)."""
+        self.tail_len, self.tail_sum = 0, None
+        self._flush(tail)
         out = {}
-        for flat, meta, work in self.pending:
+        for i, (flat, meta, work) in enumerate(self.pending):
             if work is not None:
                 work.wait()
+            grads = flat
+            if self.tail_len and i == len(self.pending) - 1:
+                grads, self.tail_sum = flat[:flat.numel() - self.tail_len], flat[flat.numel() - self.tail_len:]
             if self.world > 1:
-                flat.div_(self.world)
+                grads.div_(self.world)
             for name, shape, off, k in meta:
                 if name in out:
                     raise KeyError(f"gradient {name} handed over twice")
@@ -293,22 +304,58 @@ class GradSync:
         b, self.bucketer = self.bucketer, None
         if b is None:
             return
+        tail = None
         if is_dist():
             # the bucket layout is the order in which gradients became ready: it must be the same on every rank, or the
-            # all-reduces above summed unrelated parameters.  One tiny MIN / MAX all-reduce of a digest of that order
+            # all-reduces summed unrelated parameters.  A digest of that order travels as eight floats behind the step's
+            # LAST gradient bucket - its four bytes d and their squares, summed over the ranks: all ranks agree iff
+            # W * sum(d^2) == (sum d)^2 per byte (exact in fp32 up to 256 ranks) - so the check costs no collective of its
+            # own (it was an extra all-reduce + a blocking host read on every step).  The host looks at the sums
+            # at once only while the order is unverified (first step, or this rank's order changed); in steady state they
+            # are copied to pinned memory and looked at one step later, when the copy has long landed.
             import zlib
-            h = zlib.crc32(repr(self._order).encode()) & 0x7FFFFFFF
-            dev = self.named[0][1].device if dist.get_backend(self.kw["group"]) == "nccl" else torch.device("cpu")
-            t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.kw["group"])
-            if int(t[0]) != -int(t[1]):
-                raise RuntimeError("GradSync: the ranks produced their gradients in different orders / sizes (different graphs "
-                                   "per rank?) - the bucketed all-reduces do not line up")
-        avg = b.finish()
+            h = zlib.crc32(repr(self._order).encode())
+            d = [float((h >> (8 * i)) & 0xFF) for i in range(4)]
+            tail = d + [v * v for v in d]
+        self._resolve_order_check()
+        avg = b.finish(tail)
+        if tail is not None:
+            self._order_check(b.tail_sum, h, b.world)
         self.buckets_reduced = b.buckets_reduced
         for n, p in self.named:
             if n in avg:
                 p.grad.copy_(avg[n])
+
+    @staticmethod
+    def _order_agrees(sums, world):
+        return all(abs(world * sums[4 + i] - sums[i] * sums[i]) < 0.5 for i in range(4))
+
+    def _order_check(self, tail_sum, h, world):
+        if h != getattr(self, "_verified_digest", None) or not tail_sum.is_cuda:
+            self.order_checks_blocking = getattr(self, "order_checks_blocking", 0) + (1 if tail_sum.is_cuda else 0)
+            if not self._order_agrees(tail_sum.tolist(), world):  # (the one blocking read: first step / changed order)
+                raise RuntimeError(self._ORDER_MSG)
+            self._verified_digest = h
+            return
+        pin = getattr(self, "_pin", None)
+        if pin is None:
+            pin = self._pin = torch.empty(8, dtype=torch.float32, pin_memory=True)
+        pin.copy_(tail_sum, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending_check = (ev, world)
+
+    def _resolve_order_check(self):
+        """Last step's deferred look at the digest sums (its copy was queued a whole step ago)."""
+        pc, self._pending_check = getattr(self, "_pending_check", None), None
+        if pc is not None:
+            pc[0].synchronize()
+            if not self._order_agrees(self._pin.tolist(), pc[1]):
+                self._verified_digest = None
+                raise RuntimeError(self._ORDER_MSG)
+
+    _ORDER_MSG = ("GradSync: the ranks produced their gradients in different orders / sizes (different graphs per rank?) - "
+                  "the bucketed all-reduces do not line up")
 
     def remove(self):
         for h in self.handles:

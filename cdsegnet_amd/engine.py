@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import CdsegError
+from ._lib import CdsegError, DuplicateVoxelsError
 
 CURVES = ("z", "z-trans", "hilbert", "hilbert-trans")
 
@@ -399,8 +399,9 @@ class Engine:
                 c = cb.q_channels
                 w["x.feat_scale"] = torch.full((c,), cb.tm_feat, dtype=torch.float32, device=device)
                 w["x.feat_zero"] = torch.zeros(c, dtype=torch.float32, device=device)
-            elif (hasattr(ops, "block_rr_pack") and ops.block_rr_ok(cb.q_channels, T) and ops.block_rr_head_on(cb.q_channels)
-                  and w["x.fc1.w"].shape[0] == 4 * cb.q_channels):
+            elif (hasattr(ops, "block_rr_pack") and ops.block_rr_ok(cb.q_channels, T) and cb.q_channels in ops.DEEP_CHANNELS
+                  and w["x.fc1.w"].shape[0] == 4 * cb.q_channels):  # (deep.hip's streamed-weight image only: the LDS-resident
+                # C = 32 / 64 pack needs the head weights too)
                 # the cross block's tail (x += proj(attn); h = LN(x); x += MLP(h), ptv3.py:1205-1222) has a Block tail's
                 # shape: one launch on the streamed-weight kernel (csrc/deep.hip) instead of three GEMMs + their second passes
                 _, w["x.tail_img"] = ops.block_rr_pack(cb.q_channels, None, None, w["x.proj.w"], w["x.fc1.w"], w["x.fc2.w"])
@@ -556,8 +557,10 @@ class Engine:
             if flat[-1]:
                 # the model's input contract (GridSample upstream, structure.py:39-102 downstream): one point per voxel.
                 # The kernel maps and the derived coarse orders assume it - refuse instead of computing something else
-                raise CdsegError(f"input has {flat[-1]} duplicate voxels (points sharing (batch, grid_coord) with another "
-                                 f"point): the model expects one point per voxel - voxelise first (GridSample)")
+                # (the training graph catches this one and folds the surplus points onto their voxel, train_graph.py)
+                raise DuplicateVoxelsError(
+                    f"input has {flat[-1]} duplicate voxels (points sharing (batch, grid_coord) with another "
+                    f"point): the model expects one point per voxel - voxelise first (GridSample)", flat[-1])
             meta_h = [flat[i * (1 + nb):(i + 1) * (1 + nb)] for i in range(len(coarse))]
             host = [r[0] for r in meta_h] + [v for r in meta_h for v in r[1:]]
             for i, cum in enumerate(coarse):

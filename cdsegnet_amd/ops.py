@@ -587,7 +587,10 @@ def attn_tail_fused(o, wp, bp, ln_g, ln_b, w1, b1, w2, b2, x, xc=None, eps=1e-5)
     return x
 
 
-DEEP512_MIN_ROWS = 2560  # include/cdseg.h CDSEG_DEEP512_MIN_ROWS: below, a C = 512 Block keeps the separate GEMM launches
+# include/cdseg.h CDSEG_DEEP512_MIN_ROWS: below, a C = 512 Block keeps the separate GEMM launches.  Experimental builds of the
+# library read the CDSEG_DEEP512_MIN_ROWS environment knob (csrc/runtime.hip); the binding path follows the same variable so
+# that the two executors never disagree under an A/B run
+DEEP512_MIN_ROWS = int(os.environ.get("CDSEG_DEEP512_MIN_ROWS", 2560))
 DEEP_CHANNELS = (128, 256, 512)  # deep-stage head / tail kernels (csrc/deep.hip): weights streamed L2 -> registers
 
 

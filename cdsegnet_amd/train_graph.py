@@ -23,10 +23,13 @@ statistics), GELU between them, the swish timestep MLP on B rows, row masks of s
 (C -> classes) heads, and the criteria (cdsegnet_amd.losses).  All integer work - serialization, pooling structure,
 kernel maps, padded patch plans - is the inference engine's plan (Engine.build_plan), shared with the inference path.
 """
+import warnings
+
 import torch
 import torch.nn.functional as F
 
 from . import engine as _engine
+from ._lib import DuplicateVoxelsError
 from . import ops
 from .losses import build_criteria
 
@@ -218,6 +221,25 @@ def _bn_gelu(x, bn):
     return F.gelu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps))
 
 
+def voxel_representatives(grid, offset):
+    """Points that share a (batch element, grid_coord) voxel -> (keep, rep, offset_u): `keep` = indices of the first point
+    (caller's order) of every voxel, ascending; `rep[i]` = position in `keep` of point i's voxel; `offset_u` = cumulative
+    point counts of the kept points per batch element.  torch device ops (training path only)."""
+    n, dev = grid.shape[0], grid.device
+    ar = torch.arange(n, device=dev)
+    batch = torch.bucketize(ar, offset.to(dev), right=True)
+    g = grid.long()
+    key = ((batch << 17 | g[:, 0]) << 17 | g[:, 1]) << 17 | g[:, 2]  # grid < 2^16 per axis (structure.py:74), batch < 2^12
+    _, inverse = torch.unique(key, return_inverse=True)
+    first = torch.full((int(inverse.max()) + 1,), n, dtype=torch.long, device=dev).scatter_reduce_(0, inverse, ar, "amin")
+    keep = first.sort().values
+    pos = torch.empty(n, dtype=torch.long, device=dev)
+    pos[keep] = torch.arange(keep.numel(), device=dev)
+    rep = pos[first[inverse]]
+    offset_u = torch.bincount(batch[keep], minlength=offset.numel()).cumsum(0).to(offset.dtype)
+    return keep, rep, offset_u
+
+
 def feat_is_cuda(input_dict):
     return bool(getattr(input_dict.get("feat"), "is_cuda", False))
 
@@ -383,7 +405,28 @@ class TrainGraph:
             masks = {k: list(v) for k, v in masks.items()}
         n_orders = len(bb.order)
         grid = input_dict["grid_coord"]
-        plan = self.eng.build_plan(grid, offset.to(torch.int64), offset_host, n)
+        rep = None
+        try:
+            plan = self.eng.build_plan(grid, offset.to(torch.int64), offset_host, n)
+        except DuplicateVoxelsError as e:
+            # Mix3D (datasets/utils.py:51-54, mix_prob = 0.8 in every shipped CDSegNet training config) merges two scenes into
+            # one batch element; both grids start at 0, so some voxels hold a point of each.  spconv tolerates that (its hash
+            # keeps one row per voxel as the neighbour, every row is convolved); the kernel maps here need one point per
+            # voxel, so the surplus points are FOLDED onto their voxel: the network runs on the first point (caller's order) of
+            # every voxel, and every folded point reads its representative's prediction - it still enters the loss with its own
+            # label, and its gradient flows into the shared row.
+            keep, rep, offset_u = voxel_representatives(grid, offset)
+            if not getattr(self, "_warned_duplicates", False):
+                self._warned_duplicates = True
+                warnings.warn(f"training batch with {e.count} points in already occupied voxels (Mix3D): folded onto the "
+                              f"first point of their voxel (cdsegnet_amd/train_graph.py)")
+            feat, coord, grid = feat[keep], coord[keep], grid[keep]
+            n, offset_in = feat.shape[0], offset
+            offset = offset_u
+            offset_host = [int(v) for v in offset.cpu().tolist()]
+            if "noise" in draws:
+                draws = dict(draws, noise=torch.as_tensor(draws["noise"], dtype=torch.float32)[keep.cpu()])
+            plan = self.eng.build_plan(grid, offset.to(torch.int64), offset_host, n)
         lv0 = plan.levels[0]
         inv0 = torch.empty(n, dtype=torch.long, device=dev)
         inv0[plan.perm0.long()] = torch.arange(n, device=dev)
@@ -468,6 +511,11 @@ class TrainGraph:
             nst = dec_stage(nst, "n", s, None)
         n_phys = F.linear(nst.x, bb._n_head.weight, bb._n_head.bias) if isinstance(bb._n_head, torch.nn.Linear) else nst.x
         point["n_pred"] = n_phys[inv0]
+        if rep is not None:  # folded duplicates: back to the caller's N rows (and its offsets, which the criteria sample by)
+            point["offset"] = offset_in
+            for k in ("n_pred", "c_pred", "c_target"):
+                if point.get(k) is not None:
+                    point[k] = point[k][rep]
         point["n_target"] = input_dict["segment"]
         loss = self.criteria(point)
         return dict(loss=loss, n_pred=point["n_pred"], c_pred=point.get("c_pred"), c_target=point.get("c_target"))

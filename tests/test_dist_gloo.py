@@ -284,3 +284,41 @@ def test_data_parallel_training_step_two_ranks_gloo(tmp_path):
         assert torch.equal(r0["got"][k], r1["got"][k]), k
         r = r0["ref"][k]
         assert float((r0["got"][k] - r).abs().max()) <= 1e-5 * max(1e-3, float(r.abs().max())), k
+
+
+def _order_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(8, 8, bias=False), torch.nn.Linear(8, 8, bias=False))
+        sync = cdist.GradSync(model, bucket_bytes=1 << 20)
+        res = {}
+        # step 1: both ranks hand their gradients over in the same order; step 2: rank 1 in the opposite order (two
+        # parameters of equal size, so the all-reduces still pair up - only the digest can notice)
+        for step, flip in ((1, False), (2, rank == 1)):
+            model.zero_grad()
+            for p in model.parameters():
+                p.grad = torch.full_like(p, float(rank + 1))
+            params = list(model.named_parameters())
+            for (n, p) in (params[::-1] if flip else params):
+                sync._hook(n)(p)
+            try:
+                sync.finish()
+                res[step] = float(model[0].weight.grad[0, 0])
+            except RuntimeError as e:
+                res[step] = str(e)
+        torch.save(res, os.path.join(out_dir, f"order{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_notices_ranks_that_disagree_on_the_gradient_order(tmp_path):
+    """The order digest rides behind the last gradient bucket (no collective of its own): agreeing ranks get the
+    mean, ranks whose hand-over order differs get a RuntimeError on every rank."""
+    port = _free_port()
+    mp.spawn(_order_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), f"order{r}.pt"))
+        assert res[1] == 1.5
+        assert isinstance(res[2], str) and "different orders" in res[2]

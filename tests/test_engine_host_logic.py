@@ -610,3 +610,62 @@ def test_training_forward_in_eval_mode_leaves_the_model_untouched(monkeypatch):
         model(dict(inp), draws=dict(draws))
     changed = [k for k, v in model.named_buffers() if not torch.equal(v, buffers[k])]
     assert any(k.endswith("num_batches_tracked") for k in changed)  # ... while train mode does update them
+
+
+def test_training_forward_folds_mix3d_duplicates_instead_of_raising(monkeypatch):
+    """the reference's `point_collate_fn` merges pairs of scenes into one batch element with probability
+    mix_prob = 0.8 (Mix3D, datasets/utils.py:51-54); both grids start at 0, so voxels coincide.  Inference refuses duplicate
+    voxels (one point per voxel is its input contract); the TRAINING forward must not: surplus points are folded onto the
+    first point of their voxel - the network runs on the unique voxels, every folded point reads its representative's
+    prediction and enters the loss with its own label."""
+    import warnings
+    import cdsegnet_amd.engine as engine
+    import cdsegnet_amd.train_graph as tg
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.registry import build_model
+    monkeypatch.setattr(engine, "ops", emu_ops)
+    monkeypatch.setattr(tg, "ops", emu_ops)
+    cfg = configs.mini_config()
+    cfg["backbone"]["enable_flash"] = False
+    cfg["criteria"] = [dict(type="MSELoss", loss_weight=1.0, ignore_index=-1, batch_sample_point=-1),
+                       dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]
+    cfg["loss_type"] = "EW"
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=4))
+    model.eval()  # deterministic: running BatchNorm statistics, no DropPath
+    a, b, c = (synth.room_scene(s, 400, num_classes=cfg["num_classes"]) for s in (1, 2, 3))
+    cat = lambda k: np.concatenate([a[k], b[k], c[k]])
+    na, nb, nc = len(a["coord"]), len(b["coord"]), len(c["coord"])
+    inp = {k: torch.as_tensor(cat(k)) for k in ("coord", "grid_coord", "feat")}
+    inp["segment"] = torch.as_tensor(cat("segment").astype(np.int64))
+    # Mix3D: scenes a and b share batch element 0 (offset[1:-1:2] + offset[-1]), scene c is element 1
+    inp["offset"] = torch.as_tensor(np.array([na + nb, na + nb + nc]))
+    n = na + nb + nc
+    keep, rep, offset_u = tg.voxel_representatives(inp["grid_coord"], inp["offset"])
+    assert 0 < len(keep) < n, "the two merged rooms must share voxels for this test to mean anything"
+    assert int(offset_u[-1]) == len(keep) and torch.equal(rep[keep], torch.arange(len(keep)))
+    noise = np.random.default_rng(0).standard_normal((n, cfg["c_in_channels"])).astype(np.float32)
+    draws = dict(ts=np.array([[17], [403]]), noise=noise, perms=[[0, 1, 2, 3]] * 8)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = model(dict(inp), draws=dict(draws))
+    assert any("folded" in str(x.message) for x in w)
+    assert out["n_pred"].shape[0] == n and out["c_pred"].shape[0] == n and torch.isfinite(out["loss"])
+    assert torch.equal(out["n_pred"], out["n_pred"][keep][rep])  # a folded point reads its voxel's prediction
+    # ... and the kept points see exactly what a batch of the unique voxels alone gives
+    uniq = {k: v[keep] for k, v in inp.items() if k != "offset"}
+    uniq["offset"] = offset_u
+    ref = model(uniq, draws=dict(draws, noise=noise[keep.numpy()]))
+    assert float((out["n_pred"][keep] - ref["n_pred"]).detach().abs().max()) < 1e-6
+    model.train()
+    out = model(dict(inp), draws=dict(draws))
+    out["loss"].backward()
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    assert sum(p.grad is not None for p in model.parameters()) > 400
+    # inference keeps its input contract
+    from cdsegnet_amd._lib import DuplicateVoxelsError
+    model.eval()
+    model.precision = "fp32"
+    with pytest.raises(DuplicateVoxelsError):
+        model.inference({k: v for k, v in inp.items() if k != "segment"}, eval=False)

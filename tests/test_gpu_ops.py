@@ -654,6 +654,28 @@ def test_cross_attention_vs_oracle(ops, lp):
         assert err < tol * (1 + mag)
 
 
+@LPS
+def test_attention_16bit_output_rows_that_are_only_8_byte_aligned(ops, lp):
+    """a 16-bit output with ldo % 8 != 0 (8-byte aligned rows) was a valid call before the one-store epilogue and
+    must stay one: the kernel falls back to the two 8-byte pieces a lane holds.  Same values as the aligned call."""
+    g = torch.Generator().manual_seed(3)
+    n, H = 1500, 2
+    C = 16 * H
+    qkv = torch.randn(n, 3 * C, generator=g).to(LP()).cuda()
+    order = torch.randperm(n, generator=g).numpy()
+    offs = dev(np.array([0, n], dtype=np.int32))
+    offs_pad = dev(np.array([0, 2048], dtype=np.int32))
+    gq, wq = ops.pad_plan(dev(order.astype(np.int32)), offs, offs_pad, 1024, 2048)
+    ps = dev(np.array([0, 1024, 2048], dtype=np.int32))
+    ref = torch.empty(n, C, dtype=LP(), device="cuda")
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], gq, gq, wq, ps, H, 1024, 0.25, ref)
+    wide = torch.zeros(n, C + 4, dtype=LP(), device="cuda")  # row stride 36 elements = 72 bytes: 8- but not 16-byte aligned
+    out = wide[:, :C]
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], gq, gq, wq, ps, H, 1024, 0.25, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and float(wide[:, C:].abs().max()) == 0.0
+
+
 def test_attention_softmax_is_shift_safe(ops):
     """Large score magnitudes (|s| ~ 60): the two-pass max must keep exp in range (no NaN / inf)."""
     g = torch.Generator().manual_seed(0)

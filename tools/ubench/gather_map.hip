@@ -48,6 +48,76 @@ __global__ __launch_bounds__(512) void kb(const char* src, unsigned long long ro
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+
+// Third kernel (round 6): the same window mix / dead rows as kb, with (a) map R - lane -> (row lane >> 3, chunk lane & 7): an
+// instruction = 8 whole 128-byte rows, one cache line per 8 lanes - as plain global loads (DMA = 0) and (b) the same map as
+// LDS-DMA (global_load_lds_dwordx4, DMA = 1: lane-linear LDS destination, D pieces in flight per wave, then vmcnt(0)); dead
+// rows read a hot zero line.  Answers: is the wide conv's gather bound by tag look-ups per instruction (then R / DMA are 2 - 8x
+// cheaper than M), or by latency / outstanding misses (then nothing moves)?
+template <int D, int DMA, int DEAD, int HOT>
+__global__ __launch_bounds__(1024) void kr(const char* src, unsigned long long rows, int iters, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned long long state = (blockIdx.x * 64ull + wave) * 0x9E3779B97F4A7C15ull + 12345ull;
+  const int slot = lane >> 3, chunk = lane & 7;
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * (D * 1024);
+  unsigned acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    const char* p[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      state = state * 6364136223846793005ull + 1442695040888963407ull;
+      const unsigned long long span = ((state >> 56) & 15) < (unsigned)HOT ? 8192ull : rows;
+      unsigned long long r = (state >> 24) & (span - 1);
+      r = (r > span - 16 ? r - 16 : r) + slot + 8 * (d & 1);
+      const bool dead = (((state >> 12) + (slot + 8 * (d & 1)) * 7) & 15) < (unsigned)DEAD;
+      p[d] = dead ? src + chunk * 16 : src + r * 128 + chunk * 16;
+      asm volatile("" : "+v"(p[d]));
+    }
+    if (DMA) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(p[d]), "s"(lds_base + d * 1024) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      acc ^= *reinterpret_cast<const unsigned*>(smem + wave * (D * 1024) + lane * 4);
+    } else {
+      u4 v[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) v[d] = *reinterpret_cast<const u4*>(p[d]);
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc ^= v[d][0] ^ v[d][1] ^ v[d][2] ^ v[d][3];
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int D, int DMA, int DEAD, int HOT>
+static void runr(const char* src, size_t span, unsigned* sink, int waves) {
+  const int iters = 400;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  hipFuncSetAttribute((const void*)kr<D, DMA, DEAD, HOT>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * D * 1024);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kr<D, DMA, DEAD, HOT>), dim3(256), dim3(waves * 64), DMA ? waves * D * 1024 : 0, 0, src,
+                       (unsigned long long)(span / 128), iters, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  const double instr_per_cu = (double)waves * D * iters;
+  printf("map R (8 rows x 128 B) %s, %2d / 16 sets hot, %2d / 16 rows dead, W=%d D=%2d: %6.1f ns per wave-instruction and CU (%5.1f cycles "
+         "at 2.1 GHz)\n", DMA ? "LDS-DMA     " : "global loads", HOT, DEAD, waves, D, best * 1e6 / instr_per_cu,
+         best * 1e6 / instr_per_cu * 2.1);
+}
+
 template <int D, int MAP, int SCATTER, int PERMUTE>
 __global__ __launch_bounds__(512) void k(const char* src, unsigned long long rows /* 128-byte rows, a power of two */, int iters,
                                          unsigned* sink) {
@@ -162,6 +232,15 @@ int main() {
     runb<12, 0, 0, 14>(buf, span, sink); runb<12, 1, 0, 14>(buf, span, sink);
     runb<12, 0, 6, 14>(buf, span, sink); runb<12, 1, 6, 14>(buf, span, sink);
     runb<12, 0, 6, 0>(buf, span, sink);  runb<12, 1, 6, 0>(buf, span, sink);
+    // depth: is the 89 %-hit case latency bound? (4 / 12 / 24 instructions in flight per wave)
+    runb<4, 0, 6, 14>(buf, span, sink);  runb<24, 0, 6, 14>(buf, span, sink);
+    runb<4, 1, 6, 14>(buf, span, sink);  runb<24, 1, 6, 14>(buf, span, sink);
+    // whole-row map, plain and as LDS-DMA
+    runr<12, 0, 0, 16>(buf, span, sink, 8); runr<12, 1, 0, 16>(buf, span, sink, 8);
+    runr<12, 0, 6, 14>(buf, span, sink, 8); runr<12, 1, 6, 14>(buf, span, sink, 8);
+    runr<4, 1, 6, 14>(buf, span, sink, 8);  runr<8, 1, 6, 14>(buf, span, sink, 8);
+    runr<12, 1, 6, 14>(buf, span, sink, 4); runr<8, 1, 6, 14>(buf, span, sink, 16);
+    runr<12, 0, 6, 0>(buf, span, sink, 8);  runr<12, 1, 6, 0>(buf, span, sink, 8);
     hipFree(buf);
   }
   return 0;
