@@ -185,48 +185,56 @@ def parity_vs_cpu(model, dev, cpu_case, precisions):
     return out
 
 
-def secondary_roofline(iso):
-    """VALU + transcendental issue bound of the attention kernel ('secondary bound to report: transcendental
-    rate'): a 32x32 score tile is 16 v_exp_f32 + 8 v_cvt_pk_bf16_f32 next to 3 MFMAs; tools/ubench/pipes.hip runs exactly
-    that mix with no dependencies and no memory, 4 waves per SIMD on every SIMD - its cycles per tile and SIMD are the
-    floor of the instruction mix.  Tracked output: profiles/r03_ubench_pipes.txt; the clock the kernel holds:
-    GRBM_GUI_ACTIVE / duration of profiles/r03_pmc_attn.txt (offline)."""
+def agreement_leg(model, scene_dict, n, cfg, precision):
+    """One bench scene through `precision` and through the exact-fp32 HIP path on the same draws: arg-max agreement and
+    logit differences (random-init weights give near-ties: the margins say how far apart the flipped classes were)."""
+    keep_p, keep_n = model.precision, model.noise_source
+    gen = torch.Generator().manual_seed(54421566)
+    draws = dict(noise=torch.normal(0, 1, size=(n, cfg["c_in_channels"]), dtype=torch.float32, generator=gen),
+                 perms=[torch.randperm(4, generator=gen).tolist() for _ in range(8)])
+    try:
+        model.noise_source = "torch_cpu"
+        model.precision = precision
+        a = model.inference(dict(scene_dict), eval=False, draws=dict(draws))["seg_logits"].clone()
+        model.precision = "fp32"
+        b = model.inference(dict(scene_dict), eval=False, draws=dict(draws))["seg_logits"]
+    finally:
+        model.precision, model.noise_source = keep_p, keep_n
+    top2 = b.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]  # fp32 top-1 / top-2 margin of every point
+    flipped = a.argmax(1) != b.argmax(1)
+    return dict(points=n, precision=precision,
+                argmax_agreement=float((~flipped).float().mean()),
+                max_abs_logit_diff=float((a - b).abs().max()), rms_logit_diff=float((a - b).pow(2).mean().sqrt()),
+                mean_abs_logit=float(b.abs().mean()),
+                fp32_margin_median=float(margin.median()),
+                points_with_margin_below_0p01=float((margin < 0.01).float().mean()),
+                largest_margin_that_flipped=float(margin[flipped].max()) if bool(flipped.any()) else 0.0,
+                reference="exact-fp32 HIP path (within 5e-6 of the reference's CPU logits, tests/)")
+
+
+def attention_ceiling(achieved_tflops):
+    """ONE ceiling for the attention kernel, from the issue model of its key loop: a 32 x 32 score tile
+    (65 536 algorithmic FLOP) is 16 v_exp_f32 + 8 v_cvt_pk_bf16_f32 next to 3 MFMAs, and the VALU / transcendental side is the
+    longer one - tools/ubench/pipes.hip runs exactly that mix with no dependences and no memory, 4 waves per SIMD on every
+    SIMD: `cycles_per_tile_simd` (tracked: profiles/r03_ubench_pipes.txt).  At the clock the KERNEL holds (GRBM_GUI_ACTIVE /
+    duration of an offline rocprofv3 --pmc pass, profiles/r03_attention_clock.json) that is the ceiling in TFLOP/s;
+    `frac_of_ceiling` = achieved / ceiling.  (Context, not a second fraction: run flat out, the mix itself pulls the chip down
+    to ~1.5 GHz - `mix_alone_ns_per_tile_simd` - so in wall time the ceiling is lower still.)"""
     import re
     try:
         txt = open(os.path.join(ROOT, "profiles", "r03_ubench_pipes.txt")).read()
         m = re.search(r"round-3 tile\)\s+W=1:.*?W=4:\s+([0-9.]+) cyc/iter/SIMD\s+([0-9.]+) ns \(([0-9.]+) GHz\)", txt)
-        floor_cyc, floor_ns, floor_ghz = float(m.group(1)), float(m.group(2)), float(m.group(3))
-    except Exception:  # noqa: BLE001 - the file is part of the repository; without it there is no secondary line
+        cyc, mix_ns, mix_ghz = float(m.group(1)), float(m.group(2)), float(m.group(3))
+        clock = float(json.load(open(os.path.join(ROOT, "profiles", "r03_attention_clock.json")))["ghz"])
+    except Exception:  # noqa: BLE001 - both files are part of the repository; without them the line carries no ceiling
         return None
-    clock = None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_attention_clock.json")))
-        clock = float(pj["ghz"])
-    except Exception:  # noqa: BLE001
-        pass
-    tiles = iso["attn_work"] / 65536.0  # 4 * 32 * 32 * 16 FLOP per 32-key x 32-query tile
-    ns_ach = iso["attn_ms"] * 1e6 / (tiles / 1024.0)  # per tile and SIMD (1024 SIMDs)
-    out = {"bound": "valu+transcendental issue", "tiles_per_forward": tiles, "floor_cycles_per_tile_simd": floor_cyc,
-           "ns_per_tile_achieved": ns_ach, "source": "profiles/r03_ubench_pipes.txt ('3 mfma + 16 exp + 8 cvt_pk', W = 4)",
-           # with the matrix and the VALU / transcendental pipes both busy the chip holds only ~1.5 GHz (power): the floor of
-           # the mix in WALL TIME is what the micro-benchmark measured, not its cycle count at the kernel's higher clock
-           "floor_ns_per_tile_simd_measured": floor_ns, "floor_clock_ghz": floor_ghz, "frac_wall_time": floor_ns / ns_ach}
-    try:  # the kernel's own key loop run alone with continuously claimed tiles (tools/ubench/attn_loop.hip): what the loop's
-        #   dependent chain QK -> exp -> pack -> PV costs a SIMD in steady state, without staging, launch ramp or epilogues
-        lt = open(os.path.join(ROOT, "profiles", "r03_ubench_attn_loop.txt")).read()
-        m = re.search(r"2 tiles in flight, 8 waves x 2 blocks, dynamic\s+4 waves/SIMD: launch\s+[0-9.]+ ns per tile and SIMD =\s+([0-9.]+) cycles", lt)
-        out["key_loop_alone_cycles_per_tile_simd"] = float(m.group(1))
-        out["key_loop_source"] = "profiles/r03_ubench_attn_loop.txt ('2 tiles in flight, 8 waves x 2 blocks, dynamic')"
-    except Exception:  # noqa: BLE001
-        pass
-    if clock:
-        if "key_loop_alone_cycles_per_tile_simd" in out:
-            out["frac_of_own_key_loop"] = out["key_loop_alone_cycles_per_tile_simd"] / (ns_ach * clock)
-        out.update({"kernel_clock_ghz": clock, "ns_per_tile_floor": floor_cyc / clock, "cycles_per_tile_achieved": ns_ach * clock,
-                    "frac": floor_cyc / (ns_ach * clock), "clock_source": "profiles/r03_attention_clock.json (GRBM_GUI_ACTIVE / duration, offline rocprofv3 --pmc pass)"})
-    else:
-        out.update({"ns_per_tile_floor_at_2.4GHz": floor_cyc / 2.4, "frac_at_2.4GHz": floor_cyc / 2.4 / ns_ach})
-    return out
+    tflops = 65536.0 * 1024.0 * clock * 1e9 / cyc / 1e12  # 1024 SIMDs
+    return {"tflops": tflops, "frac_of_peak": tflops / PEAK_TFLOPS["bf16"], "frac_of_ceiling": achieved_tflops / tflops,
+            "model": "16 v_exp_f32 + 8 v_cvt_pk + 3 MFMA per 32x32 tile: VALU / transcendental issue bound",
+            "cycles_per_tile_simd": cyc, "kernel_clock_ghz": clock, "mix_alone_ns_per_tile_simd": mix_ns,
+            "mix_alone_clock_ghz": mix_ghz,
+            "sources": "profiles/r03_ubench_pipes.txt ('3 mfma + 16 exp + 8 cvt_pk', W = 4), profiles/r03_attention_clock.json"}
 
 
 def paper_protocol(args, model, cfg, dev, rank, world, dist):
@@ -383,6 +391,12 @@ def main():
             dist.destroy_process_group()
         return
     assert have_gpu, "bench.py needs an MI355X"
+    # host side of a rank: NUMA-local CPUs of this rank's GPU, a cap on torch's intra-op threads, blocking host
+    # reads - applied when there is more than one rank (a single rank keeps the process as the driver started it), reported
+    # in the line either way
+    from cdsegnet_amd import dist as cdist0
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    host_plan, host_applied = cdist0.setup_rank_host(local_rank, local_world, apply=world > 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -472,7 +486,7 @@ def main():
             for _ in range(2):
                 model.inference(dict(fwd), eval=False)
             torch.cuda.synchronize()
-            a0, c0, ab0 = eng.attn_work, eng.conv_bytes, eng.attn_bytes
+            a0, c0, ab0, cd0 = eng.attn_work, eng.conv_bytes, eng.attn_bytes, eng.conv_deep_bytes
             per, walls = [], []
             for attempt in range(3):  # the five forwards must agree (max / min of the attention totals <= 1.15): a clock
                 per, walls = [], []   # dip or an allocator stall inside one of them is a reason to measure again
@@ -482,17 +496,20 @@ def main():
                     model.inference(dict(fwd), eval=False)
                     torch.cuda.synchronize()
                     walls.append(1e3 * (time.perf_counter() - t1))
-                    per.append(ops.prof_summary(ops.PROF_ATTENTION) + ops.prof_summary(ops.PROF_CONV))
+                    per.append(ops.prof_summary(ops.PROF_ATTENTION) + ops.prof_summary(ops.PROF_CONV) +
+                               ops.prof_summary(ops.PROF_CONV_DEEP))
                 ops.attention_prof_enable(False)
                 am = [r[0] for r in per]
                 if max(am) <= 1.15 * min(am):
                     break
             nrun = (attempt + 1) * reps
             ams, al = sorted(per, key=lambda r: r[0])[reps // 2][:2]
-            cms, cl = sorted(per, key=lambda r: r[2])[reps // 2][2:]
+            cms, cl = sorted(per, key=lambda r: r[2])[reps // 2][2:4]
+            dms, dl = sorted(per, key=lambda r: r[4])[reps // 2][4:6]
             am = sorted(r[0] for r in per)
             iso = dict(reps=1, attn_ms=ams, attn_launches=al, attn_work=(eng.attn_work - a0) / nrun, conv_ms=cms,
                        conv_launches=cl, conv_bytes=(eng.conv_bytes - c0) / nrun, attn_bytes=(eng.attn_bytes - ab0) / nrun,
+                       deep_ms=dms, deep_launches=dl, deep_bytes=(eng.conv_deep_bytes - cd0) / nrun,
                        points=int(sum(sizes[:args.scenes_per_forward])),
                        attn_ms_all=[round(r[0], 3) for r in per], attn_ms_min=am[0], attn_ms_max=am[-1],
                        attn_spread=am[-1] / am[0], attempts=attempt + 1, forward_wall_ms=float(np.median(walls)),
@@ -558,32 +575,15 @@ def main():
             el2 = time.perf_counter() - t1
             iso["bf16_head"] = dict(points_per_s=pts_per_step * max(3, args.steps // 2) / el2,
                                     ms_per_step=1e3 * el2 / max(3, args.steps // 2), steps=max(3, args.steps // 2))
+            if not args.no_agreement:  # ... and what the 8-bit mantissa costs: the same scene and draws as agreement_vs_fp32 below
+                iso["bf16_head"]["agreement_vs_fp32"] = agreement_leg(model, dicts[0], sizes[0], cfg, "bf16+head")
             model.precision = args.precision
             _lib.activate(variant)
 
     # ---- 16-bit accuracy on a bench scene: same draws through the exact-fp32 HIP path (rank 0)
     agreement = None
     if rank == 0 and low and not args.no_agreement:
-        d0 = dict(dicts[0])
-        gen = torch.Generator().manual_seed(54421566)
-        draws = dict(noise=torch.normal(0, 1, size=(sizes[0], cfg["c_in_channels"]), dtype=torch.float32, generator=gen),
-                     perms=[torch.randperm(4, generator=gen).tolist() for _ in range(8)])
-        model.noise_source = "torch_cpu"
-        a = model.inference(dict(d0), eval=False, draws=dict(draws))["seg_logits"].clone()
-        model.precision = "fp32"
-        b = model.inference(dict(d0), eval=False, draws=dict(draws))["seg_logits"]
-        top2 = b.topk(2, dim=1).values
-        margin = top2[:, 0] - top2[:, 1]  # fp32 top-1 / top-2 margin of every point
-        flipped = a.argmax(1) != b.argmax(1)
-        agreement = dict(points=sizes[0], precision=args.precision,
-                         argmax_agreement=float((~flipped).float().mean()),
-                         max_abs_logit_diff=float((a - b).abs().max()), rms_logit_diff=float((a - b).pow(2).mean().sqrt()),
-                         mean_abs_logit=float(b.abs().mean()),
-                         # random-init weights give near-ties: where the arg-max flips, how far apart were the two classes?
-                         fp32_margin_median=float(margin.median()),
-                         points_with_margin_below_0p01=float((margin < 0.01).float().mean()),
-                         largest_margin_that_flipped=float(margin[flipped].max()) if bool(flipped.any()) else 0.0,
-                         reference="exact-fp32 HIP path (within 5e-6 of the reference's CPU logits, tests/)")
+        agreement = agreement_leg(model, dicts[0], sizes[0], cfg, args.precision)
         model.precision = args.precision
         model.noise_source = "device"
     parity_mode = None
@@ -617,6 +617,12 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    per_rank_rates = None
+    if world > 1:  # every rank's own rate next to the max-over-ranks time the headline uses
+        rates = torch.zeros(world, dtype=torch.float64, device=dev)
+        rates[rank] = pts_per_step * args.steps / elapsed
+        dist.all_reduce(rates, op=dist.ReduceOp.SUM)
+        per_rank_rates = [float(v) for v in rates.tolist()]
     elapsed = float(tmax.item())
     total_pts = int(pts.item())
 
@@ -669,9 +675,10 @@ def main():
                 "kernel_ms_min_median_max": [iso["attn_ms_min"], iso["attn_ms"], iso["attn_ms_max"]],
                 "spread_max_over_min": iso["attn_spread"], "measurement_attempts": iso["attempts"],
                 "stable": bool(iso["attn_spread"] <= 1.15)}
-            sec = secondary_roofline(iso) if low else None
-            if sec:
-                res["roofline"]["secondary"] = sec
+            ceil = attention_ceiling(achieved) if low else None
+            if ceil:
+                res["roofline"]["frac_of_ceiling"] = ceil.pop("frac_of_ceiling")
+                res["roofline"]["ceiling"] = ceil
             wk = iso["work"]
             res["roofline_forward"] = {
                 "what": f"one collated forward of {args.scenes_per_forward} scenes, run alone (the roofline pass above)",
@@ -681,14 +688,26 @@ def main():
                 "mflop_per_point": wk["total"] / iso["points"] / 1e6,
                 "compulsory_bytes": "inputs 60 B / point + logits + the weights once (203 MB in 16 bits): the forward is not HBM-bound as a whole",
                 "flops": "SURVEY 8(d) formulas on the plan's real sizes; sparse convs count occupied neighbours only; the dead c-decoder is not run"}
-            if iso["conv_ms"] > 0:
+            if iso["conv_ms"] > 0:  # the wide stages' weight-stationary convs: HBM / gather bound
                 gbs = iso["conv_bytes"] / (iso["conv_ms"] * 1e-3) / 1e9
                 res["roofline_conv"] = {
                     "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                    "kernel": "conv_ll_kernel<32|64> + gemm_dma_kernel<128 | 256, GATHER> (all k = 3 sparse convs of the forward; the C >= 128 ones - 128 x 128 tiles, C >= 256: 256 x 256 tiles of 8 waves - are bound by the LDS fill path and the matrix pipe, DESIGN 4.2)",
+                    "kernel": "conv_ll_kernel<32 | 64> (k = 3 sparse convs of the C <= 64 stages; in practice bound by the texture "
+                              "path's per-lane tag look-ups of the gathered rows, DESIGN 4.2, profiles/r06_pmc_conv64.txt)",
                     "launches_per_forward": iso["conv_launches"] / r, "kernel_ms_per_forward": iso["conv_ms"] / r,
+                    "avg_launch_us": 1e3 * iso["conv_ms"] / max(1, iso["conv_launches"]),
                     "algorithmic_mb_per_forward": iso["conv_bytes"] / r / 1e6,
                     "bytes": "features in + out, kernel map as stored (27 x int32 per point), weights once"}
+            if iso.get("deep_ms", 0) > 0:  # the C >= 128 convs on the gathered GEMM: MFMA / LDS-DMA bound
+                tf = wk["conv_deep"] / (iso["deep_ms"] * 1e-3) / 1e12
+                res["roofline_conv_deep"] = {
+                    "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                    "kernel": "gemm_dma_kernel<128 | 256, GATHER> (k = 3 sparse convs of the C >= 128 stages: 128 x 128 tiles, "
+                              "C >= 256: 256 x 256 tiles of 8 waves; bound by LDS-DMA pieces per FLOP and the matrix pipe, DESIGN 4.2)",
+                    "launches_per_forward": iso["deep_launches"] / r, "kernel_ms_per_forward": iso["deep_ms"] / r,
+                    "avg_launch_us": 1e3 * iso["deep_ms"] / max(1, iso["deep_launches"]),
+                    "algorithmic_gflop_per_forward": wk["conv_deep"] / 1e9,
+                    "flops": "2 x occupied neighbours x C^2 per row (zero padding of 16-row groups not counted)"}
             res["single_scene_latency_ms"] = iso["latency_ms"]
             res["single_scene_points"] = iso["latency_points"]
             res["paper_protocol"] = {
@@ -718,7 +737,7 @@ def main():
             if "bf16_head" in iso:
                 res["bf16_head"] = dict(iso["bf16_head"], what="the same timed region with precision bf16+head (bfloat16 build "
                                         "of the library; BASELINE.json configs[1] names bf16), run right after the headline")
-            tpath = next((p for p in (os.path.join(ROOT, "profiles", f"r0{k}_attention_traffic.json") for k in (5, 4, 3))
+            tpath = next((p for p in (os.path.join(ROOT, "profiles", f"r0{k}_attention_traffic.json") for k in (6, 5, 4, 3))
                           if os.path.exists(p)), "")
             if low and os.path.exists(tpath):
                 # HBM bytes per launch (mean over every attention launch of this bench's forwards) from separate rocprofv3
@@ -728,6 +747,22 @@ def main():
                     tj = json.load(f)
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tpath)} (offline rocprofv3 --pmc passes over bench.py's own forwards)"
+                # the counters belong to the build they were taken on: stale once the kernel's source is newer than the file
+                src = os.path.join(ROOT, "cdsegnet_amd", "csrc", "attention.hip")
+                res["roofline"]["traffic_stale"] = bool(os.path.getmtime(src) > os.path.getmtime(tpath))
+        if iso and "latency_ms" in iso:
+            # the headline block a reader should see first: `value` needs this build's own `inference_many` (8 scenes collated
+            # per forward, 3 forwards in flight) and the offset_host hint; the REFERENCE's loop (tools/test_*.py unchanged, one
+            # `inference()` per fragment, engines/test.py:197-224) gets the bs = 1 figures below
+            own = res.get("paper_protocol", {}).get("own_process", {})
+            res["headline"] = {
+                "value_points_per_s": res["value"],
+                "value_needs": "DefaultSegmentorV2.inference_many(batch=8, lanes=3) + the offset_host key (INTEGRATION.md)",
+                "bs1_ms_per_scene": own.get("ms_per_scene", 1e3 * iso["paper_s"] / 312.0),
+                "bs1_points_per_s": own.get("points_per_s", pts_per_step / scenes_per_step * 312.0 / iso["paper_s"]),
+                "bs1_what": "the reference's calling pattern: one inference(dict) per scene, the reference's dict, every host "
+                            "sync inside the clock (paper_protocol" + (".own_process" if "ms_per_scene" in own else "") + ")",
+                "bs1_over_value": own.get("points_per_s", pts_per_step / scenes_per_step * 312.0 / iso["paper_s"]) / res["value"]}
         if iso and "host_issue_ms" in iso:
             res["host_issue"] = {
                 "host_issue_ms_per_forward": iso["host_issue_ms"], "host_cpu_ms_per_forward": iso["host_cpu_ms"],
@@ -737,6 +772,15 @@ def main():
                 "what": "one Python thread issues every launch of a rank (no data-path collective): wall / CPU time of that "
                         "thread per collated forward, GPU idle at the start, no synchronisation at the end; host_duty = issue "
                         "time of a step's forwards / the step's GPU-bound wall time.  N ranks need N such threads"}
+        res["host_plan"] = {
+            "rank0": {"numa_node": host_plan["numa_node"], "cpus": len(host_plan["cpus"]), "first_cpu": host_plan["cpus"][0],
+                      "last_cpu": host_plan["cpus"][-1], "threads": host_plan["threads"], "blocking_sync": host_plan["blocking_sync"]},
+            "applied": host_applied,
+            "what": "per rank: CPUs of its GPU's NUMA node (split among the ranks on that node), torch intra-op thread cap, "
+                    "hipDeviceScheduleBlockingSync - cdsegnet_amd.dist.rank_host_plan; applied when n_gpus > 1"}
+        if world > 1:
+            res["per_rank_points_per_s"] = per_rank_rates
+            res["slowest_rank_ms_per_step"] = 1e3 * elapsed / args.steps
         if agreement:
             res["agreement_vs_fp32"] = agreement
         if parity_mode:

@@ -1458,7 +1458,7 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   const size_t wsb = p.ws ? a->ws_bytes : 0;
   hipStream_t s = (hipStream_t)stream;
   CdsegProfToken tok;
-  const bool prof = a->nbr && a->kvol == 27 && cdseg_prof_begin(CDSEG_PROF_CONV, s, &tok);  // the k = 3 sparse convs
+  const bool prof = a->nbr && a->kvol == 27 && cdseg_prof_begin(CDSEG_PROF_CONV_DEEP, s, &tok);  // the k = 3 sparse convs on this kernel
   int rc = CDSEG_ERR_ARG;
   if (a->compute_dtype == CDSEG_BF16) rc = a->nbr ? launch<bf16_t, true>(p, wsb, s) : launch<bf16_t, false>(p, wsb, s);
   else if (a->compute_dtype == CDSEG_F32) rc = a->nbr ? launch<float, true>(p, wsb, s) : launch<float, false>(p, wsb, s);

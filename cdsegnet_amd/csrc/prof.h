@@ -5,8 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #define CDSEG_PROF_ATTENTION 0
-#define CDSEG_PROF_CONV 1
-#define CDSEG_PROF_CLASSES 2
+#define CDSEG_PROF_CONV 1       // weight-stationary k = 3 convs of the wide stages (conv.hip: HBM / gather bound)
+#define CDSEG_PROF_CONV_DEEP 2  // gathered-GEMM k = 3 convs, C >= 128 (gemm.hip: MFMA / LDS-DMA bound)
+#define CDSEG_PROF_CLASSES 3
 
 struct CdsegProfToken {
   hipEvent_t e0;

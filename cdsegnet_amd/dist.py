@@ -41,6 +41,133 @@ def shard_scenes(sizes, rank=None, world=None):
     return mine
 
 
+# ------------------------------------------------------------------ host side of a rank (the scaling risk)
+def _parse_cpulist(text):
+    """'0-63,128-191' -> [0, ..., 63, 128, ..., 191] (sysfs cpulist format)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def read_host_topology(pci_bus_ids, sysfs="/sys"):
+    """What `rank_host_plan` needs from the host, read from sysfs: (gpu_numa, numa_cpus, all_cpus) - the NUMA node of every
+    GPU of the node (by PCI bus id '0000:c1:00.0'; -1 = unknown, e.g. a single-socket host or a container without the
+    file) and the CPU list of every node.  `all_cpus` = the CPUs this process may run on (its current affinity)."""
+    import os
+    gpu_numa = []
+    for bus in pci_bus_ids:
+        try:
+            with open(os.path.join(sysfs, "bus", "pci", "devices", bus.lower(), "numa_node")) as f:
+                gpu_numa.append(int(f.read().strip()))
+        except (OSError, ValueError):
+            gpu_numa.append(-1)
+    numa_cpus = {}
+    node_dir = os.path.join(sysfs, "devices", "system", "node")
+    try:
+        for name in sorted(os.listdir(node_dir)):
+            if name.startswith("node") and name[4:].isdigit():
+                with open(os.path.join(node_dir, name, "cpulist")) as f:
+                    numa_cpus[int(name[4:])] = _parse_cpulist(f.read())
+    except OSError:
+        pass
+    try:
+        all_cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        all_cpus = list(range(os.cpu_count() or 1))
+    return gpu_numa, numa_cpus, all_cpus
+
+
+def rank_host_plan(local_rank, local_world, gpu_numa, numa_cpus, all_cpus, max_threads=8):
+    """Which host CPUs rank `local_rank` of `local_world` ranks on this node should run on, and how many intra-op threads it
+    may start.  One process per GPU with no data-path collective shares only the HOST with its neighbours (one Python thread
+    per rank issues every launch), so the plan is the reference launcher's one-process-per-GPU layout
+    (pointcept/engines/launch.py:74-135) plus what that launcher leaves to the OS:
+
+      * cpus     the rank's share of the CPUs of ITS GPU's NUMA node (the ranks whose GPUs hang off the same node split that
+                 node's allowed CPUs into equal contiguous slices, in local-rank order); GPUs with an unknown node (-1), or a
+                 node without allowed CPUs, split ALL allowed CPUs the same way.  Never empty.
+      * threads  torch intra-op threads: min(max_threads, len(cpus)) - without a cap every rank starts one thread per host
+                 CPU (256 on the GPU boxes): 8 ranks x 256 threads for a path whose host work is one thread
+      * blocking_sync  True when there is more than one rank: host reads sleep (hipDeviceScheduleBlockingSync) instead of
+                 spinning on a core a neighbour's issuing thread could use (profiles/r05_host_contention.txt: 42 ms of spin
+                 per forward against 3.9 ms of work with 8 issuers)
+    Pure function of its arguments (tests mock an 8-GPU / 2-socket topology); `apply_rank_host_plan` acts on it."""
+    allowed = set(all_cpus)
+    node = gpu_numa[local_rank] if 0 <= local_rank < len(gpu_numa) else -1
+    pool = sorted(c for c in numa_cpus.get(node, []) if c in allowed) if node >= 0 else []
+    if pool:
+        peers = [r for r in range(local_world) if r < len(gpu_numa) and gpu_numa[r] == node]
+    else:  # unknown node: every rank that could not be placed shares the whole allowed set
+        pool = sorted(allowed)
+        peers = [r for r in range(local_world)
+                 if not (r < len(gpu_numa) and gpu_numa[r] >= 0 and any(c in allowed for c in numa_cpus.get(gpu_numa[r], [])))]
+    if local_rank not in peers:
+        peers = sorted(peers + [local_rank])
+    k, m = peers.index(local_rank), len(peers)
+    lo, hi = (k * len(pool)) // m, ((k + 1) * len(pool)) // m
+    cpus = pool[lo:hi] or [pool[k % len(pool)]]
+    return dict(cpus=cpus, threads=max(1, min(int(max_threads), len(cpus))), numa_node=node, blocking_sync=local_world > 1)
+
+
+def apply_rank_host_plan(plan, set_device_flags=True):
+    """Pin this process to plan['cpus'], cap torch's intra-op threads, and - before the first HIP call of the process - make
+    host reads block instead of spin when the plan says so.  Returns what was actually applied (for the bench line)."""
+    import os
+    applied = dict(cpus=len(plan["cpus"]), first_cpu=plan["cpus"][0], last_cpu=plan["cpus"][-1], numa_node=plan["numa_node"],
+                   threads=plan["threads"], blocking_sync=False, affinity=False)
+    try:
+        os.sched_setaffinity(0, plan["cpus"])
+        applied["affinity"] = True
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(plan["threads"])
+    if plan["blocking_sync"] and set_device_flags and torch.cuda.is_available():
+        import ctypes
+        try:
+            rc = ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(0x4))  # hipDeviceScheduleBlockingSync
+            applied["blocking_sync"] = rc == 0
+        except OSError:
+            pass
+    return applied
+
+
+def gpu_pci_bus_ids(count):
+    """PCI bus ids of the first `count` HIP devices, asked of the runtime directly (no context is created, so
+    hipSetDeviceFlags can still follow)."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return []
+    out = []
+    for i in range(count):
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, i) != 0:
+            break
+        out.append(buf.value.decode())
+    return out
+
+
+def setup_rank_host(local_rank, local_world, max_threads=8, apply=True):
+    """One call for a rank's launcher code, BEFORE its first HIP call: read the node's topology, plan (rank_host_plan) and -
+    if `apply` - pin / cap / switch the device to blocking host reads.  Returns (plan, applied or None)."""
+    import ctypes
+    gpu_numa, numa_cpus, all_cpus = read_host_topology(gpu_pci_bus_ids(local_world))
+    plan = rank_host_plan(local_rank, local_world, gpu_numa, numa_cpus, all_cpus, max_threads=max_threads)
+    if not apply:
+        return plan, None
+    if plan["blocking_sync"] and torch.cuda.is_available():
+        try:  # the flag belongs to the CURRENT device: select this rank's GPU first (no context yet)
+            ctypes.CDLL("libamdhip64.so").hipSetDevice(int(local_rank))
+        except OSError:
+            pass
+    return plan, apply_rank_host_plan(plan)
+
+
 def engine_casts(name, t):
     """True for the state_dict tensors Engine.prepare converts to the compute dtype as they are (engine.py: lin / conv /
     stem / pool / unpool).  Not: 1-D tensors (biases, norms: fp32), the timestep MLPs (``fc_t1/2``, ``t_mlp``: fp32

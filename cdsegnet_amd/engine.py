@@ -222,6 +222,7 @@ class Engine:
         # algorithmic HBM bytes of the k = 3 sparse convs issued so far: features in + out, the kernel map as stored
         # (27 x int32 per point), the weights once per launch
         self.conv_bytes = 0.0
+        self.conv_deep_bytes = 0.0
         self.attn_bytes = 0.0  # algorithmic attention bytes: q, k, v read once + o written once per launch
         # stages of a bf16 forward that run through the exact-fp32 twin engine instead (keys: n_emb, c_emb, n_enc0..4,
         # c_enc0..2, x, n_dec3..0, c_dec1..0, n_head, c_head).  The error budget of the bf16 mode is measured with it
@@ -632,7 +633,10 @@ class Engine:
     FUSE_LN_MAX_C = 512  # rows up to this width are finished by one GEMM block -> LayerNorm in the epilogue
 
     def _count_conv(self, n, c, esz):
-        self.conv_bytes += 2.0 * n * c * esz + 27.0 * 4 * n + 27.0 * c * c * esz
+        if c <= 64 and esz == 2:  # the weight-stationary kernel of the wide stages (conv.hip): HBM / gather bound
+            self.conv_bytes += 2.0 * n * c * esz + 27.0 * 4 * n + 27.0 * c * c * esz
+        else:  # the gathered GEMM (gemm.hip): MFMA / LDS-DMA bound (its FLOPs: forward_work()["conv_deep"])
+            self.conv_deep_bytes += 2.0 * n * c * esz + 27.0 * 4 * n + 27.0 * c * c * esz
 
     def _conv3(self, xc, pre, lv, y):
         """y = SubMConv3d_k3(xc) (ref: ptv3.py:356-362): the weight-stationary kernel on the wide bf16 stages, the
@@ -919,10 +923,13 @@ class Engine:
             return cache[(lv.cum, k)]
 
         out = dict(conv=0.0, linear=0.0, attention=0.0, stem=0.0, pool_unpool=0.0, head=0.0)
+        deep = [0.0]  # the part of "conv" that runs on the gathered GEMM (C >= 128, or any width in the fp32 mode)
 
         def block(mod, pre, lv):
             c, hid = mod.channels, w[pre + ".fc1.w"].shape[0]
             out["conv"] += 2.0 * occ(lv, 3) * c * c
+            if c > 64 or self.T == torch.float32:
+                deep[0] += 2.0 * occ(lv, 3) * c * c
             out["linear"] += 2.0 * lv.n * (5.0 * c * c + 2.0 * c * hid)
             out["attention"] += 64.0 * mod.attn.num_heads * lv.pad(mod.attn.patch_size, mod.attn.enable_flash)[6]
 
@@ -948,6 +955,7 @@ class Engine:
             lq, lc = plan.levels[plan.n_cum[-1]], plan.levels[plan.c_cum[-1]]
             cq, ck = cb.q_channels, cb.kv_channels
             out["conv"] += 2.0 * occ(lq, 3) * cq * cq + 2.0 * occ(lc, 3) * ck * ck
+            deep[0] += 2.0 * occ(lq, 3) * cq * cq + 2.0 * occ(lc, 3) * ck * ck
             out["linear"] += 2.0 * lq.n * (cq * cq * 3 + 2.0 * cq * w["x.fc1.w"].shape[0]) + 2.0 * lc.n * (ck * ck + ck * 2 * cq)
             out["attention"] += 64.0 * cb.attn.num_heads * lq.pad(cb.attn.q_patch_size, cb.attn.enable_flash)[6]
         for s in reversed(range(bb.n_num_stages - 1)):
@@ -963,6 +971,7 @@ class Engine:
         if "n_head.w" in w:
             out["head"] += 2.0 * lv0.n * w["n_head.w"].numel()
         out["total"] = sum(out.values())
+        out["conv_deep"] = deep[0]  # (a part of "conv": not in the total a second time)
         return out
 
     # ------------------------------------------------------------------ randomness

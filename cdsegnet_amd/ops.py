@@ -105,7 +105,7 @@ def attention_prof_summary():
     return prof_summary(PROF_ATTENTION)
 
 
-PROF_ATTENTION, PROF_CONV = 0, 1
+PROF_ATTENTION, PROF_CONV, PROF_CONV_DEEP = 0, 1, 2  # include/cdseg.h
 
 
 def prof_summary(cls):

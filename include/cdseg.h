@@ -243,9 +243,11 @@ long cdseg_attention_schedule(int num_patches, int num_heads, int max_len, int d
  * enable(1) starts recording, summary() (after a device sync) returns the summed durations. */
 int cdseg_prof_enable(int on);
 int cdseg_prof_summary(double* total_ms, long* launches); /* class CDSEG_PROF_ATTENTION */
-/* per kernel class: 0 = window attention, 1 = k = 3 sparse convs (cdseg_subm_conv3 and cdseg_gemm with a 27-offset map) */
+/* per kernel class: 0 = window attention, 1 = k = 3 sparse convs of the wide stages (cdseg_subm_conv3: HBM / gather bound),
+ * 2 = k = 3 sparse convs on the gathered GEMM (cdseg_gemm with a 27-offset map: C >= 128, MFMA / LDS-DMA bound) */
 #define CDSEG_PROF_ATTENTION 0
 #define CDSEG_PROF_CONV 1
+#define CDSEG_PROF_CONV_DEEP 2
 int cdseg_prof_summary_class(int cls, double* total_ms, long* launches);
 
 /* ------------------------------------------------------------------ pooling reduce

@@ -322,3 +322,52 @@ def test_grad_sync_notices_ranks_that_disagree_on_the_gradient_order(tmp_path):
         res = torch.load(os.path.join(str(tmp_path), f"order{r}.pt"))
         assert res[1] == 1.5
         assert isinstance(res[2], str) and "different orders" in res[2]
+
+
+def test_rank_host_plan_on_a_mocked_8_gpu_two_socket_node(tmp_path):
+    """what each of 8 ranks does to the HOST (the only thing they share): CPUs of its GPU's NUMA node,
+    split among the ranks of that node; a cap on torch's intra-op threads; blocking host reads.  Mocked topology: GPUs 0-3 on
+    node 0, 4-7 on node 1, 2 x 64 cores with SMT siblings numbered +128 (the GPU boxes' 256 hardware threads)."""
+    node0 = list(range(0, 64)) + list(range(128, 192))
+    node1 = list(range(64, 128)) + list(range(192, 256))
+    gpu_numa, numa_cpus, all_cpus = [0, 0, 0, 0, 1, 1, 1, 1], {0: node0, 1: node1}, list(range(256))
+    plans = [cdist.rank_host_plan(r, 8, gpu_numa, numa_cpus, all_cpus) for r in range(8)]
+    seen = set()
+    for r, p in enumerate(plans):
+        assert p["numa_node"] == gpu_numa[r] and len(p["cpus"]) == 32 and p["threads"] == 8 and p["blocking_sync"]
+        assert set(p["cpus"]) <= set(numa_cpus[gpu_numa[r]]) and not (set(p["cpus"]) & seen)
+        seen |= set(p["cpus"])
+    assert seen == set(range(256))  # every hardware thread belongs to exactly one rank
+    # a container that may only use 8 CPUs of node 0: nobody gets an empty set, node-1 ranks fall back to the allowed CPUs
+    small = [cdist.rank_host_plan(r, 8, gpu_numa, numa_cpus, list(range(8))) for r in range(8)]
+    assert all(p["cpus"] and set(p["cpus"]) <= set(range(8)) and p["threads"] >= 1 for p in small)
+    assert sorted(c for p in small[:4] for c in p["cpus"]) == list(range(8))
+    # no NUMA information (sysfs says -1): an even split of everything
+    flat = [cdist.rank_host_plan(r, 4, [-1] * 4, {}, list(range(64))) for r in range(4)]
+    assert [p["cpus"] for p in flat] == [list(range(16 * r, 16 * r + 16)) for r in range(4)]
+    # one rank: the whole local node, nothing to block for
+    one = cdist.rank_host_plan(0, 1, [1], numa_cpus, all_cpus, max_threads=16)
+    assert one["cpus"] == sorted(node1) and one["threads"] == 16 and not one["blocking_sync"]
+    # the sysfs reader on a fake tree
+    sysfs = tmp_path / "sys"
+    for bus, node in (("0000:05:00.0", 0), ("0000:c5:00.0", 1)):
+        d = sysfs / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    for node, text in ((0, "0-63,128-191"), (1, "64-127,192-255")):
+        d = sysfs / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(text + "\n")
+    g, nc, _ = cdist.read_host_topology(["0000:05:00.0", "0000:C5:00.0", "0000:ff:00.0"], sysfs=str(sysfs))
+    assert g == [0, 1, -1] and nc == {0: node0, 1: node1}
+    # applying a plan in this process (no GPU here): affinity + thread cap, restored afterwards
+    import os as _os
+    keep_aff, keep_thr = _os.sched_getaffinity(0), torch.get_num_threads()
+    try:
+        mine = sorted(keep_aff)
+        p = cdist.rank_host_plan(1, 2, [-1, -1], {}, mine, max_threads=2)
+        applied = cdist.apply_rank_host_plan(p, set_device_flags=False)
+        assert applied["affinity"] and _os.sched_getaffinity(0) == set(p["cpus"]) and torch.get_num_threads() == p["threads"]
+    finally:
+        _os.sched_setaffinity(0, keep_aff)
+        torch.set_num_threads(keep_thr)
