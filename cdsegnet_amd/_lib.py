@@ -144,6 +144,10 @@ SIGNATURES = {
                                   c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "cdseg_attn_tail_rr": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "cdseg_cpe_head_rr2": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
+    "cdseg_attn_tail_rr2": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_void_p, c_size_t, c_void_p]),
     "cdseg_block_scratch_bytes": (c_size_t, [POINTER(BlockDesc), c_long]),
     "cdseg_block_forward": (c_int, [POINTER(BlockDesc), POINTER(BlockIO), c_void_p]),
     "cdseg_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,

@@ -13,10 +13,13 @@
 //    (bf16: 32 KB + 32 KB row-major -> 2 blocks / CU; f32: 64 KB + 65 KB, V transposed);
 //  * scores are computed TRANSPOSED (S^T = K Q^T) so that a query's scores stay inside one lane
 //    pair: row statistics need no cross-lane traffic in the key loop;
-//  * bf16: ONE pass over the keys.  Softmax is shift invariant, so instead of the row max the kernel subtracts the
-//    Cauchy-Schwarz bound |q'_i| max_j |k_j| (one norm per query, one max over the keys after staging K): no max
-//    sweep, no second QK^T.  Scale * log2(e) is folded into Q', the shift rides in the MFMA's C operand, so a score
-//    costs ONE v_exp_f32.  Query tiles whose bound is too loose (> 2^60) are redone with the exact row max;
+//  * bf16: ONE pass over the keys, and since round 6 without any shift: softmax is shift invariant and fp32 / bfloat16
+//    carry 8 exponent bits, so P~ = exp2(s') (scale * log2(e) folded into Q' by the producer) needs neither the row max nor a
+//    bound as long as nothing leaves fp32's range; the MFMA's C operand is the inline constant 0, a score costs ONE v_exp_f32
+//    and the query tile's set-up is a row fetch.  The denominator (row 16 of the PV product) tells whether that was
+//    legitimate: rows whose denominator left [1e-30, 1e30] are redone with the exact row max (rounds 2 - 5 subtracted the
+//    Cauchy-Schwarz bound |q'_i| max_j |k_j|: a norm + sqrt + sixteen shift registers per query tile and a max-|k| pass over
+//    the staged keys per block - 4.5 - 5 % of the kernel, profiles/r06_attention_unshifted_sweep.txt);
 //  * the kernel is bound by the VALU / transcendental issue, not by the matrix pipe: 16 v_exp_f32 + 8
 //    v_cvt_pk_bf16_f32 per 32x32 score tile against 3 MFMAs of 32 cycles (tools/ubench/pipes.hip,
 //    profiles/r03_ubench_pipes.txt: 128 cycles per tile and SIMD at 4 waves per SIMD = half the MFMA-only rate - and with
@@ -671,6 +674,223 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_f32_kernel(AttnP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------ fp32 x3 (CDSEG_F32X3, round 6)
+// The parity mode's attention at a multiple of the exact-fp32 MFMA rate: q, k, v are fp32 in memory; on their way into LDS /
+// the B operand every value is split into a 16-bit PAIR and a product runs as three 16-bit MFMAs with fp32 accumulation
+// (csrc/gemm.hip "fp32 x3" does the same for the GEMMs):
+//   scores   q' = q * scale * log2 e and k as IEEE-half pairs x ~= hi + lo (22 significant bits; |q'|, |k| <= 65504):
+//            S^T = K_hi Q_hi^T + K_hi Q_lo^T + K_lo Q_hi^T, one accumulator (v_mfma_f32_32x32x16_f16)
+//   P V      P~ = exp2(s) (unshifted single pass, see attn_bf16_kernel) and v as BFLOAT16 pairs (fp32's exponent range; 16
+//            significant bits): O^T = V1^T P1^T + V2^T P1^T + V1^T P2^T; the row of ones that yields the denominator sits
+//            behind V1 only (behind V2: zeros), so the denominator is sum(p1 + p2)
+// Rows whose denominator left [1e-30, 1e30] are redone with the exact row max.  Same block -> (patch, head, slice) map and the
+// same LDS images as the 16-bit kernel (K planes with the source-side half swap, V planes row-major for ds_read_b64_tr_b16);
+// four 32 KB planes = one block of 8 waves per CU, two score tiles in flight per wave.
+constexpr int X3_KH = 0, X3_KL = KV_STAGE, X3_V1 = 2 * KV_STAGE, X3_V2 = 3 * KV_STAGE;
+constexpr int X3_ONES = 4 * KV_STAGE, X3_ZERO = X3_ONES + ONES_BYTES;
+constexpr int SMEM_X3 = X3_ZERO + ONES_BYTES;
+constexpr int X3_THREADS = 512;
+typedef _Float16 x3h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 x3h8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void x3_split_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const hw_f32x2_t v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+  const x3h2_t hh = __builtin_convertvector(v, x3h2_t);
+  const hw_f32x2_t r = v - __builtin_convertvector(hh, hw_f32x2_t);
+  hi = __builtin_bit_cast(uint32_t, hh);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, x3h2_t));
+}
+__device__ __forceinline__ void x3_split_bf16(float a, float b, uint32_t& p1, uint32_t& p2) {
+  p1 = pack_truebf16x2(a, b);
+  p2 = pack_truebf16x2(a - __uint_as_float(p1 << 16), b - __uint_as_float(p1 & 0xffff0000u));
+}
+__device__ __forceinline__ f32x16_t x3_mfma_f16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3h8_t, a), __builtin_bit_cast(x3h8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16_t x3_qk_tile(const char* k_lane, bf16x8_t qh, bf16x8_t ql, const f32x16_t& c0) {
+  const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(k_lane + X3_KH);
+  const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(k_lane + X3_KL);
+  f32x16_t s = x3_mfma_f16(kh, qh, c0);
+  s = x3_mfma_f16(kh, ql, s);
+  return x3_mfma_f16(kl, qh, s);
+}
+
+template <bool TAIL, bool FIRST = false>
+__device__ __forceinline__ void x3_pv_tile(const f32x16_t& s, int kt, int h, int L, unsigned va1, unsigned va2, f32x16_t& o) {
+  float pr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r]);
+  if (TAIL) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) pr[r] = 0.f;
+  }
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    union { bf16x8_t v; uint32_t u[4]; } p1, p2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x3_split_bf16(pr[8 * mf + 2 * j], pr[8 * mf + 2 * j + 1], p1.u[j], p2.u[j]);
+    const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(va1 + 512 * mf));
+    const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(va1 + 512 * mf + 256));
+    const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(va2 + 512 * mf));
+    const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(va2 + 512 * mf + 256));
+    const bf16x8_t v1 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8_t v2 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if (FIRST && mf == 0) {
+      const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      o = mfma_32x32x16_truebf16(v1, p1.v, z);
+    } else {
+      o = mfma_32x32x16_truebf16(v1, p1.v, o);
+    }
+    o = mfma_32x32x16_truebf16(v2, p1.v, o);
+    o = mfma_32x32x16_truebf16(v1, p2.v, o);
+  }
+}
+
+__global__ __launch_bounds__(X3_THREADS) void attn_x3_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int patch, head, qslice, qsplit;
+  if (!decode_block(p, (int)blockIdx.x, patch, head, qslice, qsplit)) return;
+  const int ps = p.patch_start[patch];
+  const int L = p.patch_start[patch + 1] - ps;
+  const int nkt = (L + 31) >> 5;
+  const float* kb = (const float*)p.k + head * 16;
+  const float* vb = (const float*)p.v + head * 16;
+  // ---- stage K and V: a thread converts whole keys (16 + 16 floats -> two half planes, two bfloat16 planes)
+  for (int s = tid; s < nkt * 32; s += X3_THREADS) {
+    uint4 kk[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kk[i] = vv[i] = make_uint4(0, 0, 0, 0);
+    if (s < L) {
+      const long g = p.kv_gidx[ps + s];
+      const uint4* kr = reinterpret_cast<const uint4*>(kb + g * p.ldk);
+      const uint4* vr = reinterpret_cast<const uint4*>(vb + g * p.ldv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { kk[i] = kr[i]; vv[i] = vr[i]; }
+    }
+    const int sw = (s >> 3) & 1;  // keys with bit 3 set store their two 16-byte halves swapped (conflict-free A reads)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {  // dims 8 hf .. 8 hf + 7
+      uint4 kh, kl, v1, v2;
+      x3_split_f16(__uint_as_float(kk[2 * hf].x), __uint_as_float(kk[2 * hf].y), kh.x, kl.x);
+      x3_split_f16(__uint_as_float(kk[2 * hf].z), __uint_as_float(kk[2 * hf].w), kh.y, kl.y);
+      x3_split_f16(__uint_as_float(kk[2 * hf + 1].x), __uint_as_float(kk[2 * hf + 1].y), kh.z, kl.z);
+      x3_split_f16(__uint_as_float(kk[2 * hf + 1].z), __uint_as_float(kk[2 * hf + 1].w), kh.w, kl.w);
+      x3_split_bf16(__uint_as_float(vv[2 * hf].x), __uint_as_float(vv[2 * hf].y), v1.x, v2.x);
+      x3_split_bf16(__uint_as_float(vv[2 * hf].z), __uint_as_float(vv[2 * hf].w), v1.y, v2.y);
+      x3_split_bf16(__uint_as_float(vv[2 * hf + 1].x), __uint_as_float(vv[2 * hf + 1].y), v1.z, v2.z);
+      x3_split_bf16(__uint_as_float(vv[2 * hf + 1].z), __uint_as_float(vv[2 * hf + 1].w), v1.w, v2.w);
+      *reinterpret_cast<uint4*>(smem + X3_KH + s * 32 + ((hf ^ sw) << 4)) = kh;
+      *reinterpret_cast<uint4*>(smem + X3_KL + s * 32 + ((hf ^ sw) << 4)) = kl;
+      *reinterpret_cast<uint4*>(smem + X3_V1 + s * 32 + (hf << 4)) = v1;
+      *reinterpret_cast<uint4*>(smem + X3_V2 + s * 32 + (hf << 4)) = v2;
+    }
+  }
+  for (int w = tid; w < ONES_BYTES / 8; w += X3_THREADS) {
+    *reinterpret_cast<uint2*>(smem + X3_ONES + w * 8) = make_uint2(0x3F80u, 0u);
+    *reinterpret_cast<uint2*>(smem + X3_ZERO + w * 8) = make_uint2(0u, 0u);
+  }
+  __syncthreads();
+
+  const int ql = lane & 31, h = lane >> 5;
+  const char* k_lane = smem + ql * 32 + ((h ^ ((ql >> 3) & 1)) << 4);
+  const bool v_lane = (lane & 16) == 0;  // lane groups 0 / 2 read V, 1 / 3 the ones (V1) / zero (V2) page
+  const unsigned vrow = (4 * h + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  const unsigned va1_0 = v_lane ? lds_base + X3_V1 + vrow : lds_base + X3_ONES + (h ? 0 : 128);
+  const unsigned va2_0 = v_lane ? lds_base + X3_V2 + vrow : lds_base + X3_ZERO + (h ? 0 : 128);
+  const unsigned vstep = v_lane ? 1024u : 0u;
+  const float c = p.scale_log2e;
+  const bool tail = (nkt << 5) != L;
+  const int nfull = tail ? nkt - 1 : nkt;
+  const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  for (int qt = qslice * ATTN_RUN + wave; qt < nkt; qt += qsplit * ATTN_RUN) {
+    const int qslot = qt * 32 + ql;
+    const bool qvalid = qslot < L;
+    const long g = p.q_gidx[ps + min(qslot, L - 1)];
+    const uint4* qrow = reinterpret_cast<const uint4*>((const float*)p.q + g * p.ldq + head * 16 + h * 8);
+    const uint4 qa = qrow[0], qb = qrow[1];
+    int w = p.widx[ps + min(qslot, L - 1)];
+    if (!qvalid) w = -1;
+    union { bf16x8_t v; uint32_t u[4]; } qh, qlo;
+    x3_split_f16(__uint_as_float(qa.x) * c, __uint_as_float(qa.y) * c, qh.u[0], qlo.u[0]);
+    x3_split_f16(__uint_as_float(qa.z) * c, __uint_as_float(qa.w) * c, qh.u[1], qlo.u[1]);
+    x3_split_f16(__uint_as_float(qb.x) * c, __uint_as_float(qb.y) * c, qh.u[2], qlo.u[2]);
+    x3_split_f16(__uint_as_float(qb.z) * c, __uint_as_float(qb.w) * c, qh.u[3], qlo.u[3]);
+    auto exp_pv_pass = [&](auto shift_tag, float mrow) {
+      constexpr bool SHIFT = decltype(shift_tag)::value;
+      const float nm = SHIFT ? -mrow : 0.f;
+      const f32x16_t negm = {nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm};
+      const f32x16_t& c0 = SHIFT ? negm : zero16;
+      f32x16_t acc;
+      const char* kp = k_lane;
+      unsigned va1 = va1_0, va2 = va2_0;
+      int kt;
+      if (nfull >= 2) {
+        const f32x16_t sa = x3_qk_tile(kp, qh.v, qlo.v, c0);
+        const f32x16_t sb = x3_qk_tile(kp + 1024, qh.v, qlo.v, c0);
+        x3_pv_tile<false, true>(sa, 0, h, L, va1, va2, acc);
+        x3_pv_tile<false>(sb, 1, h, L, va1 + 1024, va2 + 1024, acc);
+        kp += 2048; va1 += 2 * vstep; va2 += 2 * vstep;
+        kt = 2;
+      } else {
+        const f32x16_t s0 = x3_qk_tile(kp, qh.v, qlo.v, c0);
+        if (nfull == 0) x3_pv_tile<true, true>(s0, 0, h, L, va1, va2, acc);
+        else x3_pv_tile<false, true>(s0, 0, h, L, va1, va2, acc);
+        kp += 1024; va1 += vstep; va2 += vstep;
+        kt = 1;
+      }
+      for (; kt + 1 < nfull; kt += 2) {
+        const f32x16_t sa = x3_qk_tile(kp, qh.v, qlo.v, c0);
+        const f32x16_t sb = x3_qk_tile(kp + 1024, qh.v, qlo.v, c0);
+        x3_pv_tile<false>(sa, kt, h, L, va1, va2, acc);
+        x3_pv_tile<false>(sb, kt + 1, h, L, va1 + 1024, va2 + 1024, acc);
+        kp += 2048; va1 += 2 * vstep; va2 += 2 * vstep;
+      }
+      for (; kt < nkt; ++kt) {
+        const f32x16_t s = x3_qk_tile(kp, qh.v, qlo.v, c0);
+        if (kt >= nfull) x3_pv_tile<true>(s, kt, h, L, va1, va2, acc);
+        else x3_pv_tile<false>(s, kt, h, L, va1, va2, acc);
+        kp += 1024; va1 += vstep; va2 += vstep;
+      }
+      return acc;
+    };
+    f32x16_t o = exp_pv_pass(std::false_type{}, 0.f);
+    {
+      const float den = __shfl(o[8], ql, 64);
+      const bool redo = qvalid && !(den >= 1e-30f && den <= 1e30f);
+      if (__any(redo)) {  // exact row max, then the shifted pass (wave-uniform, rare)
+        float m0 = -INFINITY;
+        const char* kp = k_lane;
+        for (int kt = 0; kt < nkt; ++kt, kp += 1024) {
+          f32x16_t s = x3_qk_tile(kp, qh.v, qlo.v, zero16);
+          if (kt >= nfull) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[r] = -INFINITY;
+          }
+          m0 = tile_max(s, m0);
+        }
+        m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+        o = exp_pv_pass(std::true_type{}, m0);
+      }
+    }
+    // O^T rows (r & 3) + 8 (r >> 2) + 4 h: registers 0..3 = dims 4h .. 4h+3, 4..7 = dims 8+4h .. 8+4h+3; row 16 = denominator
+    const float inv = 1.0f / __shfl(o[8], ql, 64);
+    if (w >= 0) {
+      float* orow = (float*)p.out + (long)w * p.ldo + head * 16 + 4 * h;
+      *reinterpret_cast<float4*>(orow) = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      *reinterpret_cast<float4*>(orow + 8) = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef CDSEG_ATTN_TIMING
@@ -724,7 +944,7 @@ static unsigned make_schedule(AttnP& p, int num_patches, int num_heads, int max_
   p.num_heads = num_heads;
   // K/V staging is per block, so split a patch-head's queries over as few blocks as still fill
   // the chip (2 resident blocks per CU -> ~512 block slots)
-  const int tile = dtype == CDSEG_F32 ? 16 : 32;
+  const int tile = dtype == CDSEG_F32 ? 16 : 32;  // (CDSEG_F32X3: 32-query tiles like the 16-bit kernel)
   const int nqt = (max_len + tile - 1) / tile;
   const int ph = num_patches * num_heads;
   // (sweep at the end of round 3, tools/bench_attention.py: 202 and 224 patch-heads run 2 - 6 % faster unsplit than in two
@@ -750,16 +970,16 @@ extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, i
                                   void* out, int ldo, int dtype, int flags, void* stream) {
   if (num_patches <= 0 || num_heads <= 0) return CDSEG_OK;
   if (max_len <= 0 || max_len > CDSEG_MAX_PATCH) return CDSEG_ERR_UNSUPPORTED;
-  if (dtype != CDSEG_BF16 && dtype != CDSEG_F32) return CDSEG_ERR_ARG;
+  if (dtype != CDSEG_BF16 && dtype != CDSEG_F32 && dtype != CDSEG_F32X3) return CDSEG_ERR_ARG;
   if (flags & ~(CDSEG_ATTN_Q_PRESCALED | CDSEG_ATTN_V_BF16)) return CDSEG_ERR_ARG;
-  if (dtype == CDSEG_F32 && (flags & CDSEG_ATTN_V_BF16)) return CDSEG_ERR_ARG;
-  const int esz = dtype == CDSEG_F32 ? 4 : 2;
+  if (dtype != CDSEG_BF16 && (flags & CDSEG_ATTN_V_BF16)) return CDSEG_ERR_ARG;
+  const int esz = dtype == CDSEG_BF16 ? 2 : 4;
   // 16-byte alignment of every gathered row slice; output pieces: 16 bytes (fp32: always; 16-bit: the one-store epilogue),
   // or 8 bytes for 16-bit outputs with ldo % 8 != 0 (such calls were valid before the 16-byte store existed)
   if (((long)ldq * esz) & 15 || ((long)ldk * esz) & 15 || ((long)ldv * esz) & 15) return CDSEG_ERR_ARG;
   if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return CDSEG_ERR_ARG;
   const bool out16 = !((((long)ldo * esz) | (long)(uintptr_t)out) & 15);
-  if (!out16 && (dtype == CDSEG_F32 || ((((long)ldo * esz) | (long)(uintptr_t)out) & 7))) return CDSEG_ERR_ARG;
+  if (!out16 && (dtype != CDSEG_BF16 || ((((long)ldo * esz) | (long)(uintptr_t)out) & 7))) return CDSEG_ERR_ARG;
   AttnP p;
   p.q = q; p.k = k; p.v = v; p.q_gidx = q_gidx; p.kv_gidx = kv_gidx; p.widx = widx; p.patch_start = patch_start;
   p.out = out; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.num_heads = num_heads;
@@ -775,6 +995,8 @@ extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, i
     attr_ok = hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BF16) ==
                   hipSuccess &&
               hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F32) ==
+                  hipSuccess &&
+              hipFuncSetAttribute((const void*)attn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_X3) ==
                   hipSuccess;
   });
   if (!attr_ok) return CDSEG_ERR_LAUNCH;
@@ -782,6 +1004,8 @@ extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, i
   const bool prof = cdseg_prof_begin(CDSEG_PROF_ATTENTION, s, &tok);
   if (dtype == CDSEG_BF16) {
     hipLaunchKernelGGL(attn_bf16_kernel, grid, block, SMEM_BF16, s, p);
+  } else if (dtype == CDSEG_F32X3) {
+    hipLaunchKernelGGL(attn_x3_kernel, grid, dim3(X3_THREADS), SMEM_X3, s, p);
   } else {
     hipLaunchKernelGGL(attn_f32_kernel, grid, block, SMEM_F32, s, p);
   }
@@ -805,7 +1029,7 @@ extern "C" int cdseg_attention(const void* q, const void* k, const void* v, int 
 extern "C" long cdseg_attention_schedule(int num_patches, int num_heads, int max_len, int dtype, int32_t* table,
                                          long capacity) {
   if (num_patches <= 0 || num_heads <= 0 || max_len <= 0 || max_len > CDSEG_MAX_PATCH) return CDSEG_ERR_ARG;
-  if (dtype != CDSEG_BF16 && dtype != CDSEG_F32) return CDSEG_ERR_ARG;
+  if (dtype != CDSEG_BF16 && dtype != CDSEG_F32 && dtype != CDSEG_F32X3) return CDSEG_ERR_ARG;
   AttnP p{};
   const unsigned nb = make_schedule(p, num_patches, num_heads, max_len, dtype);
   for (long b = 0; b < (long)nb && b < capacity && table; ++b) {

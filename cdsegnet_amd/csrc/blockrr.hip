@@ -385,8 +385,8 @@ extern "C" int cdseg_cpe_head_rr(const void* y, int ldy, const void* head_img, c
   if ((ldy & 7) || (ldx & 3) || (ldqkv & 7) || (((uintptr_t)y | (uintptr_t)x | (uintptr_t)qkv | (uintptr_t)head_img) & 15))
     return CDSEG_ERR_ARG;
   if (deep_supported(channels))
-    return deep_head(y, ldy, head_img, bl, lnp_g, lnp_b, x, ldx, colbias, ln1_g, ln1_b, eps, bqkv, qkv, ldqkv, n, channels,
-                     qkv_flags, (hipStream_t)stream);
+    return deep_head(y, ldy, head_img, bl, lnp_g, lnp_b, x, ldx, x, ldx, colbias, ln1_g, ln1_b, eps, bqkv, qkv, ldqkv, n,
+                     channels, qkv_flags, (hipStream_t)stream);
   HeadRR p;
   p.y = (const bf16_t*)y; p.wimg = (const uint4*)head_img; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.bqkv = bqkv; p.qkv = (bf16_t*)qkv;
@@ -412,7 +412,8 @@ extern "C" int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, 
   if ((ldo & 7) || (ldx & 3) || (xc && (ldxc & 7)) || (((uintptr_t)o | (uintptr_t)x | (uintptr_t)xc | (uintptr_t)tail_img) & 15))
     return CDSEG_ERR_ARG;
   if (deep_supported(channels))
-    return deep_tail(o, ldo, tail_img, bp, ln_g, ln_b, eps, b1, b2, x, ldx, xc, ldxc, n, channels, (hipStream_t)stream);
+    return deep_tail(o, ldo, tail_img, bp, ln_g, ln_b, eps, b1, b2, x, ldx, x, ldx, xc, ldxc, n, channels, nullptr, 0,
+                     (hipStream_t)stream);
   TailRR p;
   p.o = (const bf16_t*)o; p.wimg = (const uint4*)tail_img; p.bp = bp; p.ln_g = ln_g; p.ln_b = ln_b; p.b1 = b1; p.b2 = b2;
   p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldo = ldo; p.ldx = ldx; p.ldxc = ldxc; p.eps = eps;
@@ -432,4 +433,37 @@ extern "C" int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, 
   }
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
+}
+
+// Deep stages (C = 128 / 256 / 512) with the residual rows read from one buffer and written to another (round 6).  With
+// x_out != x the few-row launches of a single scene's deep stages cut a tile's weight stream over several workgroups (head:
+// one per q / k / v column block; tail: by hidden chunks, through the fp32 workspace `ws` and a reduce launch) - csrc/deep.hip.
+// The native Block executor ping-pongs the residual through its scratch arena with this pair.
+extern "C" int cdseg_cpe_head_rr2(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g,
+                                  const float* lnp_b, const float* x, int ldx, float* x_out, int ldx_out, const float* colbias,
+                                  const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv, int ldqkv,
+                                  long n, int channels, int qkv_flags, void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (qkv_flags & ~CDSEG_ATTN_V_BF16) return CDSEG_ERR_ARG;
+  if (!deep_supported(channels)) return CDSEG_ERR_UNSUPPORTED;
+  if (!y || !head_img || !bl || !lnp_g || !lnp_b || !x || !x_out || !ln1_g || !ln1_b || !bqkv || !qkv) return CDSEG_ERR_ARG;
+  if ((ldy & 7) || (ldx & 3) || (ldx_out & 3) || (ldqkv & 7) ||
+      (((uintptr_t)y | (uintptr_t)x | (uintptr_t)x_out | (uintptr_t)qkv | (uintptr_t)head_img) & 15))
+    return CDSEG_ERR_ARG;
+  return deep_head(y, ldy, head_img, bl, lnp_g, lnp_b, x, ldx, x_out, ldx_out, colbias, ln1_g, ln1_b, eps, bqkv, qkv, ldqkv, n,
+                   channels, qkv_flags, (hipStream_t)stream);
+}
+
+extern "C" int cdseg_attn_tail_rr2(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g,
+                                   const float* ln_b, float eps, const float* b1, const float* b2, const float* x_in, int ldx_in,
+                                   float* x, int ldx, void* xc, int ldxc, long n, int channels, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (n <= 0) return CDSEG_OK;
+  if (!deep_supported(channels)) return CDSEG_ERR_UNSUPPORTED;
+  if (!o || !tail_img || !bp || !ln_g || !ln_b || !b1 || !b2 || !x || !x_in) return CDSEG_ERR_ARG;
+  if ((ldo & 7) || (ldx & 3) || (ldx_in & 3) || (xc && (ldxc & 7)) ||
+      (((uintptr_t)o | (uintptr_t)x | (uintptr_t)x_in | (uintptr_t)xc | (uintptr_t)tail_img) & 15))
+    return CDSEG_ERR_ARG;
+  return deep_tail(o, ldo, tail_img, bp, ln_g, ln_b, eps, b1, b2, x_in, ldx_in, x, ldx, xc, ldxc, n, channels, ws, ws_bytes,
+                   (hipStream_t)stream);
 }

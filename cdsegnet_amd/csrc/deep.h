@@ -6,8 +6,11 @@
 bool deep_supported(int channels);
 int deep_pack(int channels, const void* wl, const void* wqkv, void* head_img, const void* wp, const void* w1, const void* w2,
               void* tail_img, hipStream_t s);
-int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b, float* x,
-              int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
-              int ldqkv, long n, int channels, int qkv_flags, hipStream_t s);
+// x / x_in: the residual rows read; x_out / x: the rows written (may alias the rows read: the in-place form, which never splits
+// the head).  ws: optional fp32 workspace (16-byte aligned) that allows the tail's few-row hidden-chunk split.
+int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b,
+              const float* x, int ldx, float* x_out, int ldxo, const float* colbias, const float* ln1_g, const float* ln1_b,
+              float eps, const float* bqkv, void* qkv, int ldqkv, long n, int channels, int qkv_flags, hipStream_t s);
 int deep_tail(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b, float eps,
-              const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n, int channels, hipStream_t s);
+              const float* b1, const float* b2, const float* x_in, int ldxi, float* x, int ldx, void* xc, int ldxc, long n,
+              int channels, void* ws, size_t ws_bytes, hipStream_t s);

@@ -194,10 +194,12 @@ struct DeepCfg {
 };
 
 struct DeepHeadP {
-  const bf16_t* y; const uint4* wimg; const float* bl; const float* lnp_g; const float* lnp_b; float* x;
+  const bf16_t* y; const uint4* wimg; const float* bl; const float* lnp_g; const float* lnp_b; const float* x;
+  float* x_out;  // the updated residual rows (= x for the in-place form; a split launch needs x_out != x: three workgroups read a row)
   const float* colbias; const float* ln1_g; const float* ln1_b; const float* bqkv; bf16_t* qkv;
-  long n; int ldy, ldx, ldqkv; float eps;
+  long n; int ldy, ldx, ldxo, ldqkv; float eps;
   int v_bf16;  // IEEE-half build: write the v third as bfloat16 (CDSEG_ATTN_V_BF16)
+  int nsplit;  // 1: a workgroup writes q, k and v of its tile; 3: workgroup (tile, c) writes column block c only (few-row launches)
 };
 
 template <int C, int BM>
@@ -212,7 +214,11 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;
-  const long m0 = (long)blockIdx.x * BM;
+  // few-row launches (a single scene's deep stages): three workgroups per tile, one per q / k / v column block - each repeats
+  // the cpe linear + the two LayerNorms (a quarter of the weight stream) and streams a third of Wqkv, so the chain a
+  // workgroup waits for is half as long and three times as many CUs stream weights; x is written by block 0 alone
+  const int c_lo = P.nsplit == 3 ? (int)(blockIdx.x % 3u) : 0, c_hi = P.nsplit == 3 ? c_lo + 1 : 3;
+  const long m0 = (long)(P.nsplit == 3 ? blockIdx.x / 3u : blockIdx.x) * BM;
   const uint4* wp = P.wimg + (size_t)wave * S * 128 + lane;
   DT_STAMP(0);
   uint4 ring[DEEP_D][2];
@@ -264,13 +270,13 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[pt][f][r] = ((v[pt][f][r] - mean[pt]) * rstd[pt] * ga[r] + be[r]) + xr[pt][f][r] + tb[r];
       const long m = m0 + 16 * pt + p;
-      if (m < P.n) *reinterpret_cast<f32x4_t*>(P.x + m * P.ldx + ch0 + 4 * f) = v[pt][f];
+      if (m < P.n && c_lo == 0) *reinterpret_cast<f32x4_t*>(P.x_out + m * P.ldxo + ch0 + 4 * f) = v[pt][f];
     }
   }
   DT_STAMP(4);
   row_stats<PTS, NW>(v, st1, st2, wave, p, g, inv_c, P.eps, mean, rstd);
   DT_STAMP(5);
-  prime(ring, wp, KS);
+  prime(ring, wp, KS * (1 + c_lo));
   {
     // h = LN1(x) over the tile, in place of y (every wave is past its y reads: the statistics barriers above)
     const f32x4_t ga0 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + ch0), ga1 = *reinterpret_cast<const f32x4_t*>(pr + 4 * C + ch0 + 4);
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
   lds_barrier();
   DT_STAMP(6);
 #pragma unroll 1
-  for (int c = 0; c < 3; ++c) {  // q, k, v column blocks
+  for (int c = c_lo; c < c_hi; ++c) {  // q, k, v column blocks
     f32x4_t a[PTS][2];
     {
       const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + 6 * C + c * C + ch0);
@@ -314,8 +320,10 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
 
 struct DeepTailP {
   const bf16_t* o; const uint4* wimg; const float* bp; const float* ln_g; const float* ln_b; const float* b1;
-  const float* b2; float* x; bf16_t* xc;
-  long n; int ldo, ldx, ldxc; float eps;
+  const float* b2; const float* x_in; float* x; bf16_t* xc;  // x_in: residual rows (= x for the in-place form)
+  long n; int ldo, ldx, ldxi, ldxc; float eps;
+  int nsplit;   // 1 | 2 | 4: workgroup (tile, js) runs hidden chunks [4 js / nsplit, 4 (js + 1) / nsplit) of the MLP
+  float* part;  // nsplit > 1: (nsplit, n, C) fp32 partial rows; deep_tail_reduce_kernel adds them up in a fixed order
 };
 
 template <int C, int BM>
@@ -331,7 +339,13 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;
-  const long m0 = (long)blockIdx.x * BM;
+  // few-row launches (round 6): a tile's MLP is cut by hidden chunks over nsplit workgroups - each repeats proj + LayerNorm
+  // (one ninth of the weight stream) and streams its own chunks' fc1 / fc2 weights, so the serial weight chain a workgroup
+  // waits for shrinks from 9 to 3 phases at nsplit = 4 and four times as many CUs stream; the partial rows (split 0's carry
+  // the residual) meet in deep_tail_reduce_kernel.  At 778 rows x C = 512 the unsplit tile took ~56 us whatever the row count
+  const int nsp = P.nsplit, js = nsp > 1 ? (int)(blockIdx.x % (unsigned)nsp) : 0;
+  const int j_lo = js * (4 / nsp), j_hi = j_lo + 4 / nsp;
+  const long m0 = (long)(nsp > 1 ? blockIdx.x / (unsigned)nsp : blockIdx.x) * BM;
   const uint4* wp = P.wimg + (size_t)wave * S * 128 + lane;
   DT_STAMP(0);
   uint4 ring[DEEP_D][2];
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
       long m = m0 + 16 * pt + p;
       if (m >= P.n) m = P.n - 1;
 #pragma unroll
-      for (int f = 0; f < 2; ++f) xr[pt][f] = *reinterpret_cast<const f32x4_t*>(P.x + m * P.ldx + ch0 + 4 * f);
+      for (int f = 0; f < 2; ++f) xr[pt][f] = *reinterpret_cast<const f32x4_t*>(P.x_in + m * P.ldxi + ch0 + 4 * f);
     }
     lds_barrier();
     DT_STAMP(1);
@@ -380,13 +394,19 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
       *reinterpret_cast<uint4*>(bufA + act_off<NCH>(16 * pt + p, 4 * wave + g)) = pack8(h0, h1);
     }
   }
+  if (js) {  // the ring holds chunk 0's first steps (requested behind proj): this workgroup's chunks start elsewhere, and its
+    prime(ring, wp, KS * (1 + 2 * j_lo));  // partial rows carry no residual
+    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) { acc2[pt][0] = z; acc2[pt][1] = z; }
+  }
   lds_barrier();
   DT_STAMP(5);
 #ifdef CDSEG_DEEP_TIMING
   unsigned long long dt_fc1 = 0, dt_gelu = 0, dt_fc2 = 0;
 #endif
 #pragma unroll 1
-  for (int j = 0; j < 4; ++j) {  // hidden units C j .. C j + C - 1
+  for (int j = j_lo; j < j_hi; ++j) {  // hidden units C j .. C j + C - 1
 #ifdef CDSEG_DEEP_TIMING
     const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
 #ifdef CDSEG_DEEP_TIMING
     const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
-    if (j) lds_barrier();  // every wave is done with the previous chunk's fc2 reads of bufU
+    if (j > j_lo) lds_barrier();  // every wave is done with the previous chunk's fc2 reads of bufU
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) {
       gelu_lp4(acc1[pt][0]);
@@ -425,7 +445,17 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
     g_deep_t[blockIdx.x * 16 + 8] = dt_fc1; g_deep_t[blockIdx.x * 16 + 9] = dt_gelu; g_deep_t[blockIdx.x * 16 + 10] = dt_fc2;
   }
 #endif
-  {
+  if (nsp > 1) {
+#pragma unroll
+    for (int pt = 0; pt < PTS; ++pt) {
+      const long m = m0 + 16 * pt + p;
+      if (m < P.n) {
+        float* dst = P.part + ((size_t)js * P.n + m) * C + ch0;
+        *reinterpret_cast<f32x4_t*>(dst) = acc2[pt][0];
+        *reinterpret_cast<f32x4_t*>(dst + 4) = acc2[pt][1];
+      }
+    }
+  } else {
     const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(pr + 3 * C + ch0), b1 = *reinterpret_cast<const f32x4_t*>(pr + 3 * C + ch0 + 4);
 #pragma unroll
     for (int pt = 0; pt < PTS; ++pt) {
@@ -439,6 +469,28 @@ __global__ __launch_bounds__(2 * C, 2) void deep_tail_kernel(DeepTailP P) {
     }
   }
   DT_STAMP(7);
+}
+
+// x = sum_js part[js] + b2 (js in ascending order: the result does not depend on which workgroup finished first), xc = T(x)
+__global__ __launch_bounds__(256) void deep_tail_reduce_kernel(const float* __restrict__ part, int nsplit, long n, int C,
+                                                               const float* __restrict__ b2, float* x, int ldx, bf16_t* xc,
+                                                               int ldxc) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-channel piece of a row
+  const int per_row = C / 8;
+  if (u >= n * per_row) return;
+  const long m = u / per_row;
+  const int ch = (int)(u % per_row) * 8;
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(part + m * C + ch), b = *reinterpret_cast<const f32x4_t*>(part + m * C + ch + 4);
+  for (int js = 1; js < nsplit; ++js) {
+    const float* src = part + ((size_t)js * n + m) * C + ch;
+    a += *reinterpret_cast<const f32x4_t*>(src);
+    b += *reinterpret_cast<const f32x4_t*>(src + 4);
+  }
+  a += *reinterpret_cast<const f32x4_t*>(b2 + ch);
+  b += *reinterpret_cast<const f32x4_t*>(b2 + ch + 4);
+  *reinterpret_cast<f32x4_t*>(x + m * ldx + ch) = a;
+  *reinterpret_cast<f32x4_t*>(x + m * ldx + ch + 4) = b;
+  if (xc) *reinterpret_cast<uint4*>(xc + m * ldxc + ch) = pack8(a, b);
 }
 
 // ---- weight images.  One product phase: KS steps x 2 fragments per wave.  16-byte unit
@@ -474,6 +526,25 @@ int pack_phase(const void* w, int ld, int C, int S, int step0, int row_base, int
 // rows per workgroup: 128 when that still gives most CUs a workgroup, else 32 (single scenes, the deepest levels)
 inline int pick_bm(long n) { return (n + 127) / 128 >= 160 ? 128 : 32; }
 
+// Few-row launches (32-row tiles that leave most of the 256 CUs without a workgroup): cut a tile's weight stream over several
+// workgroups - the head by q / k / v column block (3), the tail by hidden chunks (4, or 2) - while the grid stays within one
+// workgroup per CU, and only at C = 512, whose 16-wave workgroup streams 2 / 4.7 MB per tile.  Measured (profiles/
+// r06_deep_split.txt): 778 rows x 512: head 27.7 (separate launches) / 28.1 (one workgroup per tile) -> 19.9 us, tail 40.7 /
+// 55.3 -> 28.1 us incl. the reduce launch; at 6224 rows (195 tiles: 585 / 780 workgroups) the split LOSES (34 -> 62, 58 ->
+// 82 us), and so it does at C = 256 with 106 tiles (12.3 -> 14.1, 17.8 -> 24.6 us): hence the cap and the channel count.
+inline int pick_head_split(long n, int C, int bm) {
+  const long tiles = (n + bm - 1) / bm;
+  return (bm == 32 && C >= cdseg_knob("CDSEG_DEEP_SPLIT_MIN_C", 512) && tiles * 3 <= cdseg_knob("CDSEG_DEEP_SPLIT_MAX_WGS", 256)) ? 3 : 1;
+}
+inline int pick_tail_split(long n, int C, int bm, size_t ws_bytes) {
+  const long tiles = (n + bm - 1) / bm;
+  if (bm != 32 || C < cdseg_knob("CDSEG_DEEP_SPLIT_MIN_C", 512)) return 1;
+  const long cap = cdseg_knob("CDSEG_DEEP_SPLIT_MAX_WGS", 256);
+  for (int k = 4; k >= 2; k >>= 1)
+    if (tiles * k <= cap && (size_t)k * n * C * 4 <= ws_bytes) return k;
+  return 1;
+}
+
 template <int C, int BM>
 int launch_head(const DeepHeadP& p, hipStream_t s) {
   constexpr int lds = DeepCfg<C, BM>::HEAD_LDS;
@@ -483,7 +554,7 @@ int launch_head(const DeepHeadP& p, hipStream_t s) {
       return CDSEG_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL((deep_head_kernel<C, BM>), dim3((unsigned)((p.n + BM - 1) / BM)), dim3(2 * C), lds, s, p);
+  hipLaunchKernelGGL((deep_head_kernel<C, BM>), dim3((unsigned)((p.n + BM - 1) / BM) * (unsigned)p.nsplit), dim3(2 * C), lds, s, p);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }
@@ -497,8 +568,14 @@ int launch_tail(const DeepTailP& p, hipStream_t s) {
       return CDSEG_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL((deep_tail_kernel<C, BM>), dim3((unsigned)((p.n + BM - 1) / BM)), dim3(2 * C), lds, s, p);
+  hipLaunchKernelGGL((deep_tail_kernel<C, BM>), dim3((unsigned)((p.n + BM - 1) / BM) * (unsigned)p.nsplit), dim3(2 * C), lds, s, p);
   CDSEG_CHECK_LAUNCH();
+  if (p.nsplit > 1) {
+    const long units = p.n * (C / 8);
+    hipLaunchKernelGGL(deep_tail_reduce_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, p.part, p.nsplit, p.n, C,
+                       p.b2, p.x, p.ldx, p.xc, p.ldxc);
+    CDSEG_CHECK_LAUNCH();
+  }
   return CDSEG_OK;
 }
 
@@ -537,15 +614,18 @@ int deep_pack(int C, const void* wl, const void* wqkv, void* head_img, const voi
   return CDSEG_OK;
 }
 
-int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b, float* x,
-              int ldx, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
+int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b,
+              const float* x, int ldx, float* x_out, int ldxo, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
               int ldqkv, long n, int channels, int qkv_flags, hipStream_t s) {
   DeepHeadP p;
   p.v_bf16 = (qkv_flags & CDSEG_ATTN_V_BF16) ? 1 : 0;
   p.y = (const bf16_t*)y; p.wimg = (const uint4*)head_img; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
+  p.x_out = x_out; p.ldxo = ldxo;
   p.colbias = colbias; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.bqkv = bqkv; p.qkv = (bf16_t*)qkv;
   p.n = n; p.ldy = ldy; p.ldx = ldx; p.ldqkv = ldqkv; p.eps = eps;
-  const int bm = cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
+  const int bm = channels == 512 ? 32 : cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
+  // (in place - x_out == x - a split launch would race: the three workgroups of a tile read the rows one of them rewrites)
+  p.nsplit = (cdseg_knob("CDSEG_DEEP_SPLIT", 1) && (const float*)x_out != x) ? pick_head_split(n, channels, bm) : 1;
   if (channels == 128) return bm == 128 ? launch_head<128, 128>(p, s) : launch_head<128, 32>(p, s);
   if (channels == 256) return bm == 128 ? launch_head<256, 128>(p, s) : launch_head<256, 32>(p, s);
   if (channels == 512) return launch_head<512, 32>(p, s);
@@ -553,11 +633,15 @@ int deep_head(const void* y, int ldy, const void* head_img, const float* bl, con
 }
 
 int deep_tail(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b, float eps,
-              const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n, int channels, hipStream_t s) {
+              const float* b1, const float* b2, const float* x_in, int ldxi, float* x, int ldx, void* xc, int ldxc, long n,
+              int channels, void* ws, size_t ws_bytes, hipStream_t s) {
   DeepTailP p;
   p.o = (const bf16_t*)o; p.wimg = (const uint4*)tail_img; p.bp = bp; p.ln_g = ln_g; p.ln_b = ln_b; p.b1 = b1; p.b2 = b2;
+  p.x_in = x_in; p.ldxi = ldxi;
   p.x = x; p.xc = (bf16_t*)xc; p.n = n; p.ldo = ldo; p.ldx = ldx; p.ldxc = ldxc; p.eps = eps;
-  const int bm = cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
+  const int bm = channels == 512 ? 32 : cdseg_knob("CDSEG_DEEP_BM", pick_bm(n));
+  p.nsplit = (ws && cdseg_knob("CDSEG_DEEP_SPLIT", 1) && !(((uintptr_t)ws) & 15)) ? pick_tail_split(n, channels, bm, ws_bytes) : 1;
+  p.part = (float*)ws;
   if (channels == 128) return bm == 128 ? launch_tail<128, 128>(p, s) : launch_tail<128, 32>(p, s);
   if (channels == 256) return bm == 128 ? launch_tail<256, 128>(p, s) : launch_tail<256, 32>(p, s);
   if (channels == 512) return launch_tail<512, 32>(p, s);

@@ -86,6 +86,31 @@ struct GemmP {
 #endif
 };
 
+// ---- "fp32 x3" compute type (round 6; CDSEG_F32X3): A and W are fp32 in memory; on their way into LDS every value is split
+// into an IEEE-half pair, x ~= hi + lo' / 2048 (hi = rn(x), lo' = rn((x - hi) * 2048): 22 significant bits, the scaled low
+// part stays clear of half's subnormals), and a product runs as THREE half MFMAs - hi hi' into one accumulator, hi lo' +
+// lo' hi' into a second one that is folded in with 2^-11 at the end (the lo' lo'' term, <= 2^-22 of the product, is dropped).
+// fp32 accumulation as before.  3 x v_mfma_f32_16x16x32_f16 (48 cycles) replace 8 x v_mfma_f32_16x16x4_f32 (256 cycles) per
+// 16 x 16 x 32 block: the parity mode's 1e-3 logit bound at a multiple of the exact-fp32 rate.  Range: |x| <= 65504
+// (saturating, as in the half trunk).
+struct F32X3 { float v; };
+template <typename CT> constexpr bool kIsX3 = false;
+template <> constexpr bool kIsX3<F32X3> = true;
+typedef _Float16 x3_f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 x3_f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const hw_f32x2_t v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+  const x3_f16x2_t h = __builtin_convertvector(v, x3_f16x2_t);
+  const hw_f32x2_t hf = __builtin_convertvector(h, hw_f32x2_t);
+  const hw_f32x2_t r = (v - hf) * 2048.f;
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, x3_f16x2_t));
+}
+__device__ __forceinline__ f32x4_t x3_mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8_t, a), __builtin_bit_cast(x3_f16x8_t, b), c, 0, 0, 0);
+}
+
 template <int NCH>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   constexpr int RB = NCH * 16;
@@ -625,24 +650,43 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
       }
     }
   };
+  // x3: a row of the LDS tile holds the hi plane in chunks [0, NCH / 2) and the scaled lo plane in [NCH / 2, NCH); a thread's
+  // four floats (float chunk ch) become 8 bytes of each plane
+  auto store_x3 = [&](char* base, int row, int ch, const uint4& r) {
+    uint2 hi, lo;
+    x3_split2(__uint_as_float(r.x), __uint_as_float(r.y), hi.x, lo.x);
+    x3_split2(__uint_as_float(r.z), __uint_as_float(r.w), hi.y, lo.y);
+    *reinterpret_cast<uint2*>(base + lds_off<NCH>(row, ch >> 1) + ((ch & 1) << 3)) = hi;
+    *reinterpret_cast<uint2*>(base + lds_off<NCH>(row, NCH / 2 + (ch >> 1)) + ((ch & 1) << 3)) = lo;
+  };
   auto store_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const int id = i * NT + tid;
-      if (id < A_CH) *reinterpret_cast<uint4*>(As + lds_off<NCH>(id / NCH, id % NCH)) = a_reg[i];
+      if (id < A_CH) {
+        if constexpr (kIsX3<CT>) store_x3(As, id / NCH, id % NCH, a_reg[i]);
+        else *reinterpret_cast<uint4*>(As + lds_off<NCH>(id / NCH, id % NCH)) = a_reg[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
       const int id = i * NT + tid;
-      if (id < B_CH) *reinterpret_cast<uint4*>(Bs + lds_off<NCH>(id / NCH, id % NCH)) = b_reg[i];
+      if (id < B_CH) {
+        if constexpr (kIsX3<CT>) store_x3(Bs, id / NCH, id % NCH, b_reg[i]);
+        else *reinterpret_cast<uint4*>(Bs + lds_off<NCH>(id / NCH, id % NCH)) = b_reg[i];
+      }
     }
   };
 
   f32x4_t acc[2][TN];
+  f32x4_t accx[kIsX3<CT> ? 2 : 1][kIsX3<CT> ? TN : 1];  // x3: the cross terms hi lo' + lo' hi', scaled by 2^11
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) {
+      acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if constexpr (kIsX3<CT>) accx[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
   const int fr = lane & 15, fg = lane >> 4;
 
@@ -657,7 +701,31 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
   for (int kc = kc0; kc < kc1; ++kc) {
     if (kc + 1 < kc1) load_tiles(kc + 1);  // global loads in flight during the MFMAs below
 
-    if constexpr (sizeof(CT) == 2) {
+    if constexpr (kIsX3<CT>) {
+      constexpr int HC = NCH / 2;  // 16-byte chunks per plane
+#pragma unroll
+      for (int kk = 0; kk < HC / 4; ++kk) {
+        bf16x8_t ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off<NCH>(wm * 32 + i * 16 + fr, 4 * kk + fg));
+          al[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off<NCH>(wm * 32 + i * 16 + fr, HC + 4 * kk + fg));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<NCH>(wn * (BN / 2) + j * 16 + fr, 4 * kk + fg));
+          bl[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off<NCH>(wn * (BN / 2) + j * 16 + fr, HC + 4 * kk + fg));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = x3_mfma(ah[i], bh[j], acc[i][j]);
+            accx[i][j] = x3_mfma(ah[i], bl[j], accx[i][j]);
+            accx[i][j] = x3_mfma(al[i], bh[j], accx[i][j]);
+          }
+      }
+    } else if constexpr (sizeof(CT) == 2) {
 #pragma unroll
       for (int kk = 0; kk < NCH / 4; ++kk) {
         bf16x8_t a[2], b[TN];
@@ -704,6 +772,12 @@ __global__ __launch_bounds__(4 * BM, BM >= 128 ? 4 : 1) void gemm_kernel(GemmP g
     __syncthreads();
   }
 
+  if constexpr (kIsX3<CT>) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += accx[i][j] * (1.0f / 2048.f);
+  }
   tile_epilogue<BN, BM>(g, acc, smem, tid, lane, wm, wn, m0, n0, zs);
 }
 
@@ -1410,11 +1484,12 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W || !a->out) return CDSEG_ERR_ARG;
   if (a->M <= 0 || a->N <= 0) return CDSEG_OK;
   if (a->K <= 0 || (a->K & 7) || a->K > 65536 || a->kvol <= 0 || a->kvol > 128) return CDSEG_ERR_ARG;
-  if (a->a_dtype != a->compute_dtype) return CDSEG_ERR_UNSUPPORTED;
+  // (CDSEG_F32X3: fp32 operands in memory, split-half arithmetic on the matrix pipe)
+  if (a->a_dtype != a->compute_dtype && !(a->compute_dtype == CDSEG_F32X3 && a->a_dtype == CDSEG_F32)) return CDSEG_ERR_UNSUPPORTED;
   if (a->scale && !a->shift) return CDSEG_ERR_ARG;
   if (a->add_src && !a->add_idx) return CDSEG_ERR_ARG;
   if (!a->nbr && a->kvol != 1) return CDSEG_ERR_ARG;
-  const int esz = a->compute_dtype == CDSEG_F32 ? 4 : 2;
+  const int esz = a->compute_dtype == CDSEG_BF16 ? 2 : 4;
   if (((long)a->lda * esz) & 15) return CDSEG_ERR_ARG;  // 16-byte row alignment for the vector loads
   GemmP p;
 #ifdef CDSEG_EXPERIMENTS
@@ -1462,6 +1537,7 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   int rc = CDSEG_ERR_ARG;
   if (a->compute_dtype == CDSEG_BF16) rc = a->nbr ? launch<bf16_t, true>(p, wsb, s) : launch<bf16_t, false>(p, wsb, s);
   else if (a->compute_dtype == CDSEG_F32) rc = a->nbr ? launch<float, true>(p, wsb, s) : launch<float, false>(p, wsb, s);
+  else if (a->compute_dtype == CDSEG_F32X3) rc = a->nbr ? launch<F32X3, true>(p, wsb, s) : launch<F32X3, false>(p, wsb, s);
   if (prof) cdseg_prof_end(tok, s);
   return rc;
 }

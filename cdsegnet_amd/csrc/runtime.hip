@@ -26,10 +26,12 @@ struct Carver {
 constexpr int FUSE_LN_MAX_C = 512;  // widest row one GEMM block finishes (LayerNorm fused into the epilogue)
 constexpr size_t SPLITK_WS_CAP = (size_t)64 << 20;
 
-inline size_t esz(int dtype) { return dtype == CDSEG_F32 ? 4 : 2; }
+inline size_t esz(int dtype) { return dtype == CDSEG_BF16 ? 2 : 4; }
+// storage type of a descriptor's activations / weights: CDSEG_F32X3 is fp32 in memory (split-half arithmetic, gemm.hip)
+inline int storage_dtype(int dtype) { return dtype == CDSEG_F32X3 ? CDSEG_F32 : dtype; }
 
 struct Layout {
-  void *y, *h, *qkv, *o, *u, *y2, *ws;
+  void *y, *h, *qkv, *o, *u, *y2, *ws, *xs;
   size_t ws_bytes, total;
 };
 
@@ -56,6 +58,9 @@ Layout carve(const cdseg_block_desc* d, long n, void* scratch) {
   }
   if (L.ws_bytes > SPLITK_WS_CAP) L.ws_bytes = SPLITK_WS_CAP;
   L.ws = L.ws_bytes ? c.take(L.ws_bytes) : nullptr;
+  // deep stages: the residual rows between the fused head and the fused tail live here (head reads x, writes xs; tail reads
+  // xs, writes x), which lets the few-row launches split a tile over several workgroups (deep.hip, cdseg_*_rr2)
+  L.xs = (d->dtype == CDSEG_BF16 && C >= 128 && d->head_img && d->tail_img) ? c.take(n * C * 4) : nullptr;
   L.total = align_up(c.off, 256);
   return L;
 }
@@ -65,7 +70,8 @@ cdseg_gemm_args base_args(const cdseg_block_desc* d, const Layout& L, long n) {
   std::memset(&a, 0, sizeof(a));
   a.M = n;
   a.kvol = 1;
-  a.a_dtype = a.compute_dtype = d->dtype;
+  a.a_dtype = storage_dtype(d->dtype);
+  a.compute_dtype = d->dtype;
   a.ws = L.ws;
   a.ws_bytes = L.ws_bytes;
   a.ln_eps = d->ln_eps;
@@ -83,7 +89,7 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
 
 extern "C" int cdseg_block_forward(const cdseg_block_desc* d, const cdseg_block_io* io, void* stream) {
   const int rc = block_forward_impl(d, io, stream);
-  if (rc != CDSEG_OK || !io->sat_counter || io->n <= 0 || d->dtype != CDSEG_BF16) return rc;
+  if (rc != CDSEG_OK || !io->sat_counter || io->n <= 0 || d->dtype != CDSEG_BF16) return rc;  // (16-bit trunks only)
   // diagnostic (IEEE-half build): clamped values in the Block's 16-bit buffers that reach memory - conv output, q and k
   // (v may be bfloat16), attention output, shadow copy of the residual stream.  LayerNorm outputs and the MLP's hidden
   // units live inside the fused kernels and are not seen.
@@ -103,7 +109,7 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
     return CDSEG_ERR_ARG;
   const long n = io->n;
   if (n <= 0) return CDSEG_OK;
-  const int C = d->channels, T = d->dtype;
+  const int C = d->channels, T = storage_dtype(d->dtype);  // T: what the buffers hold; d->dtype: how products are computed
   if (C != d->heads * CDSEG_HEAD_DIM) return CDSEG_ERR_UNSUPPORTED;
   const Layout L = carve(d, n, io->scratch);
   if (!io->scratch || io->scratch_bytes < L.total) return CDSEG_ERR_WORKSPACE;
@@ -134,12 +140,22 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
   static const bool deep_on = cdseg_knob("CDSEG_DEEP_FUSED", 1) != 0;
   // C = 512: a workgroup streams the Block's whole weight set (2 + 4.7 MB) through ONE CU at ~85 GB/s, ~58 us whatever the
   // row count - a win from ~2.5 k rows (8 collated scenes: 6.2 k rows, head 51 -> 35 us, tail 85 -> 61 us), a loss on a single
-  // scene's 800 rows (tail 42 -> 56 us), which keeps the separate launches (profiles/r05_deep512.txt)
+  // scene's 800 rows (tail 42 -> 56 us; profiles/r05_deep512.txt).  Round 6: below that row count the tile's weight stream is
+  // cut over 3 / 4 workgroups (cdseg_*_rr2, residual rows ping-ponged through the scratch arena), which needs L.xs
   static const long deep512_min = cdseg_knob("CDSEG_DEEP512_MIN_ROWS", CDSEG_DEEP512_MIN_ROWS);
-  const bool deep = deep_on && T == CDSEG_BF16 && (C == 128 || C == 256 || (C == 512 && n >= deep512_min)) &&
-                    d->hidden == 4 * C;
+  static const bool deep512_split = cdseg_knob("CDSEG_DEEP_SPLIT", 1) != 0;
+  const bool deep = deep_on && T == CDSEG_BF16 &&
+                    (C == 128 || C == 256 || (C == 512 && (n >= deep512_min || (deep512_split && L.xs)))) && d->hidden == 4 * C;
   const bool head = (fused_head && T == CDSEG_BF16 && (C == 32 || C == 64)) || (deep && d->head_img);
-  if (head && d->head_img) {
+  const bool pingpong = deep && d->head_img && d->tail_img && L.xs;
+  if (pingpong) {
+    if ((rc = cdseg_cpe_head_rr2(L.y, C, d->head_img, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
+                                 (const float*)d->cpe_ln_b, (const float*)io->x, C, (float*)L.xs, C, (const float*)io->tbias,
+                                 (const float*)d->norm1_g, (const float*)d->norm1_b, d->ln_eps, (const float*)d->qkv_b, L.qkv,
+                                 3 * C, n, C, CDSEG_ATTN_V_BF16, stream)) != CDSEG_OK)
+      return rc;
+    attn_flags |= CDSEG_ATTN_V_BF16;
+  } else if (head && d->head_img) {
     // wide stages: weights resident in LDS, activations in registers (blockrr.hip)
     if ((rc = cdseg_cpe_head_rr(L.y, C, d->head_img, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
                                 (const float*)d->cpe_ln_b, (float*)io->x, C, (const float*)io->tbias,
@@ -186,10 +202,16 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
     const char* q = (const char*)L.qkv;
     if ((rc = cdseg_attention_ex(q, q + (size_t)C * e, q + (size_t)2 * C * e, 3 * C, 3 * C, 3 * C, io->gidx, io->gidx,
                                  io->widx, io->patch_start, io->num_patches, d->heads, io->max_len, d->attn_scale, L.o, C,
-                                 T, attn_flags, stream)) != CDSEG_OK)
+                                 d->dtype, attn_flags, stream)) != CDSEG_OK)
       return rc;
   }
   static const bool fused_tail = cdseg_knob("CDSEG_FUSED_TAIL", 1) != 0 && cdseg_knob("CDSEG_FUSED_MLP", 1) != 0;
+  if (pingpong) {
+    void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
+    return cdseg_attn_tail_rr2(L.o, C, d->tail_img, (const float*)d->proj_b, (const float*)d->norm2_g, (const float*)d->norm2_b,
+                               d->ln_eps, (const float*)d->fc1_b, (const float*)d->fc2_b, (const float*)L.xs, C, (float*)io->x,
+                               C, xc, C, n, C, L.ws, L.ws_bytes, stream);
+  }
   if (deep && d->tail_img) {
     void* xc = (const void*)io->xc_out != (const void*)io->x ? io->xc_out : nullptr;
     return cdseg_attn_tail_rr(L.o, C, d->tail_img, (const float*)d->proj_b, (const float*)d->norm2_g, (const float*)d->norm2_b,

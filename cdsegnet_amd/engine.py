@@ -179,7 +179,7 @@ class _HeadsInFp32:
 
 
 class Engine:
-    PRECISIONS = ("bf16", "bf16+head", "fp16", "fp16+head", "fp32")
+    PRECISIONS = ("bf16", "bf16+head", "fp16", "fp16+head", "fp32", "fp32x3")
 
     def __init__(self, model, precision="bf16", variant=None):
         """precision: the 16-bit trunk type ("bf16*": bfloat16, "fp16*": IEEE half - the library is built once for each,
@@ -195,7 +195,11 @@ class Engine:
             raise ValueError(f"conditional PT-v3m1 needs 3 c-branch and 5 n-branch stages (ptv3.py:1785-1794), got "
                              f"{bb.c_num_stages} / {bb.n_num_stages}")
         self.variant = variant or ("f16" if precision.startswith("fp16") else "bf16")
-        self.T = torch.float32 if precision == "fp32" else ops.LP_DTYPES[self.variant]
+        # "fp32x3": the fp32 engine (fp32 tensors, the reference's order of operations) with every matrix product computed as
+        # three IEEE-half MFMAs on split operands (csrc/gemm.hip, attention.hip): inside north_star's 1e-3 at a multiple of the
+        # exact-fp32 MFMA rate
+        self.x3 = precision == "fp32x3"
+        self.T = torch.float32 if precision in ("fp32", "fp32x3") else ops.LP_DTYPES[self.variant]
         self.device = None
         self.w = None
         self.rng_offset = 0
@@ -440,7 +444,8 @@ class Engine:
                     t["head_img"] = w[pre + ".head_img"]
                 self.block_desc[pre] = ops.make_block_desc(T, mod.channels, mod.attn.num_heads, w[pre + ".fc1.w"].shape[0],
                                                            mod.attn.scale, 1e-5, t,
-                                                           attn_flags=ops.ATTN_Q_PRESCALED if self.q_prescaled else 0)
+                                                           attn_flags=ops.ATTN_Q_PRESCALED if self.q_prescaled else 0,
+                                                           x3=self.x3)
         self._scratch = {}
         self._scratch_bytes = {}
 
@@ -715,13 +720,18 @@ class Engine:
             return
         qkv = self._buf(n, 3 * c, self.T)
         aflags = ops.ATTN_Q_PRESCALED if self.q_prescaled else 0  # what the qkv producer has done for the attention kernel
-        deep_ok = c != 512 or n >= ops.DEEP512_MIN_ROWS  # (as the native executor decides, csrc/runtime.hip)
-        if (pre + ".head_img") in w and deep_ok and not ops.cpe_head_fused_ok(st.xc):  # deep stages (C = 128 / 256 / 512): csrc/deep.hip
+        # deep stages (C = 128 / 256 / 512: csrc/deep.hip), as the native executor runs them (csrc/runtime.hip): the residual rows
+        # go head -> tail through a second buffer (`xs`), which lets the few-row launches split a tile over several workgroups
+        deep_rr = ((pre + ".head_img") in w and (pre + ".tail_img") in w and not ops.cpe_head_fused_ok(st.xc)
+                   and hasattr(ops, "cpe_head_rr2"))
+        xs = None
+        if deep_rr:
             y = self._buf(n, c, self.T)
             self._conv3(st.xc, pre + ".cpe0", lv, y)
-            ops.cpe_head_rr(y, w[pre + ".head_img"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x,
-                            tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.b"], qkv,
-                            qkv_flags=ops.ATTN_V_BF16)
+            xs = self._buf(n, c, torch.float32)
+            ops.cpe_head_rr2(y, w[pre + ".head_img"], w[pre + ".cpe1.b"], (w[pre + ".cpe2.g"], w[pre + ".cpe2.b"]), st.x, xs,
+                             tbias, (w[pre + ".norm1.g"], w[pre + ".norm1.b"]), w[pre + ".qkv.b"], qkv,
+                             qkv_flags=ops.ATTN_V_BF16)
             aflags |= ops.ATTN_V_BF16
         elif ops.cpe_head_fused_ok(st.xc):  # big stages: cpe linear + LN + residual + LN1 + qkv in one launch
             y = self._buf(n, c, self.T)
@@ -756,10 +766,10 @@ class Engine:
             ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], gidx, gidx, widx, patch_start, att.num_heads,
                           max_len, att.scale, o, work=64.0 * att.num_heads * sum_l2, flags=aflags)
         hid = w[pre + ".fc1.w"].shape[0]
-        if (pre + ".tail_img") in w and deep_ok and not ops.attn_tail_fused_ok(o, hid):  # deep stages: proj + LN2 + MLP, one launch
+        if xs is not None:  # deep stages: proj + LN2 + MLP, one launch (+ the reduce launch of a split one)
             st.xc = self._buf(n, c, self.T)
-            ops.attn_tail_rr(o, w[pre + ".tail_img"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
-                             w[pre + ".fc1.b"], w[pre + ".fc2.b"], st.x, st.xc)
+            ops.attn_tail_rr2(o, w[pre + ".tail_img"], w[pre + ".proj.b"], w[pre + ".norm2.g"], w[pre + ".norm2.b"],
+                              w[pre + ".fc1.b"], w[pre + ".fc2.b"], xs, st.x, st.xc, ws=self.scratch(4 * n * c * 4 + 256))
             return
         if ops.attn_tail_fused_ok(o, hid):  # big stages: proj + LN2 + MLP in one launch
             st.xc = self._buf(n, c, self.T)
@@ -897,10 +907,19 @@ class Engine:
         o = self._buf(n, cq, self.T)
         ops.attention(q, kv[:, :cq], kv[:, cq:], q_gidx, kv_gidx, widx, patch_start, att.num_heads, max_len, att.scale, o,
                       work=64.0 * att.num_heads * sum_l2, flags=ops.ATTN_Q_PRESCALED if self.q_prescaled else 0)
-        if "x.tail_img" in w and n >= ops.DEEP512_MIN_ROWS:  # (fewer rows: the separate launches are faster, csrc/runtime.hip)
+        if "x.tail_img" in w and n >= ops.DEEP512_MIN_ROWS:
             nst.xc = self._buf(n, cq, self.T)
             ops.attn_tail_rr(o, w["x.tail_img"], w["x.proj.b"], w["x.q_norm2.g"], w["x.q_norm2.b"], w["x.fc1.b"], w["x.fc2.b"],
                              nst.x, nst.xc)
+            return
+        if "x.tail_img" in w and hasattr(ops, "attn_tail_rr2"):
+            # few rows (a single scene's bottleneck): the tile's weight stream cut over four workgroups (csrc/deep.hip) - the
+            # residual is read from the old rows and the result lands in fresh ones, so no workgroup reads what another writes
+            x_new = self._buf(n, cq, torch.float32)
+            nst.xc = self._buf(n, cq, self.T)
+            ops.attn_tail_rr2(o, w["x.tail_img"], w["x.proj.b"], w["x.q_norm2.g"], w["x.q_norm2.b"], w["x.fc1.b"], w["x.fc2.b"],
+                              nst.x, x_new, nst.xc, ws=self.scratch(4 * n * cq * 4 + 256))
+            nst.x = x_new
             return
         if cb.tm_feat == 1.0:
             ops.gemm(o, w["x.proj.w"], nst.x, bias=w["x.proj.b"], res=nst.x)
@@ -1040,19 +1059,25 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def inference(self, input_dict, noise_level=None, draws=None):
         """Single-step inference (ref: default.py:371-422)."""
+        prev = ops.set_f32x3(self.x3) if hasattr(ops, "set_f32x3") else None
         try:
             with _lib.use(self.variant):
                 return self._inference(input_dict, noise_level, draws)
         finally:
+            if prev is not None:
+                ops.set_f32x3(prev)
             if hasattr(ops, "unbind_stream"):
                 ops.unbind_stream()
 
     def inference_ddim(self, input_dict, step=1, mode="avg", noise_level=None, draws=None):
         """Multi-step inference MSAI (mode="avg") / MSFI ("final") (ref: default.py:278-369)."""
+        prev = ops.set_f32x3(self.x3) if hasattr(ops, "set_f32x3") else None
         try:
             with _lib.use(self.variant):
                 return self._inference_ddim(input_dict, step, mode, noise_level, draws)
         finally:
+            if prev is not None:
+                ops.set_f32x3(prev)
             if hasattr(ops, "unbind_stream"):
                 ops.unbind_stream()
 

@@ -137,6 +137,7 @@ class _ThreadState(threading.local):
         self.stream = None      # ctypes.c_void_p of the bound HIP stream
         self.stream_obj = None  # the torch stream object
         self.gemm_cache = {}
+        self.f32x3 = False  # fp32 products of this thread's calls run as three half MFMAs on split operands (set_f32x3)
         self.block_io = None
 
 
@@ -459,6 +460,16 @@ def pad_plan_batch(items, nb):
     return res
 
 
+F32X3 = 2  # include/cdseg.h CDSEG_F32X3: fp32 in memory, split-half arithmetic on the matrix pipe
+
+
+def set_f32x3(on):
+    """This thread's fp32 `gemm` / `attention` calls compute in the split-half "fp32 x3" form (csrc/gemm.hip) from now on;
+    returns the previous setting.  The engine of precision "fp32x3" brackets its forwards with it."""
+    prev, _TLS.f32x3 = _TLS.f32x3, bool(on)
+    return prev
+
+
 def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None, add_src=None, add_idx=None,
          nbr=None, out_idx=None, out2=None, out2_pre_add=False, M=None, kvol=1, colbias=None, ln_pre=None,
          nbr_kmajor=False,
@@ -470,7 +481,8 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
     if not A.is_cuda:
         _need_gpu(A, W, out)
     # the weight-side half of the argument block is static per layer: cache it keyed by the weight tensor
-    key = (W.data_ptr(), _dp(bias), _dp(scale), _dp(shift), int(kvol), int(act))
+    x3 = _TLS.f32x3 and W.dtype == torch.float32
+    key = (W.data_ptr(), _dp(bias), _dp(scale), _dp(shift), int(kvol), int(act), x3)
     cache_d = _TLS.gemm_cache
     ent = cache_d.get(key) if cache else None
     if ent is None:
@@ -482,7 +494,7 @@ def gemm(A, W, out, *, bias=None, scale=None, shift=None, act=ACT_NONE, res=None
         a.N = W.shape[0]
         a.kvol = int(kvol)
         a.K = W.shape[1] // a.kvol
-        a.compute_dtype = dt(W)
+        a.compute_dtype = F32X3 if x3 else dt(W)
         a.act = int(act)
         ent = (a, ctypes.byref(a), W)  # keep W alive with the cache entry
         if cache:
@@ -627,6 +639,26 @@ def cpe_head_rr(y, head_img, bl, lnp, x, colbias, ln1, bqkv, qkv, eps=1e-5, qkv_
     return qkv
 
 
+def cpe_head_rr2(y, head_img, bl, lnp, x, x_out, colbias, ln1, bqkv, qkv, eps=1e-5, qkv_flags=0):
+    """Deep stages: `cpe_head_rr` with the residual rows read from x and written to x_out (distinct buffers let few-row launches
+    split a tile over three workgroups, csrc/deep.hip)."""
+    check(_lib.load().cdseg_cpe_head_rr2(_ptr(y), y.stride(0), _ptr(head_img), _ptr(bl), _ptr(lnp[0]), _ptr(lnp[1]), _ptr(x),
+                                         x.stride(0), _ptr(x_out), x_out.stride(0), _ptr(colbias), _ptr(ln1[0]), _ptr(ln1[1]),
+                                         float(eps), _ptr(bqkv), _ptr(qkv), qkv.stride(0), y.shape[0], y.shape[1],
+                                         int(qkv_flags), _stream()), "cpe_head_rr2")
+    return qkv
+
+
+def attn_tail_rr2(o, tail_img, bp, ln_g, ln_b, b1, b2, x_in, x, xc=None, ws=None, eps=1e-5):
+    """Deep stages: `attn_tail_rr` with the residual read from x_in, the result written to x; ws: fp32 / byte workspace that
+    allows the few-row hidden-chunk split (>= 4 * n * C * 4 bytes for four workgroups per tile)."""
+    check(_lib.load().cdseg_attn_tail_rr2(_ptr(o), o.stride(0), _ptr(tail_img), _ptr(bp), _ptr(ln_g), _ptr(ln_b), float(eps),
+                                          _ptr(b1), _ptr(b2), _ptr(x_in), x_in.stride(0), _ptr(x), x.stride(0), _ptr(xc),
+                                          xc.stride(0) if xc is not None else 0, o.shape[0], o.shape[1], _ptr(ws),
+                                          0 if ws is None else ws.numel() * ws.element_size(), _stream()), "attn_tail_rr2")
+    return x
+
+
 def attn_tail_rr(o, tail_img, bp, ln_g, ln_b, b1, b2, x, xc=None, eps=1e-5):
     check(_lib.load().cdseg_attn_tail_rr(_ptr(o), o.stride(0), _ptr(tail_img), _ptr(bp), _ptr(ln_g), _ptr(ln_b), float(eps),
                                          _ptr(b1), _ptr(b2), _ptr(x), x.stride(0), _ptr(xc),
@@ -639,12 +671,12 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
-def make_block_desc(dtype, channels, heads, hidden, attn_scale, ln_eps, tensors, attn_flags=0):
+def make_block_desc(dtype, channels, heads, hidden, attn_scale, ln_eps, tensors, attn_flags=0, x3=False):
     """Describe one Block's weights once (tensors: dict field -> tensor); returns an object to pass to
     block_forward.  The tensors are kept alive by the returned handle.  attn_flags: ATTN_Q_PRESCALED when the q rows of
     qkv_w / qkv_b (and the images packed from them) carry attn_scale * log2(e)."""
     d = _lib.BlockDesc()
-    d.dtype, d.channels, d.heads, d.hidden = _DT[dtype], int(channels), int(heads), int(hidden)
+    d.dtype, d.channels, d.heads, d.hidden = (F32X3 if (x3 and dtype == torch.float32) else _DT[dtype]), int(channels), int(heads), int(hidden)
     d.attn_scale, d.ln_eps = float(attn_scale), float(ln_eps)
     d.attn_flags = int(attn_flags)
     for k, t in tensors.items():
@@ -759,7 +791,8 @@ def attention(q, k, v, q_gidx, kv_gidx, widx, patch_start, num_heads, max_len, s
     tok = TIMER.begin("attention") if TIMER is not None else None
     check(_lib.load().cdseg_attention_ex(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(q_gidx),
                                          _ptr(kv_gidx), _ptr(widx), _ptr(patch_start), num_patches, int(num_heads),
-                                         int(max_len), float(scale), _ptr(out), out.stride(0), dt(q), int(flags), _stream()),
+                                         int(max_len), float(scale), _ptr(out), out.stride(0),
+                                         F32X3 if (_TLS.f32x3 and q.dtype == torch.float32) else dt(q), int(flags), _stream()),
           "attention")
     if tok is not None:
         TIMER.end(tok, work)

@@ -37,6 +37,9 @@ extern "C" {
 
 #define CDSEG_F32 0
 #define CDSEG_BF16 1
+/* compute type only (cdseg_gemm compute_dtype, cdseg_attention_ex dtype, cdseg_block_desc dtype): fp32 tensors in memory, every
+ * product as three IEEE-half MFMAs on split operands (x ~= hi + lo' / 2048), fp32 accumulation - csrc/gemm.hip "fp32 x3" */
+#define CDSEG_F32X3 2
 
 #define CDSEG_ORDER_Z 0
 #define CDSEG_ORDER_Z_TRANS 1
@@ -413,6 +416,20 @@ int cdseg_cpe_head_rr(const void* y, int ldy, const void* head_img, const float*
 int cdseg_attn_tail_rr(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b,
                        float eps, const float* b1, const float* b2, float* x, int ldx, void* xc, int ldxc, long n,
                        int channels, void* stream);
+/* Deep stages only (C = 128 / 256 / 512): the same two launches with the residual rows READ from one buffer (x / x_in) and
+ * WRITTEN to another (x_out / x; they may alias, which gives the in-place forms above).  With distinct buffers, launches of
+ * few rows (a single scene's deep stages: 32-row tiles on a fraction of the CUs) cut a tile's weight stream over several
+ * workgroups - the head one per q / k / v column block, the tail by MLP hidden chunks through the fp32 workspace `ws`
+ * (>= 4 * n * C * 4 bytes for the four-way split, 16-byte aligned; NULL / smaller: fewer or no splits) and a fixed-order
+ * reduce launch.  Results do not depend on scheduling; they differ from the unsplit form by fp32 summation order only.
+ * (ref: the Block's cpe linear + norms + qkv, ptv3.py:401-414, and proj + norm2 + MLP, ptv3.py:416-427) */
+int cdseg_cpe_head_rr2(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b,
+                       const float* x, int ldx, float* x_out, int ldx_out, const float* colbias, const float* ln1_g,
+                       const float* ln1_b, float eps, const float* bqkv, void* qkv, int ldqkv, long n, int channels,
+                       int qkv_flags, void* stream);
+int cdseg_attn_tail_rr2(const void* o, int ldo, const void* tail_img, const float* bp, const float* ln_g, const float* ln_b,
+                        float eps, const float* b1, const float* b2, const float* x_in, int ldx_in, float* x, int ldx, void* xc,
+                        int ldxc, long n, int channels, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ native Block executor
  * One PTv3 Block (ref: ptv3.py:399-428, eval mode) per call: the library issues every launch of the

@@ -116,6 +116,32 @@ def test_seeded_default_draws_replay_the_reference():
     assert err < 1e-3
 
 
+@pytest.mark.parametrize("name", E2E)
+def test_fp32x3_mode_matches_reference_golden(name):
+    """Round 6, precision "fp32x3": the fp32 engine with every matrix product as three half MFMAs on split operands - a path
+    inside north_star's 1e-3 at a multiple of the exact-fp32 rate.  Same goldens as the fp32 mode (logits of the reference's
+    own Python): error bound 1e-4 (measured ~1e-5), arg-max 100 %."""
+    fx = load_fixture(name + ".npz")
+    # (the golden vectors come from the reference's CPU branch: enable_flash=False patching)
+    model = build(fixture_cfg(fx), fixture_state_dict(fx), "fp32x3", enable_flash=False)
+    logits = run(model, fixture_input(fx), fixture_draws(fx),
+                 noise_level=float(fx["noise_level"]) if "noise_level" in fx.files else None)
+    err, agree = report(f"{name} fp32x3 vs reference", logits, fx["logits"])
+    assert err < 1e-4 and agree == 1.0
+
+
+def test_fp32x3_mode_full_width_vs_reference_golden_and_both_executors():
+    fx = load_fixture("full_e2e_8k.npz")
+    model = build(fixture_cfg(fx), fixture_state_dict(fx), "fp32x3")
+    a = run(model, fixture_input(fx), fixture_draws(fx))
+    err, agree = report("full width 8k fp32x3 vs reference", a, fx["logits"])
+    assert err < 2e-4 and agree == 1.0
+    model._drop_engine()
+    model.engine().use_native_blocks = False
+    b = run(model, fixture_input(fx), fixture_draws(fx))
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_native_block_executor_equals_binding_sequence(precision):
     """The C++ Block executor (cdseg_block_forward) issues the same kernels as the per-op binding path."""

@@ -392,6 +392,106 @@ def test_gemm_fused_layernorm_epilogue(ops, dtype, M, N, K):
     assert torch.equal(x3, x2) and torch.equal(h3, h)
 
 
+@pytest.fixture
+def x3(ops):
+    """This thread's fp32 products in the split-half "fp32 x3" form (ops.set_f32x3) for the duration of a test."""
+    prev = ops.set_f32x3(True)
+    yield
+    ops.set_f32x3(prev)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 96, 32), (777, 20, 64), (4096, 128, 128), (300, 512, 512), (65, 2048, 512),
+                                   (130, 40, 16), (5000, 64, 2048), (448, 512, 2048), (3392, 256, 256)])
+def test_gemm_fp32x3_is_as_good_as_fp32_on_fp32_operands(ops, x3, M, N, K):
+    """Round 6, CDSEG_F32X3 (csrc/gemm.hip): fp32 A and W, every value split into an IEEE-half pair on its way into LDS
+    (x ~= hi + lo' / 2048), three half MFMAs per product, fp32 accumulation.  Against fp64 on operands that are NOT exactly
+    representable in 16 bits, incl. tiny magnitudes (the scaled low part keeps them out of half's subnormals) and the
+    split-K / GELU / residual / second-output epilogues: the error bound of the exact-fp32 kernel, doubled."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    A[:, ::3] *= 1e-4  # small activations next to O(1) ones
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm(dev(A), dev(W), out, bias=dev(b))
+    err = (out.cpu().double() - ref).abs().max().item()
+    prev = ops.set_f32x3(False)
+    exact = torch.empty_like(out)
+    ops.gemm(dev(A), dev(W), exact, bias=dev(b))
+    ops.set_f32x3(prev)
+    err32 = (exact.cpu().double() - ref).abs().max().item()
+    report(f"gemm fp32x3 {M}x{N}x{K}", max_err=err, exact_fp32_err=err32)
+    assert err < 2 * (2e-5 * K ** 0.5 + 1e-5) and err < 8 * err32 + 2e-6
+    out2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm(dev(A), dev(W), out, bias=dev(b), act=ops.ACT_GELU, res=dev(res), out2=out2)
+    ref2 = F.gelu(ref.float()).double() + res.double()
+    assert (out.cpu().double() - ref2).abs().max().item() < 2 * (2e-5 * K ** 0.5 + 1e-4)
+    assert torch.equal(out2, out)
+
+
+def test_sparse_conv_and_layernorm_epilogue_fp32x3(ops, x3):
+    """The gathered (sparse-conv) form and the LayerNorm-fused epilogue run on the same kernel: fp32x3 vs the oracle conv /
+    fp64 LayerNorm."""
+    fx = load_fixture("serialization_lidar5000.npz")
+    zs, perm0, g0, b0, depth, p = _physical(ops, fx)
+    nbr = ops.nbr_table(zs, g0, b0, depth, 3)
+    C = 128
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(len(p), C, generator=g)
+    w = torch.randn(C, 27, C, generator=g) / (27 * C) ** 0.5
+    b = torch.randn(C, generator=g)
+    ref = OM.subm_conv3d(x, nbr.cpu().numpy().astype(np.int64), w.reshape(C, 3, 3, 3, C), b)
+    out = torch.empty(len(p), C, dtype=torch.float32, device="cuda")
+    ops.gemm(dev(x), dev(w.reshape(C, -1)), out, bias=dev(b), nbr=nbr, kvol=27)
+    err = (out.cpu() - ref).abs().max().item()
+    report("conv fp32x3 C=128", max_err=err)
+    assert err < 5e-5
+    M, N, K = 3000, 256, 256
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    bias, ga, be, res = (torch.randn(N, generator=g) for _ in range(3)), None, None, None
+    bias, ga, be = bias
+    res = torch.randn(M, N, generator=g)
+    t = A.double() @ W.double().t() + bias.double()
+    want = res.double() + F.layer_norm(t, (N,), ga.double(), be.double(), 1e-5)
+    xo = dev(res)
+    ops.gemm(dev(A), dev(W), xo, bias=dev(bias), ln_pre=(dev(ga), dev(be)), res=xo)
+    assert (xo.cpu().double() - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("lens,H,K", [([2500], 2, 1024), ([1024], 4, 1024), ([991], 32, 1024), ([26], 4, 1024),
+                                      ([1500, 1100], 2, 1024), ([700, 500, 3000], 1, 1024), ([10], 1, 4),
+                                      ([100, 37], 2, 16), ([1025], 8, 1024), ([33], 2, 1024)])
+def test_attention_fp32x3_vs_oracle(ops, x3, lens, H, K):
+    """attn_x3_kernel: fp32 q / k / v, half pairs for the scores, bfloat16 pairs for P V - against the oracle's fp32 attention
+    on the same UNROUNDED inputs; and the cross form."""
+    err, mag = _attention_case(ops, torch.float32, lens, H, K, seed=sum(lens) + H)
+    report(f"attn fp32x3 lens={lens} H={H} K={K}", max_err=err, ref_max=mag)
+    assert err < 4e-5 * (1 + mag)
+    err, mag = _attention_case(ops, torch.float32, lens, H, K, seed=sum(lens) + H + 1, cross=True)
+    assert err < 4e-5 * (1 + mag)
+
+
+def test_attention_fp32x3_takes_the_exact_pass_on_scores_outside_fp32_range(ops, x3):
+    g = torch.Generator().manual_seed(0)
+    n, H = 1024, 2
+    C = 16 * H
+    qkv = torch.randn(n, 3 * C, generator=g)
+    qkv[:, :2 * C] *= 6.0
+    order = torch.randperm(n, generator=g).numpy()
+    inverse = np.empty(n, dtype=np.int64)
+    inverse[order] = np.arange(n)
+    t_order = torch.from_numpy(order)
+    ref = OM._patch_attention(qkv[:, :C][t_order], qkv[:, C:2 * C][t_order], qkv[:, 2 * C:][t_order],
+                              np.array([0, n]), H, 0.25)[torch.from_numpy(inverse)]
+    offs = dev(np.array([0, n], dtype=np.int32))
+    gq, wq = ops.pad_plan(dev(order.astype(np.int32)), offs, offs, 1024, n)
+    d = dev(qkv)
+    out = torch.empty(n, C, dtype=torch.float32, device="cuda")
+    ops.attention(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], gq, gq, wq, offs, H, n, 0.25, out)
+    assert (out.cpu() - ref).abs().max().item() < 2e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(448, 512, 2048), (832, 1536, 512), (100, 256, 4096), (3392, 256, 256)])
 def test_gemm_split_k(ops, dtype, M, N, K):
@@ -1335,6 +1435,53 @@ def _deep_case(M, C, seed, with_t):
     d["cb"] = torch.randn(C, generator=g) if with_t else None
     d["x0"] = torch.randn(M, C, generator=g)
     return d, bf
+
+
+@LPS
+@pytest.mark.parametrize("M,C,tb", [(779, 512, True), (31, 512, False), (3364, 256, True), (2561, 512, True), (97, 256, False),
+                                    (1000, 128, True)])
+def test_deep_head_and_tail_split_over_workgroups_equal_the_in_place_forms(ops, lp, M, C, tb):
+    """Round 6 (csrc/deep.hip, cdseg_cpe_head_rr2 / cdseg_attn_tail_rr2): few-row launches cut a tile's weight stream over
+    three (head: q / k / v column blocks) or four (tail: MLP hidden chunks + a fixed-order reduce launch) workgroups, with the
+    residual rows read from one buffer and written to another.  Head: every output is the same chain of products in the
+    same order -> BIT-identical to the in-place launch.  Tail: the partial sums meet in a different order -> fp32 rounding
+    of the row only; deterministic (two runs are bit-identical).  C = 128 never splits (same entry points, unsplit path)."""
+    d, bf = _deep_case(M, C, M * 7 + C, tb)
+    D = lambda k, dt=None: None if d[k] is None else dev(d[k], dt)  # noqa: E731
+    himg, timg = ops.block_rr_pack(C, D("wl", bf), D("wq", bf), D("wp", bf), D("w1", bf), D("w2", bf))
+    # ---- head
+    xa, qa = D("x0"), torch.full((M, 3 * C), float("nan"), dtype=bf, device="cuda")
+    ops.cpe_head_rr(D("y", bf), himg, D("bl"), (D("g1"), D("e1")), xa, D("cb"), (D("g2"), D("e2")), D("bq"), qa,
+                    qkv_flags=ops.ATTN_V_BF16)
+    x_in, x_out = D("x0"), torch.full((M, C), float("nan"), dtype=torch.float32, device="cuda")
+    qb = torch.full((M, 3 * C), float("nan"), dtype=bf, device="cuda")
+    ops.cpe_head_rr2(D("y", bf), himg, D("bl"), (D("g1"), D("e1")), x_in, x_out, D("cb"), (D("g2"), D("e2")), D("bq"), qb,
+                     qkv_flags=ops.ATTN_V_BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(x_in, D("x0")), "the rows read must stay untouched"
+    assert torch.equal(x_out, xa) and torch.equal(qb.view(torch.int16), qa.view(torch.int16))
+    # ---- tail
+    xa, xca = D("x0"), torch.full((M, C), float("nan"), dtype=bf, device="cuda")
+    ops.attn_tail_rr(D("o", bf), timg, D("bp"), D("g3"), D("e3"), D("b1"), D("b2"), xa, xca)
+    ws = torch.empty(4 * M * C * 4 + 64, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        x_in, xb = D("x0"), torch.full((M, C), float("nan"), dtype=torch.float32, device="cuda")
+        xcb = torch.full((M, C), float("nan"), dtype=bf, device="cuda")
+        ops.attn_tail_rr2(D("o", bf), timg, D("bp"), D("g3"), D("e3"), D("b1"), D("b2"), x_in, xb, xcb, ws=ws)
+        torch.cuda.synchronize()
+        assert torch.equal(x_in, D("x0"))
+        outs.append((xb, xcb))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    xb, xcb = outs[0]
+    dd = (xb - xa).abs().max().item()
+    report(f"deep tail split vs in place M={M} C={C} {lp}", max_diff=dd, row_norm=float(xa.norm(dim=1).mean()))
+    assert dd < 4e-6 * C ** 0.5 * max(1.0, float(xa.abs().max()))
+    assert torch.equal(xcb, xb.to(bf))
+    # without a workspace the same entry point runs the unsplit tail: bit-identical to the in-place form
+    x_in, xc2 = D("x0"), torch.empty(M, C, dtype=torch.float32, device="cuda")
+    ops.attn_tail_rr2(D("o", bf), timg, D("bp"), D("g3"), D("e3"), D("b1"), D("b2"), x_in, xc2, None, ws=None)
+    assert torch.equal(xc2, xa)
 
 
 @LPS

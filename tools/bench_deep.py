@@ -12,7 +12,9 @@ variant = sys.argv[2] if len(sys.argv) > 2 else "f16"
 _lib.activate(variant)
 dev = torch.device("cuda")
 bf = torch.float16 if variant == "f16" else torch.bfloat16
-for n, C in ((14293 * scenes, 128), (3364 * scenes, 256), (778 * scenes, 128), (778 * scenes, 512), (778, 512)):
+shapes = ((14293 * scenes, 128), (3364 * scenes, 256), (778 * scenes, 128), (778 * scenes, 512), (778, 512), (3364, 256),
+          (14293, 128))
+for n, C in shapes:
     r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
     y, o = r(n, C).to(bf), r(n, C).to(bf)
     wl, wq, wp = (r(C, C) / C ** 0.5).to(bf), (r(3 * C, C) / C ** 0.5).to(bf), (r(C, C) / C ** 0.5).to(bf)
@@ -42,3 +44,8 @@ for n, C in ((14293 * scenes, 128), (3364 * scenes, 256), (778 * scenes, 128), (
     t_old = time_op(tail_old, 10)
     t_new = time_op(lambda: ops.attn_tail_rr(o, timg, bp, g1, e1, b1, b2, x, xc), 10)
     print(f"tail n={n} C={C}: separate launches {t_old:.1f} us, fused {t_new:.1f} us ({tf / t_new:.0f} TFLOP/s)")
+    if hasattr(ops, "cpe_head_rr2"):  # round 6: residual in / out in separate buffers -> few-row launches split a tile's stream
+        x2, ws = torch.empty_like(x), torch.empty(4 * n * C * 4 + 64, dtype=torch.uint8, device=dev)
+        t_h = time_op(lambda: ops.cpe_head_rr2(y, himg, bl, (g1, e1), x, x2, None, (g2, e2), bq, qkv), 10)
+        t_t = time_op(lambda: ops.attn_tail_rr2(o, timg, bp, g1, e1, b1, b2, x2, x, xc, ws=ws), 10)
+        print(f"rr2  n={n} C={C}: head {t_h:.1f} us, tail (+ reduce launch when split) {t_t:.1f} us")
