@@ -186,6 +186,9 @@ SIGNATURES = {
                                   c_void_p]),
     "cdseg_axpy": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
     "cdseg_count_saturated": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "cdseg_subm_conv3_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_float, c_int,
+                                     c_void_p]),
+    "cdseg_split16": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
 }
 
 _libs = {}

@@ -44,7 +44,11 @@ struct ConvP {
   int ldx, ldy;
   int row_shift;        // log2(ldx * 2): byte stride of a feature row (a power of two)
   int tiles;            // ceil(n / rows per block)
-                        // treated as dead, 2 = every neighbour replaced by the row itself (perfectly local gathers)
+  // fp32 output form (cdseg_subm_conv3_f32, the operand-pair convs of precision "fp32x3"): yf (n, ldyf) fp32,
+  // yf = (accumulate ? yf : 0) + (acc + bias) * out_scale; y is then unused
+  float* yf;
+  int ldyf, accumulate;
+  float out_scale;
 };
 
 // offsets in LDS-residency priority order (C = 64 keeps the first CONV64_LDS_OFFSETS = 20 in LDS): centre, 6 faces, 12 edges, 8 corners
@@ -345,6 +349,24 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void conv_ll_kernel(ConvP p, const
       });
     } while (o[0] < 27);
     // ---- epilogue: lane (j, cgrp) holds channels cgrp * C/4 + [0, C/4) of point j
+    if (p.yf) {  // fp32 output, optionally accumulating (wave-uniform)
+#pragma unroll
+      for (int g = 0; g < K::RG; ++g) {
+        const long myrow = row0 + g * 16 + jrow;
+        if (myrow >= p.n) continue;
+        float* dst = p.yf + myrow * p.ldyf + cgrp * (C / 4);
+#pragma unroll
+        for (int ct = 0; ct < K::CT; ++ct) {
+          float4 b = make_float4(0.f, 0.f, 0.f, 0.f), o = b;
+          if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + cgrp * (C / 4) + 4 * ct);
+          if (p.accumulate) o = *reinterpret_cast<const float4*>(dst + 4 * ct);
+          o.x += (acc[g][ct][0] + b.x) * p.out_scale; o.y += (acc[g][ct][1] + b.y) * p.out_scale;
+          o.z += (acc[g][ct][2] + b.z) * p.out_scale; o.w += (acc[g][ct][3] + b.w) * p.out_scale;
+          *reinterpret_cast<float4*>(dst + 4 * ct) = o;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int g = 0; g < K::RG; ++g) {
       const long myrow = row0 + g * 16 + jrow;
@@ -437,9 +459,31 @@ extern "C" int cdseg_subm_conv3(const void* x, int ldx, const void* wimg, const 
   ConvP p;
   p.x = (const bf16_t*)x; p.bias = bias; p.nbr = nbr_kmajor; p.y = (bf16_t*)y;
   p.n = n; p.ldx = ldx; p.ldy = ldy; p.tiles = 0;
+  p.yf = nullptr; p.ldyf = 0; p.accumulate = 0; p.out_scale = 1.f;
   p.row_shift = 0;
   while ((1 << p.row_shift) < ldx * 2) ++p.row_shift;
   if ((1 << p.row_shift) != ldx * 2) return CDSEG_ERR_UNSUPPORTED;  // feature rows with a power-of-two stride only
+  hipStream_t s = (hipStream_t)stream;
+  return channels == 32 ? launch_conv<32>(p, wimg, s) : launch_conv<64>(p, wimg, s);
+}
+
+// The same kernel with an fp32 output: yf = (accumulate ? yf : 0) + (sum_o W_o x[nbr] + bias) * out_scale.  Precision
+// "fp32x3" runs it three times per conv on IEEE-half operand pairs (x_hi W_hi; x_hi W_lo and x_lo W_hi with out_scale = 2^-11)
+extern "C" int cdseg_subm_conv3_f32(const void* x, int ldx, const void* wimg, const float* bias, const int32_t* nbr_kmajor,
+                                    long n, int channels, float* yf, int ldyf, float out_scale, int accumulate, void* stream) {
+  if (!x || !nbr_kmajor || !yf || !wimg) return CDSEG_ERR_ARG;
+  if (n <= 0) return CDSEG_OK;
+  if (channels != 32 && channels != 64) return CDSEG_ERR_UNSUPPORTED;
+  if (n * 27 * 4 >= (1l << 31) || n * (long)ldx * 2 >= (1l << 31) - 65536) return CDSEG_ERR_UNSUPPORTED;
+  if ((ldx & 7) || (ldyf & 3) || (((uintptr_t)x | (uintptr_t)yf | (uintptr_t)wimg) & 15)) return CDSEG_ERR_ARG;
+  if (bias && (((uintptr_t)bias) & 15)) return CDSEG_ERR_ARG;
+  ConvP p;
+  p.x = (const bf16_t*)x; p.bias = bias; p.nbr = nbr_kmajor; p.y = nullptr;
+  p.n = n; p.ldx = ldx; p.ldy = 0; p.tiles = 0;
+  p.yf = yf; p.ldyf = ldyf; p.accumulate = accumulate ? 1 : 0; p.out_scale = out_scale;
+  p.row_shift = 0;
+  while ((1 << p.row_shift) < ldx * 2) ++p.row_shift;
+  if ((1 << p.row_shift) != ldx * 2) return CDSEG_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   return channels == 32 ? launch_conv<32>(p, wimg, s) : launch_conv<64>(p, wimg, s);
 }

@@ -231,6 +231,27 @@ __global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict
 
 }  // namespace
 
+__global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, int ldx, long rows, int cols, bf16_t* hi,
+                                                      bf16_t* lo, int ld16, float lo_scale) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one group of 4 columns
+  const int per_row = cols >> 2;
+  if (u >= rows * per_row) return;
+  const long m = u / per_row;
+  const int c = (int)(u % per_row) * 4;
+  const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + c);
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  uint32_t h[2], l[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    h[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);  // (saturating in the half build)
+    float a, b;
+    unpack_bf16x2(h[e], a, b);
+    l[e] = pack_bf16x2((f[2 * e] - a) * lo_scale, (f[2 * e + 1] - b) * lo_scale);
+  }
+  *reinterpret_cast<uint2*>(hi + m * ld16 + c) = make_uint2(h[0], h[1]);
+  *reinterpret_cast<uint2*>(lo + m * ld16 + c) = make_uint2(l[0], l[1]);
+}
+
 // Diagnostic of the IEEE-half build: how many elements of a 16-bit activation buffer sit exactly at +-65504, the value every
 // float -> half conversion of that build clamps to (common.h).  A trained checkpoint whose activations leave half's range
 // shows up as a non-zero count instead of silently clamped logits.  (The bfloat16 build never clamps: counts nothing.)
@@ -360,6 +381,20 @@ int cdseg_count_saturated(const void* x, long rows, int cols, int ld, unsigned l
   const unsigned blocks = (unsigned)((total + 256 * 8 - 1) / (256 * 8));
   hipLaunchKernelGGL(count_saturated_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)x, rows, cols, ld, counter);
+  CDSEG_CHECK_LAUNCH();
+  return CDSEG_OK;
+}
+
+// fp32 matrix -> a pair of matrices in the build's 16-bit type: hi = rn(x) (saturating), lo = rn((x - hi) * lo_scale).  With
+// lo_scale = 2048 in the IEEE-half build x ~= hi + lo / 2048 to 22 significant bits - the operand form of the "fp32 x3"
+// sparse convs, which run the 16-bit gathered GEMM three times into one fp32 output (engine.py, precision fp32x3)
+int cdseg_split16(const float* x, int ldx, long rows, int cols, void* hi, void* lo, int ld16, float lo_scale, void* stream) {
+  if (rows <= 0 || cols <= 0) return CDSEG_OK;
+  if (!x || !hi || !lo || (cols & 3) || (ldx & 3) || (ld16 & 3) || ldx < cols || ld16 < cols) return CDSEG_ERR_ARG;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)hi | (uintptr_t)lo) & 7)) return CDSEG_ERR_ARG;
+  const long groups = rows * (long)(cols >> 2);
+  hipLaunchKernelGGL(split16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
+                     cols, (bf16_t*)hi, (bf16_t*)lo, ld16, lo_scale);
   CDSEG_CHECK_LAUNCH();
   return CDSEG_OK;
 }

@@ -1240,6 +1240,15 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   static const int deep_bm = cdseg_knob("CDSEG_CONV_DEEP_BM", 256);
   const bool deep = tall && sizeof(CT) == 2 && deep_bm == 256 && p.N >= 256 && p.M >= 512;
   int bm = deep ? 256 : (tall ? 128 : 64);
+  // fp32 x3, plain products over many rows on 128-row tiles (the tile's W slice split into half pairs once per 128 rows instead
+  // of once per 64): measured SLOWER - 45.1 -> 50.9 ms per 8-scene forward, the K > 64 products 74 -> 244 us per launch on two
+  // 65 KB blocks per CU (profiles/r06_fp32x3.txt) - and off (0); experimental builds can switch it on
+  bool tall_x3 = false;
+  if constexpr (kIsX3<CT> && !GATHER) {
+    static const long x3_tall_m = cdseg_knob("CDSEG_X3_TALL_MIN_M", 0);
+    tall_x3 = x3_tall_m > 0 && !ln && p.M >= x3_tall_m;
+    if (tall_x3) bm = 128;
+  }
   // LDS-DMA main loop (bf16, K % 64 == 0, N > 64): 128-row tiles for plain linears too (CDSEG_GEMM_DMA_BM overrides)
   int dma_use_bm = -1;
   if constexpr (NCH == 16 && sizeof(CT) == 2) {
@@ -1443,6 +1452,30 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
           attr_done = true;
         }
         hipLaunchKernelGGL((gemm_kernel<CT, 128, 16, GATHER, 128>), grid, dim3(512), smem, s, p);
+      }
+    }
+  }
+  if constexpr (kIsX3<CT> && !GATHER) {
+    if (tall_x3 && !launched) {
+      launched = true;
+      if (bn == 32) {
+        hipLaunchKernelGGL((gemm_kernel<CT, 32, NCH, false, 128>), grid, dim3(512), 0, s, p);
+      } else if (bn == 64) {
+        hipLaunchKernelGGL((gemm_kernel<CT, 64, NCH, false, 128>), grid, dim3(512), 0, s, p);
+      } else {
+        constexpr int smem = gemm_smem_bytes<CT, 128, NCH, 128>();
+        if constexpr (smem > 65536) {
+          static std::atomic<bool> attr_x3{false};  // (a concurrent first call sets the attribute twice: harmless)
+          if (!attr_x3) {
+            if (hipFuncSetAttribute((const void*)gemm_kernel<CT, 128, NCH, false, 128>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+              return CDSEG_ERR_LAUNCH;
+            attr_x3 = true;
+          }
+          hipLaunchKernelGGL((gemm_kernel<CT, 128, NCH, false, 128>), grid, dim3(512), smem, s, p);
+        } else {
+          hipLaunchKernelGGL((gemm_kernel<CT, 128, NCH, false, 128>), grid, dim3(512), 0, s, p);
+        }
       }
     }
   }

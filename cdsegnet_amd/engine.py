@@ -194,7 +194,8 @@ class Engine:
             # this shape (ptv3.py:1785-1794); every shipped config has it - reject anything else here, not mid-forward
             raise ValueError(f"conditional PT-v3m1 needs 3 c-branch and 5 n-branch stages (ptv3.py:1785-1794), got "
                              f"{bb.c_num_stages} / {bb.n_num_stages}")
-        self.variant = variant or ("f16" if precision.startswith("fp16") else "bf16")
+        # ("fp32x3" lives in the IEEE-half build: its sparse convs hand half pairs to that build's 16-bit gathered GEMM)
+        self.variant = variant or ("f16" if precision.startswith("fp16") or precision == "fp32x3" else "bf16")
         # "fp32x3": the fp32 engine (fp32 tensors, the reference's order of operations) with every matrix product computed as
         # three IEEE-half MFMAs on split operands (csrc/gemm.hip, attention.hip): inside north_star's 1e-3 at a multiple of the
         # exact-fp32 MFMA rate
@@ -278,6 +279,18 @@ class Engine:
         def conv(mod, pre):
             w[pre + ".w"] = mod.weight.detach().reshape(mod.weight.shape[0], -1).to(device=device, dtype=T).contiguous()
             w[pre + ".b"] = f32(mod.bias) if mod.bias is not None else None
+            if self.x3 and mod.kernel_size == 3 and hasattr(ops, "split16"):
+                # fp32x3: the k = 3 convs run the FAST 16-bit gathered GEMM three times into one fp32 output
+                # (x_hi W_hi + (x_hi W_lo + x_lo W_hi) / 2048, _conv3): the weight's half pair, made once
+                w[pre + ".w_hi"], w[pre + ".w_lo"] = ops.split16(w[pre + ".w"])
+                cout = w[pre + ".w"].shape[0]
+                if mod.in_channels == cout and cout in (32, 64) and hasattr(ops, "subm_conv3_f32"):
+                    # wide stages: the weight-stationary kernel (csrc/conv.hip) with its fp32 accumulate output
+                    w[pre + ".wimg_hi"] = ops.subm_conv3_pack(w[pre + ".w_hi"])
+                    w[pre + ".wimg_lo"] = ops.subm_conv3_pack(w[pre + ".w_lo"])
+                if ("x3.scale", cout) not in w:
+                    w[("x3.scale", cout)] = torch.full((cout,), 1.0 / 2048.0, dtype=torch.float32, device=device)
+                    w[("x3.zero", cout)] = torch.zeros(cout, dtype=torch.float32, device=device)
             # wide bf16 stages (C = 32 / 64, k = 3): fragment-order image for the weight-stationary conv kernel
             k, cin, cout = mod.kernel_size, mod.in_channels, mod.out_channels
             if (k == 3 and cin == cout and hasattr(ops, "subm_conv3_pack") and
@@ -427,7 +440,8 @@ class Engine:
                     mod.channels, w[pre + ".cpe1.w"], w[pre + ".qkv.w"], w[pre + ".proj.w"], w[pre + ".fc1.w"], w[pre + ".fc2.w"])
                 if ops.block_rr_head_on(mod.channels):  # C = 32 / 64: slower than the 64-row-tile fused head; deep: on
                     w[pre + ".head_img"] = himg
-        self.native_blocks = hasattr(ops, "block_forward") and self.use_native_blocks
+        # (fp32x3 issues its Blocks from the binding path: its convs are three launches on operands the descriptor does not carry)
+        self.native_blocks = hasattr(ops, "block_forward") and self.use_native_blocks and not self.x3
         if self.native_blocks:
             for mod, pre in self._blocks_to_describe:
                 t = dict(cpe_conv_w=w[pre + ".cpe0.w"], cpe_conv_b=w[pre + ".cpe0.b"], cpe_lin_w=w[pre + ".cpe1.w"],
@@ -648,6 +662,22 @@ class Engine:
         gathered-A GEMM elsewhere."""
         w = self.w
         self._count_conv(lv.n, xc.shape[1], xc.element_size())
+        if (pre + ".w_hi") in w and y.dtype == torch.float32:
+            # fp32x3: x = x_hi + x_lo / 2048, W = W_hi + W_lo / 2048 (IEEE-half pairs, 22 significant bits); the dropped
+            # x_lo W_lo term is <= 2^-22 of the product.  Launches 2 and 3 scale their sum by 2^-11 and add the running output
+            cout = w[pre + ".w"].shape[0]
+            sc, ze = w[("x3.scale", cout)], w[("x3.zero", cout)]
+            xh, xl = ops.split16(xc)
+            nbr = lv.nbr(3, True)
+            if (pre + ".wimg_hi") in w and ops.subm_conv3_ok(xh) and y.stride(0) == y.shape[1]:
+                ops.subm_conv3_f32(xh, w[pre + ".wimg_hi"], w[pre + ".b"], nbr, y)
+                ops.subm_conv3_f32(xh, w[pre + ".wimg_lo"], None, nbr, y, out_scale=1.0 / 2048.0, accumulate=True)
+                ops.subm_conv3_f32(xl, w[pre + ".wimg_hi"], None, nbr, y, out_scale=1.0 / 2048.0, accumulate=True)
+                return
+            ops.gemm(xh, w[pre + ".w_hi"], y, bias=w[pre + ".b"], nbr=nbr, nbr_kmajor=True, kvol=27)
+            ops.gemm(xh, w[pre + ".w_lo"], y, scale=sc, shift=ze, res=y, nbr=nbr, nbr_kmajor=True, kvol=27)
+            ops.gemm(xl, w[pre + ".w_hi"], y, scale=sc, shift=ze, res=y, nbr=nbr, nbr_kmajor=True, kvol=27)
+            return
         if (pre + ".wimg") in w and ops.subm_conv3_ok(xc):
             ops.subm_conv3(xc, w[pre + ".wimg"], w[pre + ".b"], lv.nbr(3, True), y)
         else:

@@ -696,6 +696,17 @@ def count_saturated(x, counter):
           "count_saturated")
 
 
+def split16(x, lo_scale=2048.0):
+    """fp32 (rows, cols) -> (hi, lo) in the active build's 16-bit type: hi = T(x), lo = T((x - hi) * lo_scale)."""
+    _need_gpu(x)
+    T = LP_DTYPES[_lib.active()]
+    hi = torch.empty(x.shape, dtype=T, device=x.device)
+    lo = torch.empty(x.shape, dtype=T, device=x.device)
+    check(_lib.load().cdseg_split16(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(hi), _ptr(lo), hi.stride(0),
+                                    float(lo_scale), _stream()), "split16")
+    return hi, lo
+
+
 def block_forward(desc, n, x, xc_in, xc_out, tbias, nbr, gidx, widx, patch_start, num_patches, max_len, scratch,
                   sat_counter=None):
     """One PTv3 Block on the native executor (all launches issued by the library, one host call).  sat_counter: 1-element
@@ -766,6 +777,16 @@ def subm_conv3(x, wimg, bias, nbr_kmajor, out):
     n, c = x.shape
     check(_lib.load().cdseg_subm_conv3(_ptr(x), x.stride(0), _ptr(wimg), _ptr(bias), _ptr(nbr_kmajor), n, c, _ptr(out),
                                        out.stride(0), _stream()), "subm_conv3")
+    return out
+
+
+def subm_conv3_f32(x, wimg, bias, nbr_kmajor, out, out_scale=1.0, accumulate=False):
+    """The weight-stationary conv with an fp32 output: out = (accumulate ? out : 0) + (conv + bias) * out_scale."""
+    _need_gpu(x, wimg, nbr_kmajor, out)
+    n, c = x.shape
+    check(_lib.load().cdseg_subm_conv3_f32(_ptr(x), x.stride(0), _ptr(wimg), _ptr(bias), _ptr(nbr_kmajor), n, c, _ptr(out),
+                                           out.stride(0), float(out_scale), 1 if accumulate else 0, _stream()),
+          "subm_conv3_f32")
     return out
 
 

@@ -292,6 +292,14 @@ int cdseg_ddim_update(const float* xt, const float* eps, float sqrt_ab_prev, flo
  * build never clamps and adds nothing.  cdseg_block_forward runs it over a Block's conv output, q / k, attention output and
  * shadow copy when cdseg_block_io.sat_counter is set. */
 int cdseg_count_saturated(const void* x, long rows, int cols, int ld, unsigned long long* counter, void* stream);
+/* x (rows, cols) fp32 -> hi = T(x) (saturating), lo = T((x - hi) * lo_scale) in the build's 16-bit type T (cols, ldx, ld16
+ * multiples of 4).  The IEEE-half build with lo_scale = 2048 gives x ~= hi + lo / 2048 to 22 significant bits: the operand
+ * pairs of precision "fp32x3"'s sparse convs (three 16-bit gathered GEMMs into one fp32 output). */
+/* cdseg_subm_conv3 with an fp32 output: yf = (accumulate ? yf : 0) + (conv + bias) * out_scale (C = 32 / 64, 16-bit x and
+ * weight image as above).  Three calls on IEEE-half operand pairs give a k = 3 conv to 22 significant bits ("fp32x3"). */
+int cdseg_subm_conv3_f32(const void* x, int ldx, const void* wimg, const float* bias, const int32_t* nbr_kmajor, long n,
+                         int channels, float* yf, int ldyf, float out_scale, int accumulate, void* stream);
+int cdseg_split16(const float* x, int ldx, long rows, int cols, void* hi, void* lo, int ld16, float lo_scale, void* stream);
 /* out = a + alpha * b (fp32).  ref: default.py:228-236 (add_gaussian_noise) */
 int cdseg_axpy(const float* a, const float* b, float alpha, float* out, long n, void* stream);
 

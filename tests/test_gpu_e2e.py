@@ -130,16 +130,15 @@ def test_fp32x3_mode_matches_reference_golden(name):
     assert err < 1e-4 and agree == 1.0
 
 
-def test_fp32x3_mode_full_width_vs_reference_golden_and_both_executors():
+def test_fp32x3_mode_full_width_vs_reference_golden():
+    """... and at full width (101.4 M parameters, 8 k points): the sparse convs of this mode are three launches of the 16-bit
+    gathered GEMM on half pairs (engine._conv3), everything else the split-half GEMM / attention kernels."""
     fx = load_fixture("full_e2e_8k.npz")
     model = build(fixture_cfg(fx), fixture_state_dict(fx), "fp32x3")
     a = run(model, fixture_input(fx), fixture_draws(fx))
     err, agree = report("full width 8k fp32x3 vs reference", a, fx["logits"])
     assert err < 2e-4 and agree == 1.0
-    model._drop_engine()
-    model.engine().use_native_blocks = False
-    b = run(model, fixture_input(fx), fixture_draws(fx))
-    assert np.array_equal(a, b)
+    assert np.array_equal(a, run(model, fixture_input(fx), fixture_draws(fx))), "non-deterministic"
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
