@@ -690,7 +690,14 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_f32_kernel(AttnP p) {
 constexpr int X3_KH = 0, X3_KL = KV_STAGE, X3_V1 = 2 * KV_STAGE, X3_V2 = 3 * KV_STAGE;
 constexpr int X3_ONES = 4 * KV_STAGE, X3_ZERO = X3_ONES + ONES_BYTES;
 constexpr int SMEM_X3 = X3_ZERO + ONES_BYTES;
-constexpr int X3_THREADS = 512;
+#ifndef ATTN_X3_WAVES
+#define ATTN_X3_WAVES 8
+#endif
+#ifndef ATTN_X3_TILES
+#define ATTN_X3_TILES 2
+#endif
+constexpr int X3_WAVES = ATTN_X3_WAVES, X3_THREADS = 64 * X3_WAVES, X3_TILES = ATTN_X3_TILES;  // 8 x 2 | 16 x 1 (128 VGPRs)
+static_assert(X3_WAVES % ATTN_RUN == 0, "whole runs of query tiles per block");
 typedef _Float16 x3h2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 x3h8_t __attribute__((ext_vector_type(8)));
 
@@ -810,7 +817,10 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_kernel(AttnP p) {
   const int nfull = tail ? nkt - 1 : nkt;
   const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  for (int qt = qslice * ATTN_RUN + wave; qt < nkt; qt += qsplit * ATTN_RUN) {
+  // a slice takes every qsplit-th run of 8 query tiles (decode_block); a block of 16 waves works on two of its runs at a time
+  for (int run = qslice + (wave / ATTN_RUN) * qsplit; run * ATTN_RUN + (wave % ATTN_RUN) < nkt;
+       run += (X3_WAVES / ATTN_RUN) * qsplit) {
+    const int qt = run * ATTN_RUN + (wave % ATTN_RUN);
     const int qslot = qt * 32 + ql;
     const bool qvalid = qslot < L;
     const long g = p.q_gidx[ps + min(qslot, L - 1)];
@@ -832,7 +842,7 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_kernel(AttnP p) {
       const char* kp = k_lane;
       unsigned va1 = va1_0, va2 = va2_0;
       int kt;
-      if (nfull >= 2) {
+      if (X3_TILES == 2 && nfull >= 2) {
         const f32x16_t sa = x3_qk_tile(kp, qh.v, qlo.v, c0);
         const f32x16_t sb = x3_qk_tile(kp + 1024, qh.v, qlo.v, c0);
         x3_pv_tile<false, true>(sa, 0, h, L, va1, va2, acc);
@@ -846,7 +856,7 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_kernel(AttnP p) {
         kp += 1024; va1 += vstep; va2 += vstep;
         kt = 1;
       }
-      for (; kt + 1 < nfull; kt += 2) {
+      for (; X3_TILES == 2 && kt + 1 < nfull; kt += 2) {
         const f32x16_t sa = x3_qk_tile(kp, qh.v, qlo.v, c0);
         const f32x16_t sb = x3_qk_tile(kp + 1024, qh.v, qlo.v, c0);
         x3_pv_tile<false>(sa, kt, h, L, va1, va2, acc);

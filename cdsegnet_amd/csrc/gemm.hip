@@ -1362,7 +1362,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
       if (!launched && sq && dma_on) {
         launched = true;
         using Q = DmaCfg<256, true, 256, 2, true>;
-        static bool aq = false;
+        static std::atomic<bool> aq{false};  // (a concurrent first call sets the attribute twice: harmless)
         if (!aq) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<256, true, 256, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Q::LDS) != hipSuccess)
@@ -1374,7 +1374,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
       if (!launched && wide && dma_on && p.kshift >= 6) {
         launched = true;
         using W = DmaCfg<128, true, 256, 3>;
-        static bool aw = false;
+        static std::atomic<bool> aw{false};  // (a concurrent first call sets the attribute twice: harmless)
         if (!aw) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<128, true, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   W::LDS) != hipSuccess)
@@ -1389,7 +1389,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
       launched = true;
       (void)dma_bm;
       if (bm == 256) {
-        static bool a256 = false;
+        static std::atomic<bool> a256{false};  // (a concurrent first call sets the attribute twice: harmless)
         if (!a256) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<256, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   DmaCfg<256, GATHER>::LDS) != hipSuccess)
@@ -1399,7 +1399,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
         constexpr int lds256 = DmaCfg<256, GATHER>::LDS;
         hipLaunchKernelGGL((gemm_dma_kernel<256, GATHER>), grid, dim3(1024), lds256, s, p);
       } else if (bm == 128) {
-        static bool a128 = false;
+        static std::atomic<bool> a128{false};  // (a concurrent first call sets the attribute twice: harmless)
         if (!a128) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<128, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   DmaCfg<128, GATHER>::LDS) != hipSuccess)
@@ -1409,7 +1409,7 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
         constexpr int lds128 = DmaCfg<128, GATHER>::LDS;
         hipLaunchKernelGGL((gemm_dma_kernel<128, GATHER>), grid, dim3(512), lds128, s, p);
       } else {
-        static bool a64 = false;
+        static std::atomic<bool> a64{false};  // (a concurrent first call sets the attribute twice: harmless)
         if (!a64) {
           if (hipFuncSetAttribute((const void*)gemm_dma_kernel<64, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   DmaCfg<64, GATHER>::LDS) != hipSuccess)

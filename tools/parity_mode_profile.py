@@ -3,6 +3,9 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.getcwd())
+from cdsegnet_amd import _lib
+if os.environ.get("CDSEG_AB_LIB_F16"):  # A/B runs against another IEEE-half build of the library (tools only)
+    _lib.LIB_PATH_F16 = os.path.abspath(os.environ["CDSEG_AB_LIB_F16"])
 from cdsegnet_amd import configs, synth
 from cdsegnet_amd.models import collate_device
 from cdsegnet_amd.param_init import fill_state_dict
