@@ -70,6 +70,32 @@ class BlockIO(Structure):
     ]
 
 
+class PlanSpec(Structure):
+    _fields_ = [
+        ("nlev", c_int), ("cum", c_int * 9), ("ncurve", c_int), ("curve_rows", c_int * 3),
+        ("nslot_curve", c_int), ("slot_curve", c_int * 4),
+        ("nlink", c_int), ("link_a", c_int * 16), ("link_b", c_int * 16),
+        ("npad", c_int), ("pad_patch", c_int * 4), ("pad_flash", c_int * 4),
+    ]
+
+
+class PlanBeginIO(Structure):
+    _fields_ = [
+        ("grid", c_void_p), ("grid_elem_bytes", c_int), ("offset", c_void_p), ("nb", c_int), ("n", c_long),
+        ("depth", c_int), ("end_bit", c_int), ("i32", c_void_p), ("i64", c_void_p), ("ws", c_void_p),
+        ("ws_bytes", c_size_t), ("gmax_host", c_void_p), ("meta_host", c_void_p),
+    ]
+
+
+class PlanFinishIO(Structure):
+    _fields_ = [
+        ("n", c_long), ("nb", c_int), ("depth", c_int), ("m_host", POINTER(c_long)), ("offs_host", POINTER(c_int)),
+        ("grid0", c_void_p), ("bat0", c_void_p), ("code0", c_void_p), ("cluster", c_void_p), ("seg", c_void_p),
+        ("orders0", c_void_p), ("i32", c_void_p), ("i64", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t),
+        ("pads_host", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/cdseg.h declares
 SIGNATURES = {
     "cdseg_abi_version": (c_int, []),
@@ -106,6 +132,11 @@ SIGNATURES = {
     "cdseg_pad_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "cdseg_pad_plan_batch": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
                                      POINTER(c_long), c_int, c_void_p, c_void_p, c_void_p]),
+    "cdseg_plan_begin_layout": (c_int, [POINTER(PlanSpec), c_long, c_int, POINTER(c_long), POINTER(c_long)]),
+    "cdseg_plan_begin": (c_int, [POINTER(PlanSpec), POINTER(PlanBeginIO), c_int, c_void_p]),
+    "cdseg_plan_finish_layout": (c_int, [POINTER(PlanSpec), c_long, c_int, POINTER(c_long), POINTER(c_int), POINTER(c_long),
+                                         POINTER(c_long)]),
+    "cdseg_plan_finish": (c_int, [POINTER(PlanSpec), POINTER(PlanFinishIO), c_void_p]),
     "cdseg_voxelize": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cdseg_voxelize_f64": (c_int, [c_void_p, ctypes.c_double, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cdseg_center_shift": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p]),

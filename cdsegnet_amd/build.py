@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcdseg_hip.so")
 LIB_F16 = os.path.join(HERE, "libcdseg_hip_f16.so")
 VARIANTS = [(LIB, "_build", []), (LIB_F16, "_build_f16", ["-DCDSEG_LP_F16"])]
-SOURCES = ["serialize.hip", "gemm.hip", "elementwise.hip", "attention.hip", "conv.hip", "stem.hip", "mlp.hip", "blockrr.hip", "deep.hip", "pool.hip", "runtime.hip", "testtime.hip", "train.hip", "prof.hip", "abi.hip"]
+SOURCES = ["serialize.hip", "plan.hip", "gemm.hip", "elementwise.hip", "attention.hip", "conv.hip", "stem.hip", "mlp.hip", "blockrr.hip", "deep.hip", "pool.hip", "runtime.hip", "testtime.hip", "train.hip", "prof.hip", "abi.hip"]
 HEADERS = ["common.h", "curves.h", "prof.h", "deep.h", os.path.join("..", "..", "include", "cdseg.h")]
 ARCH = "gfx950"
 

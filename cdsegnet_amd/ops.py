@@ -371,11 +371,8 @@ def coarse_orders(clusters, orders, sizes):
     cp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in clusters])
     op = (ctypes.c_void_p * nc)(*[t.data_ptr() for t in orders])
     check(lib.cdseg_coarse_orders(cp, nl, op, nc, n0, _ptr(out), _ptr(ws), ws.numel(), _stream()), "coarse_orders")
-    res, pos = [], 0
-    for m in sizes:
-        res.append([out[pos + c * m: pos + (c + 1) * m] for c in range(nc)])
-        pos += nc * m
-    return res
+    parts = out.split([int(m) for m in sizes for _ in range(nc)])
+    return [list(parts[i * nc:(i + 1) * nc]) for i in range(nl)]
 
 
 def pool_gather(seg_start, m, n_fine, pooling_depth, grid_f, batch_f, code4_f):
@@ -431,6 +428,74 @@ def pad_plan(order, offs, offs_pad, patch, n_pad):
     return gidx, widx
 
 
+# ------------------------------------------------------------------ native plan builder (csrc/plan.hip)
+class NativePlanCall:
+    """One forward's plan through cdseg_plan_begin / cdseg_plan_finish: owns the two arenas of each call and hands out views.
+    `spec` is a filled _lib.PlanSpec (static per model and serialization depth)."""
+
+    def __init__(self, spec, grid, offset_dev, n, nb, depth, end_bit, gmax_pin, meta_pin):
+        lib = _lib.load()
+        self.lib, self.spec, self.n, self.nb, self.depth = lib, spec, int(n), int(nb), int(depth)
+        self.sp = ctypes.byref(spec)
+        off = (ctypes.c_long * 13)()
+        tot = (ctypes.c_long * 3)()
+        check(lib.cdseg_plan_begin_layout(self.sp, self.n, self.nb, off, tot), "plan_begin_layout")
+        dev = grid.device
+        self.b32 = torch.empty(tot[0], dtype=torch.int32, device=dev)
+        self.b64 = torch.empty(tot[1], dtype=torch.int64, device=dev)
+        self.ws = workspace(tot[2], dev)
+        self.boff = list(off)
+        io = self.bio = _lib.PlanBeginIO()
+        io.grid, io.grid_elem_bytes, io.offset = grid.data_ptr(), grid.element_size(), offset_dev.data_ptr()
+        io.nb, io.n, io.depth, io.end_bit = self.nb, self.n, self.depth, int(end_bit)
+        io.i32, io.i64, io.ws, io.ws_bytes = self.b32.data_ptr(), self.b64.data_ptr(), self.ws.data_ptr(), self.ws.numel()
+        io.gmax_host = None if gmax_pin is None else gmax_pin.data_ptr()
+        io.meta_host = meta_pin.data_ptr()
+        self._keep = (grid, offset_dev)
+
+    def begin(self, phase):
+        check(self.lib.cdseg_plan_begin(self.sp, ctypes.byref(self.bio), int(phase), _stream()), "plan_begin")
+
+    def begin_views(self):
+        """perm0 (n), grid0 (n, 3), bat0 (n), code0 (4, n), cluster (nlev, n), seg_start (nlev, n + 1), orders0 (ncurve, n)."""
+        o, n, b32, b64, L, nc = self.boff, self.n, self.b32, self.b64, self.spec.nlev, self.spec.ncurve
+        return (b32[o[1]:o[1] + n], b32[o[2]:o[2] + 3 * n].view(n, 3), b32[o[3]:o[3] + n],
+                b64[o[12]:o[12] + 4 * n].view(4, n), b32[o[5]:o[5] + L * n].view(L, n),
+                b32[o[6]:o[6] + L * (n + 1)].view(L, n + 1), b32[o[8]:o[8] + nc * n].view(nc, n) if nc else None)
+
+    def finish(self, m, offs_rows, pads_pin):
+        """m: pooled sizes; offs_rows: (nlev + 1) lists of nb + 1 batch offsets; pads_pin(count) -> pinned int32 tensor with
+        at least `count` elements (called once).  Returns (off, info): the layout lists of include/cdseg.h."""
+        lib, spec, L, npad = self.lib, self.spec, self.spec.nlev, self.spec.npad
+        mh = (ctypes.c_long * L)(*m)
+        flat = [v for r in offs_rows for v in r]
+        oh = (ctypes.c_int * len(flat))(*flat)
+        n_off = 3 * L + 2 * spec.nlink + 2 * (L + 1) + 1 + 3 * (L + 1) * npad + 2
+        n_info = 5 + 5 * (L + 1) * npad
+        off = (ctypes.c_long * n_off)()
+        info = (ctypes.c_long * n_info)()
+        check(lib.cdseg_plan_finish_layout(self.sp, self.n, self.nb, mh, oh, off, info), "plan_finish_layout")
+        dev = self.b32.device
+        self.f32 = torch.empty(info[0], dtype=torch.int32, device=dev)
+        self.f64 = torch.empty(max(1, info[1]), dtype=torch.int64, device=dev)
+        if info[2] > self.ws.numel():
+            self.ws = workspace(info[2], dev)
+        pin = pads_pin(info[3])
+        o, n, b32, b64 = self.boff, self.n, self.b32, self.b64
+        io = _lib.PlanFinishIO()
+        io.n, io.nb, io.depth, io.m_host, io.offs_host = self.n, self.nb, self.depth, mh, oh
+        io.grid0 = b32.data_ptr() + 4 * o[2]
+        io.bat0 = b32.data_ptr() + 4 * o[3]
+        io.code0 = b64.data_ptr() + 8 * o[12]
+        io.cluster = b32.data_ptr() + 4 * o[5]
+        io.seg = b32.data_ptr() + 4 * o[6]
+        io.orders0 = b32.data_ptr() + 4 * o[8]
+        io.i32, io.i64, io.ws, io.ws_bytes = self.f32.data_ptr(), self.f64.data_ptr(), self.ws.data_ptr(), self.ws.numel()
+        io.pads_host = pin.data_ptr()
+        check(lib.cdseg_plan_finish(self.sp, ctypes.byref(io), _stream()), "plan_finish")
+        return list(off), list(info)
+
+
 # ------------------------------------------------------------------ float ops
 PAD_BATCH_MAX = 48
 
@@ -453,10 +518,8 @@ def pad_plan_batch(items, nb):
         npad = (ctypes.c_long * k)(*[int(it[4]) for it in chunk])
         check(lib.cdseg_pad_plan_batch(k, orders, offs, offs_pad, patch, npad, int(nb), _ptr(gidx), _ptr(widx), _stream()),
               "pad_plan_batch")
-        pos = 0
-        for it in chunk:
-            res.append((gidx[pos:pos + int(it[4])], widx[pos:pos + int(it[4])]))
-            pos += int(it[4])
+        sizes = [int(it[4]) for it in chunk]
+        res.extend(zip(gidx.split(sizes), widx.split(sizes)))  # (one call per buffer: 2 k Python slices cost ~1.5 us each)
     return res
 
 

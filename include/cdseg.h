@@ -500,6 +500,88 @@ typedef struct cdseg_block_io {
 size_t cdseg_block_scratch_bytes(const cdseg_block_desc* desc, long n);
 int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, void* stream);
 
+/* ------------------------------------------------------------------ native plan builder (round 6)
+ * ref: models/utils/structure.py:47-102 (Point.serialization), ptv3.py:188-250 (padding plan), :477-505 (pooling structure).
+ * The integer side of one forward - (batch | z) sort, level-0 codes, all pooled levels, links, 3x3x3 kernel maps, curve orders,
+ * padding tables, slot plans - in TWO library calls around the forward's one host read (the pooled sizes), written into two
+ * caller-owned arenas (int32 / int64 elements; every item starts on a 256-byte boundary).  Same kernels, same results as the
+ * per-op entry points above (tests/test_gpu_ops.py::test_native_plan_equals_per_op_plan); exists because a single scene's
+ * plan phase was bound by ~40 binding round trips, not by the device (csrc/plan.hip).
+ * Level indices: 0 = the input resolution, 1 .. nlev the pooled levels in ascending cumulative pooling depth. */
+#define CDSEG_PLAN_MAX_LEVELS 8
+#define CDSEG_PLAN_MAX_LINKS 16
+#define CDSEG_PLAN_MAX_PADS 4
+typedef struct cdseg_plan_spec {
+  int nlev;            /* pooled levels (1 .. 8) */
+  int cum[9];          /* cumulative pooling depth per level index, cum[0] = 0, strictly ascending */
+  int ncurve;          /* curves other than z in use (0 .. 3) */
+  int curve_rows[3];   /* their rows of the (4, n) code array: 1 = z-trans, 2 = hilbert, 3 = hilbert-trans */
+  int nslot_curve;     /* curves that get slot plans (1 .. 4) */
+  int slot_curve[4];   /* -1 = z (identity order), else an index into curve_rows */
+  int nlink;           /* links a -> b between POOLED levels (1 <= a < b); the (0, l) links come out of the pooling pass.
+                          Must contain (l, l + 1) for every pooled level l whose parent is one octree step up */
+  int link_a[CDSEG_PLAN_MAX_LINKS];
+  int link_b[CDSEG_PLAN_MAX_LINKS];
+  int npad;            /* padding keys (1 .. 4) */
+  int pad_patch[CDSEG_PLAN_MAX_PADS]; /* patch size */
+  int pad_flash[CDSEG_PLAN_MAX_PADS]; /* enable_flash: K = patch size; else K = min(smallest batch element, patch size) */
+} cdseg_plan_spec;
+
+typedef struct cdseg_plan_begin_io {
+  const void* grid;        /* (n, 3) int32 | int64 voxel coordinates, caller's point order */
+  int grid_elem_bytes;
+  const int64_t* offset;   /* (nb) cumulative batch offsets */
+  int nb;
+  long n;
+  int depth;               /* serialization depth (structure.py:66) */
+  int end_bit;             /* significant bits of the (batch | z) code */
+  int32_t* i32;            /* arenas: cdseg_plan_begin_layout */
+  int64_t* i64;
+  void* ws;
+  size_t ws_bytes;
+  int64_t* gmax_host;      /* PINNED host word <- max(grid), or NULL */
+  int32_t* meta_host;      /* PINNED host ints <- cdseg_pool_levels' meta (nlev * (1 + nb) + 1), or NULL */
+} cdseg_plan_begin_io;
+
+/* off_out[13]: offsets (elements) of batch, perm0, grid0, bat0, last_idx, cluster (nlev, n), seg_start (nlev, n + 1), meta,
+ * orders0 (ncurve, n) in the int32 arena, then gmax, zcode, zcode_sorted, code0 (4, n) in the int64 arena.
+ * totals_out[3]: int32 elements, int64 elements, workspace bytes. */
+int cdseg_plan_begin_layout(const cdseg_plan_spec* spec, long n, int nb, long* off_out, long* totals_out);
+/* phase 0: everything up to the two asynchronous host copies; phase 1: the level-0 orders of the non-z curves (one sort) -
+ * independent of the host read, so the caller records its event between the phases and waits for it after phase 1 is queued */
+int cdseg_plan_begin(const cdseg_plan_spec* spec, const cdseg_plan_begin_io* io, int phase, void* stream);
+
+typedef struct cdseg_plan_finish_io {
+  long n;
+  int nb;
+  int depth;
+  const long* m_host;      /* (nlev) pooled sizes, from meta */
+  const int* offs_host;    /* (nlev + 1, nb + 1) batch offsets of every level index, level 0 first */
+  const int32_t* grid0;    /* items of the begin arena */
+  const int32_t* bat0;
+  const int64_t* code0;
+  const int32_t* cluster;
+  const int32_t* seg;
+  const int32_t* orders0;
+  int32_t* i32;            /* arenas: cdseg_plan_finish_layout */
+  int64_t* i64;
+  void* ws;
+  size_t ws_bytes;
+  int32_t* pads_host;      /* PINNED staging buffer for the padding tables (>= info_out[3] ints), free again once the call's
+                              copy has run */
+} cdseg_plan_finish_io;
+
+/* off_out (element offsets), in this order: per pooled level l = 1 .. nlev: grid (int32 arena), batch (int32), code4 (int64);
+ * per link: cluster, seg_start (int32); per level 0 .. nlev: nbr3 (27, m_l) offset-major (int32); per level 0 .. nlev:
+ * child_info (int64) or -1; the coarse-order base (int32: level l / curve c at base + ncurve * sum_{1 <= l' < l} m_l' + c * m_l);
+ * per (level 0 .. nlev, pad key): offs, offs_pad, patch_start (int32); slot gidx base, slot widx base (int32: the plan of
+ * (level, pad key, slot curve), in that nesting, starts at the sum of the n_pad of the plans before it).
+ * info_out: int32 elements, int64 elements, workspace bytes, padding-table ints, padding-table base; then per (level, pad key):
+ * K, n_pad, patches, longest patch, sum of squared patch lengths (a double's bits). */
+int cdseg_plan_finish_layout(const cdseg_plan_spec* spec, long n, int nb, const long* m_host, const int* offs_host,
+                             long* off_out, long* info_out);
+int cdseg_plan_finish(const cdseg_plan_spec* spec, const cdseg_plan_finish_io* io, void* stream);
+
 /* ------------------------------------------------------------------ training path, first slice (exact fp32)
  * ref: pointcept/models/default.py:424-493 (training forward), pointcept/engines/train.py:216-271 (loss.backward());
  *      what autograd differentiates: ptv3.py:246-296 (SerializedAttention core), ptv3.py:399-428 (Block tail).

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from cdsegnet_amd import configs, synth
+from cdsegnet_amd import configs, ops, synth
 from cdsegnet_amd.param_init import fill_state_dict
 from cdsegnet_amd.registry import build_model
 import cdsegnet_amd.models  # noqa: F401
@@ -963,3 +963,96 @@ def test_speculated_serialization_depth_is_verified():
         assert plain.engine().last_plan.depth == depths[-1]
         assert np.array_equal(a, b)
     assert len(set(depths)) == 3, depths
+
+
+def _plan_items(plan, pad_keys, curves):
+    """Every item of a plan as numpy arrays, keyed by name (forces the lazy ones)."""
+    out = {"perm0": plan.perm0.cpu().numpy(), "depth": np.array(plan.depth)}
+    cums = sorted(plan.levels)
+    for cum in cums:
+        lv = plan.levels[cum]
+        out[f"L{cum}.n"] = np.array(lv.n)
+        out[f"L{cum}.offs"] = np.array(lv.offs_host)
+        out[f"L{cum}.grid"] = lv.grid.cpu().numpy()
+        out[f"L{cum}.batch"] = lv.batch.cpu().numpy()
+        out[f"L{cum}.code4"] = lv.code4.cpu().numpy()
+        out[f"L{cum}.nbr3"] = lv.nbr(3, True).cpu().numpy()
+        if lv.parent is not None:
+            out[f"L{cum}.child_info"] = lv.child_info().cpu().numpy()
+            out[f"L{cum}.parent"] = np.array(lv.parent[0].cum)
+        for c in curves:
+            o = lv.order(c)
+            if o is not None:
+                out[f"L{cum}.order{c}"] = o.cpu().numpy()
+        for key in pad_keys:
+            K, n_pad, offs, offs_pad, patch_start, max_len, sum_l2 = lv.pad(*key)
+            out[f"L{cum}.pad{key}"] = np.concatenate([[K, n_pad, max_len], offs.cpu().numpy(), offs_pad.cpu().numpy(),
+                                                      patch_start.cpu().numpy()])
+            out[f"L{cum}.pad{key}.sum_l2"] = np.array(sum_l2)
+            for c in curves:
+                g, w = lv.slots(c, *key)
+                out[f"L{cum}.slots{(c,) + key}"] = np.stack([g.cpu().numpy(), w.cpu().numpy()])
+    for a in cums:
+        for b in cums:
+            if a < b and ((0, a) in plan.links or a == 0):
+                cl, sg = plan.link(a, b)
+                nb_ = plan.levels[b].n
+                out[f"link{a}-{b}"] = np.concatenate([cl.cpu().numpy(), sg.cpu().numpy()[:nb_ + 1]])
+    return out
+
+
+@pytest.mark.parametrize("case", ["single_120k", "two_scenes", "eight_sweeps", "tiny", "flash_off"])
+def test_native_plan_equals_per_op_plan(case):
+    """Round 6: build_plan through the native builder (cdseg_plan_begin / cdseg_plan_finish, csrc/plan.hip: two library calls,
+    two arenas) against the per-op path (one binding call per kernel) - every item of the plan bit for bit: sorted order,
+    level-0 and pooled grids / batches / codes, links, kernel maps, child_info words, curve orders, padding tables and their
+    host-side statistics, slot plans.  Cases: a full-size scene, a ragged batch, eight collated LiDAR sweeps (4 batch bits,
+    4 input channels), a scene below one patch, and enable_flash = False (K = the smallest batch element)."""
+    from cdsegnet_amd import configs, synth
+    from cdsegnet_amd.param_init import fill_state_dict
+    from cdsegnet_amd.engine import CURVES
+    ds = "nuscenes" if case == "eight_sweeps" else "scannet"
+    cfg = configs.cdsegnet_config(ds)
+    if case == "flash_off":
+        cfg = copy.deepcopy(cfg)
+        cfg["backbone"]["enable_flash"] = False
+    model = build_model(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+    model = model.cuda().eval()
+    if case == "single_120k":
+        scs = [synth.room_scene(0, 120000)]
+    elif case == "two_scenes":
+        scs = [synth.room_scene(1, 30000), synth.room_scene(2, 1700)]
+    elif case == "eight_sweeps":
+        scs = [synth.lidar_scene(i, 20000) for i in range(8)]
+    elif case == "tiny":
+        scs = [synth.room_scene(3, 600)]
+    else:
+        scs = [synth.room_scene(4, 9000), synth.room_scene(5, 2500)]
+    grid = torch.as_tensor(np.concatenate([s["grid_coord"] for s in scs])).cuda()
+    offs, tot = [], 0
+    for s in scs:
+        tot += len(s["grid_coord"])
+        offs.append(tot)
+    offset = torch.tensor(offs, dtype=torch.int64).cuda()
+    eng = model.engine()
+    eng.prepare(grid.device)
+    ops.bind_stream()
+    bb = model.backbone
+    curves = sorted({CURVES.index(o) for o in bb.order})
+    try:
+        plans = {}
+        for native in (False, True):
+            eng.native_plan = native
+            # (the first call of an engine takes the exact depth through the per-op path; the second one speculates)
+            for _ in range(2):
+                plan = eng.build_plan(grid, offset, offs, tot)
+            assert (getattr(plan, "native", None) is not None) == native
+            plans[native] = _plan_items(plan, eng._pad_keys, curves)
+            torch.cuda.synchronize()
+    finally:
+        ops.unbind_stream()
+    a, b = plans[False], plans[True]
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k

@@ -19,7 +19,6 @@ MI355X-first data layout (not the reference's):
 Host<->device syncs: offset + grid max (depth), pooled point counts (one copy for all levels).
 """
 import math
-import struct
 import os
 import threading
 
@@ -70,10 +69,6 @@ class Level:
         self._nbr = {}
         self._pad = {}
         self._slots = {}
-        # native plan (csrc/plan.hip): padding tables / slot plans already on the device inside the plan's arena; their views
-        # are cut on first use (a model touches ~20 of the ~110)
-        self._pad_lazy = {}
-        self._slot_lazy = {}
 
     def order(self, curve):
         """rank -> physical row for a curve (None = identity for z)."""
@@ -104,38 +99,24 @@ class Level:
             return ops.child_info(self.code4[0], seg, par.n)
         return _shared(self._nbr, "child_info", build)
 
-    def pad_host_py(self, patch_size, enable_flash):
-        """Host side of the padding plan (ref: ptv3.py:188-250) in plain Python ints - a scene has a handful of batch
-        elements and numpy's per-call overhead was most of the plan's host time: K, offs, offs_pad, patch_start (lists)."""
-        offs = self.offs_host
-        counts = [b - a for a, b in zip(offs[:-1], offs[1:])]
-        K = int(patch_size) if enable_flash else int(min(min(counts), patch_size))
-        offs_pad, patch_start = [0], []
-        for c in counts:
-            pc = (c + K - 1) // K * K if c > K else c
-            patch_start.extend(range(offs_pad[-1], offs_pad[-1] + pc, K))
-            offs_pad.append(offs_pad[-1] + pc)
-        patch_start.append(offs_pad[-1])
-        return K, offs, offs_pad, patch_start
-
     def pad_host(self, patch_size, enable_flash):
-        """The same as int32 arrays."""
-        K, offs, offs_pad, patch_start = self.pad_host_py(patch_size, enable_flash)
-        return (K, np.asarray(offs, dtype=np.int32), np.asarray(offs_pad, dtype=np.int32),
-                np.asarray(patch_start, dtype=np.int32))
+        """Host side of the padding plan (ref: ptv3.py:188-250): K, offs, offs_pad, patch_start (int32 arrays)."""
+        counts = np.diff(np.asarray(self.offs_host, dtype=np.int64))
+        K = int(patch_size) if enable_flash else int(min(int(counts.min()), patch_size))
+        pad_counts = np.where(counts > K, (counts + K - 1) // K * K, counts)
+        offs_pad = np.concatenate([[0], np.cumsum(pad_counts)])
+        starts = [np.arange(offs_pad[b], offs_pad[b + 1], K) for b in range(len(counts))]
+        patch_start = np.concatenate(starts + [offs_pad[-1:]]).astype(np.int32)
+        return K, np.asarray(self.offs_host, dtype=np.int32), offs_pad.astype(np.int32), patch_start
 
-    def set_pad(self, key, K, offs_pad, patch_start, offs_dev, offs_pad_dev, patch_start_dev):
-        lens = [int(b) - int(a) for a, b in zip(patch_start[:-1], patch_start[1:])]
-        self._pad[key] = (K, int(offs_pad[-1]), offs_dev, offs_pad_dev, patch_start_dev,
-                          max(lens), float(sum(v * v for v in lens)))
+    def set_pad(self, key, K, offs_pad_np, patch_start_np, offs_dev, offs_pad_dev, patch_start_dev):
+        self._pad[key] = (K, int(offs_pad_np[-1]), offs_dev, offs_pad_dev, patch_start_dev,
+                          int(np.diff(patch_start_np).max()),
+                          float((np.diff(patch_start_np).astype(np.float64) ** 2).sum()))
 
     def pad(self, patch_size, enable_flash):
         """(K, n_pad, offs_dev, offs_pad_dev, patch_start_dev, max_len, sum_L2) - ref: ptv3.py:188-250."""
         key = (patch_size, enable_flash)
-        lz = self._pad_lazy.pop(key, None) if self._pad_lazy else None
-        if lz is not None:
-            K, n_pad, max_len, sum_l2, A, oo, op, ot, nb, npatch = lz
-            self._pad[key] = (K, n_pad, A[oo:oo + nb + 1], A[op:op + nb + 1], A[ot:ot + npatch + 1], max_len, sum_l2)
         if key not in self._pad:  # not pre-uploaded by Engine.build_plan: upload now
             K, offs, offs_pad, patch_start = self.pad_host(patch_size, enable_flash)
             dev = self.grid.device
@@ -145,11 +126,6 @@ class Level:
         return self._pad[key]
 
     def slots(self, curve, patch_size, enable_flash):
-        lz = self._slot_lazy.pop((curve, patch_size, enable_flash), None) if self._slot_lazy else None
-        if lz is not None:
-            A, go, wo, n_pad, sid = lz
-            self._slots[(curve, patch_size, enable_flash)] = ((A[go:go + n_pad], A[wo:wo + n_pad]), sid, None)
-
         def build():
             K, n_pad, offs, offs_pad = self.pad(patch_size, enable_flash)[:4]
             return ops.pad_plan(self.order(curve), offs, offs_pad, K, n_pad)
@@ -160,14 +136,6 @@ class Plan:
     def __init__(self):
         self.levels = {}
         self.links = {}
-        self._finish = None  # Engine.build_plan(defer_pads=True): the padding / slot plans, not built yet
-
-    def finish_pads(self):
-        """Build the deferred padding / slot plans (no-op when build_plan already did).  Called on the stream the plan was
-        built on, before any fork: the items carry no events."""
-        fin, self._finish = self._finish, None
-        if fin is not None:
-            fin()
 
     def link(self, a, b):
         """fine level a -> coarse level b: (cluster (n_a) int32, seg_start (n_b + 1) int32)."""
@@ -251,9 +219,6 @@ class Engine:
         self._sat = None
         self.exact_attention_core = False  # budget tool only: fp32 attention core inside a 16-bit trunk (binding path)
         self._pad_keys = None
-        self.native_plan = True  # build_plan through cdseg_plan_begin / cdseg_plan_finish (False: one binding call per step; tools A/B)
-        self._plan_specs = {}
-        self.eager_kernel_maps = True  # kernel maps of all levels built inside build_plan (False: at first use; tools A/B)
         self._side = {}
         self.fork_stage = 1  # dominant-branch encoder stage at which the noise-branch encoder is forked (None: serial)
         self._work_lock = threading.Lock()
@@ -547,203 +512,37 @@ class Engine:
         return out, done
 
     # ------------------------------------------------------------------ plan
-    def _pin(self, name, numel, ring=1):
-        """Per host thread: pinned int32 staging buffers (`ring` of them, handed out in turn together with the event that
-        guards the buffer's previous use).  Returns (tensor, its numpy view, slot dict)."""
-        slots = getattr(self._tls, "pins", None)
-        if slots is None:
-            slots = self._tls.pins = {}
-        ent = slots.get(name)
-        if ent is None:
-            ent = slots[name] = {"i": 0, "bufs": [None] * ring}
-        i = ent["i"] = (ent["i"] + 1) % ring
-        slot = ent["bufs"][i]
-        if slot is None or slot["t"].numel() < numel:
-            t = torch.empty(max(256, int(numel * 1.5)), dtype=torch.int32, pin_memory=True)
-            slot = ent["bufs"][i] = {"t": t, "np": t.numpy(), "ev": None}
-        elif slot["ev"] is not None:
-            slot["ev"].synchronize()  # (a copy out of this buffer issued `ring` plans ago: long done)
-        return slot["t"], slot["np"], slot
-
-    def _native_spec(self, depth, n_cum, c_cum, all_cum, end_bit):
-        """The static description cdseg_plan_begin / cdseg_plan_finish need (include/cdseg.h cdseg_plan_spec), cached per
-        serialization depth; None when this model / depth is outside what the native builder covers (the per-op path runs)."""
-        key = (depth, end_bit + 2 <= 64)
-        if key in self._plan_specs:
-            return self._plan_specs[key]
-        bb = self.model.backbone
-        ent = None
-        if self._pad_keys is None:
-            self._pad_keys = self._collect_pad_keys()
-        used = sorted({CURVES.index(o) for o in bb.order} - {0})
-        curves = sorted({CURVES.index(o) for o in bb.order})
-        nlev = len(all_cum) - 1
-        strictly = all(b > a for cum in (n_cum, c_cum) for a, b in zip(cum[:-1], cum[1:]))
-        li = {c: i for i, c in enumerate(all_cum)}
-        links = sorted({(li[a], li[b]) for cum in (n_cum, c_cum) for a, b in zip(cum[:-1], cum[1:]) if li[a] >= 1} |
-                       {(i, i + 1) for i in range(1, nlev) if all_cum[i + 1] - all_cum[i] == 1})
-        ok = (1 <= nlev <= 8 and strictly and len(used) <= 3 and (not used or (end_bit + 2 <= 64 and FUSED_CURVE_SORT)) and
-              len(links) <= 16 and 1 <= len(self._pad_keys) <= 4 and hasattr(_lib.load(), "cdseg_plan_finish"))
-        if ok:
-            sp = _lib.PlanSpec()
-            sp.nlev = nlev
-            for i, c in enumerate(all_cum):
-                sp.cum[i] = c
-            sp.ncurve = len(used)
-            for i, c in enumerate(used):
-                sp.curve_rows[i] = c
-            sp.nslot_curve = len(curves)
-            for i, c in enumerate(curves):
-                sp.slot_curve[i] = -1 if c == 0 else used.index(c)
-            sp.nlink = len(links)
-            for i, (a, b) in enumerate(links):
-                sp.link_a[i], sp.link_b[i] = a, b
-            sp.npad = len(self._pad_keys)
-            for i, (ps, fl) in enumerate(self._pad_keys):
-                sp.pad_patch[i], sp.pad_flash[i] = int(ps), int(bool(fl))
-            ent = (sp, used, curves, links)
-        self._plan_specs[key] = ent
-        return ent
-
-    def _collect_pad_keys(self):
-        bb = self.model.backbone
-        return sorted({(int(m_.patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
-                       if hasattr(m_, "patch_size") and hasattr(m_, "enable_flash")} |
-                      {(int(m_.q_patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
-                       if hasattr(m_, "q_patch_size")})
-
-    def _build_plan_native(self, ent, grid, offset_dev, offset_host, n, depth, end_bit, gmax_host, n_cum, c_cum, all_cum,
-                           while_device_works):
-        """build_plan through the native builder (csrc/plan.hip): two library calls around the one host read, every plan item
-        a view into one of two arenas per call.  Same items, bit for bit, as the per-op path below
-        (tests/test_gpu_ops.py::test_native_plan_equals_per_op_plan)."""
-        sp, used, curves, links = ent
-        nb = len(offset_host)
-        grid = grid.contiguous()
-        nlev = sp.nlev
-        nmeta = nlev * (1 + nb) + 1
-        mt, mnp, _ = self._pin("meta", nmeta)
-        call = ops.NativePlanCall(sp, grid, offset_dev, n, nb, depth, end_bit, gmax_host, mt)
-        call.begin(0)
-        ev = ops.record_event()
-        call.begin(1)  # the level-0 curve sort does not need the pooled sizes: queued before the host waits
-        if while_device_works is not None:
-            while_device_works()
-        perm0, grid0, bat0, code0, cl_all, seg_all, orders0 = call.begin_views()
-        ev.synchronize()  # the one sync: pooled sizes, duplicate-voxel count, grid maximum
-        flat = mnp[:nmeta].tolist()
-        if gmax_host is not None:
-            true_depth = int(gmax_host.item()).bit_length()
-            self._depth_hint[grid.device] = true_depth
-            if true_depth != depth:  # the guess was wrong: everything built so far used the wrong code width
-                return self.build_plan(grid, offset_dev, offset_host, n, _exact_depth=true_depth)
-        if flat[-1]:
-            raise DuplicateVoxelsError(
-                f"input has {flat[-1]} duplicate voxels (points sharing (batch, grid_coord) with another "
-                f"point): the model expects one point per voxel - voxelise first (GridSample)", flat[-1])
-        sid = ops.current_stream_id()
-        plan = Plan()
-        plan.perm0, plan.n_cum, plan.c_cum, plan.depth = perm0, n_cum, c_cum, depth
-        plan.native = call  # (keeps the arenas' owner alive with the plan)
-        offs0 = [0] + [int(v) for v in offset_host]
-        m = [flat[i * (1 + nb)] for i in range(nlev)]
-        offs_rows = [offs0] + [[0] + [v + 1 for v in flat[i * (1 + nb) + 1:(i + 1) * (1 + nb)]] for i in range(nlev)]
-        slot = {}
-
-        def pads_pin(count):
-            pt, _, sl = self._pin("pads", count, ring=4)
-            slot["s"] = sl
-            return pt
-
-        off, info = call.finish(m, offs_rows, pads_pin)
-        slot["s"]["ev"] = ops.record_event()
-        f32, f64 = call.f32, call.f64
-        it = iter(off)
-        sizes = [n] + m
-        lv0 = plan.levels[0] = Level(0, depth, n, grid0, bat0, code0, offs0)
-        levels = [lv0]
-        for i in range(nlev):
-            go, bo, co = next(it), next(it), next(it)
-            mi, cum = m[i], all_cum[i + 1]
-            lv = Level(cum, depth - cum, mi, f32[go:go + 3 * mi].view(mi, 3), f32[bo:bo + mi], f64[co:co + 4 * mi].view(4, mi),
-                       offs_rows[i + 1])
-            plan.levels[cum] = lv
-            levels.append(lv)
-            plan.links[(0, cum)] = ((cl_all[i], seg_all[i]), sid, None)
-        for a, b in links:
-            clo, sgo = next(it), next(it)
-            plan.links[(all_cum[a], all_cum[b])] = ((f32[clo:clo + sizes[a]], f32[sgo:sgo + sizes[b] + 1]), sid, None)
-        for i in range(nlev):
-            if all_cum[i + 1] - all_cum[i] == 1:
-                levels[i].parent = (levels[i + 1], plan.links[(all_cum[i], all_cum[i + 1])][0])
-        for i, lv in enumerate(levels):
-            o = next(it)
-            lv._nbr[(3, True)] = (f32[o:o + 27 * sizes[i]].view(27, sizes[i]), sid, None)
-        for i, lv in enumerate(levels):
-            o = next(it)
-            if o >= 0:
-                lv._nbr["child_info"] = (f64[o:o + sizes[i + 1]], sid, None)
-        pos = next(it)
-        nc = len(used)
-        for k, c in enumerate(used):
-            lv0._order[c] = (orders0[k], sid, None)
-        for i in range(1, nlev + 1):
-            for k, c in enumerate(used):
-                levels[i]._order[c] = (f32[pos + k * sizes[i]:pos + (k + 1) * sizes[i]], sid, None)
-            pos += nc * sizes[i]
-        q = 5
-        per = []
-        for i, lv in enumerate(levels):
-            for key in self._pad_keys:
-                oo, op, ot = next(it), next(it), next(it)
-                K, n_pad, npatch, max_len, bits = info[q:q + 5]
-                q += 5
-                lv._pad_lazy[key] = (K, n_pad, max_len, struct.unpack("d", struct.pack("q", bits))[0], f32, oo, op, ot, nb,
-                                     npatch)
-                per.append((lv, key, n_pad))
-        gb, wb = next(it), next(it)
-        pos = 0
-        for lv, key, n_pad in per:
-            for c in curves:
-                lv._slot_lazy[(c,) + key] = (f32, gb + pos, wb + pos, n_pad, sid)
-                pos += n_pad
-        return plan
-
-    def build_plan(self, grid, offset_dev, offset_host, n, _exact_depth=None, while_device_works=None, defer_pads=False):
+    def build_plan(self, grid, offset_dev, offset_host, n, _exact_depth=None):
         """Serialization, pooled levels, kernel-map sources, padding / slot plans of one forward.
         Host reads: ONE in steady state (round 5) - the pooled sizes.  The serialization depth (`int(grid_coord.max())
         .bit_length()`, structure.py:66: the reference's first host sync) is taken from the previous call's plan, the grid
         maximum of THIS call travels to the host behind the pooled-size read, and a mismatch (a scene on a coarser / finer
-        grid than the last one) rebuilds the plan with the right depth - results never depend on the guess.
-
-        Round 6 (bs = 1 is the reference's protocol and there the device used to idle ~0.7 ms per scene behind this function's
-        host work, profiles/r06_bs1_gaps.txt): nothing in here blocks the host except the one read, and the device has work
-        queued across it - the pooled sizes travel through a pinned buffer behind an event, the level-0 curve sort (which does
-        not need them) is issued BEFORE the host waits, `while_device_works` (the caller's host-only work: the random draws)
-        runs in that shadow too, the kernel maps are built before the padding plans' host arithmetic (plain Python ints), and
-        the padding tables go up through a pinned buffer without a blocking copy.  `defer_pads`: the padding / slot plans (host
-        arithmetic + one upload + one launch; first needed by the first Block's attention) are left to `plan.finish_pads()`,
-        which `backbone` calls once the stem is queued - device work for that stretch of host time."""
+        grid than the last one) rebuilds the plan with the right depth - results never depend on the guess."""
         bb = self.model.backbone
         nb = len(offset_host)
-        on_gpu = grid.is_cuda
+        gmax_dev = ops.grid_max(grid)
         hint = self._depth_hint.get(grid.device) if _exact_depth is None else None
-        gmax_host = gmax_dev = None
+        gmax_host = None
         if _exact_depth is not None:
             depth = _exact_depth
-        elif hint is not None and on_gpu and self.speculate_depth:
+        elif hint is not None and grid.is_cuda and self.speculate_depth:
             depth = hint
             gmax_host = getattr(self._tls, "gmax_pin", None)  # one pinned word per issuing host thread (build_plan does not
             if gmax_host is None:                               # return before it has read it)
                 gmax_host = self._tls.gmax_pin = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            gmax_host.copy_(gmax_dev, non_blocking=True)  # complete once the pooled-size read below has returned
         else:
-            gmax_dev = ops.grid_max(grid)
             depth = int(gmax_dev.item()).bit_length()
             self._depth_hint[grid.device] = depth
         # same guards as the reference (structure.py:69,74)
         assert depth * 3 + nb.bit_length() <= 63, "serialization code does not fit int64"
         assert depth <= 16, "grid extent exceeds 2^16 voxels per axis"
         end_bit = min(64, 3 * depth + max(1, nb.bit_length()))
+        batch = ops.offset2batch(offset_dev, n)
+        zc = ops.encode(grid, batch, depth, "z")
+        zs, perm0 = ops.sort_pairs(zc, None, end_bit=end_bit)
+        grid0, bat0 = ops.plan_gather_grid(grid, perm0, zs, depth)
+        code0 = ops.encode4(grid0, bat0, depth)
 
         def cum_depths(strides):
             cum, d = [0], depth
@@ -758,60 +557,22 @@ class Engine:
         n_cum = cum_depths(bb.n_stride)
         c_cum = cum_depths(bb.c_stride) if bb.condition else [0]
         all_cum = sorted(set(n_cum + c_cum))
-        coarse = [c for c in all_cum if c > 0]
-        if on_gpu and self.native_plan and (gmax_host is not None or _exact_depth is not None):
-            ent = self._native_spec(depth, n_cum, c_cum, all_cum, end_bit)
-            if ent is not None:
-                return self._build_plan_native(ent, grid, offset_dev, offset_host, n, depth, end_bit, gmax_host, n_cum, c_cum,
-                                               all_cum, while_device_works)
-        if gmax_dev is None:
-            gmax_dev = ops.grid_max(grid)
-            if gmax_host is not None:
-                gmax_host.copy_(gmax_dev, non_blocking=True)  # complete once the pooled-size read below has returned
-        # index of every batch element's last point, on the device from the device offsets (a host list would be a blocking
-        # pageable copy in the middle of the plan kernels)
-        last_idx = (offset_dev.to(torch.int32) - 1) if coarse else None
-        batch = ops.offset2batch(offset_dev, n)
-        zc = ops.encode(grid, batch, depth, "z")
-        zs, perm0 = ops.sort_pairs(zc, None, end_bit=end_bit)
-        grid0, bat0 = ops.plan_gather_grid(grid, perm0, zs, depth)
-        code0 = ops.encode4(grid0, bat0, depth)
-
         plan = Plan()
         plan.perm0, plan.n_cum, plan.c_cum, plan.depth = perm0, n_cum, c_cum, depth
         offs0 = [0] + [int(v) for v in offset_host]
-        lv0 = plan.levels[0] = Level(0, depth, n, grid0, bat0, code0, offs0)
-        used = sorted({CURVES.index(o) for o in bb.order} - {0})
-
-        def sort_level0_curves():  # the level-0 orders of all curves in use with ONE sort (Onesweep's cost is mostly fixed)
-            if used and end_bit + 2 <= 64 and FUSED_CURVE_SORT and not all(c in lv0._order for c in used):
-                srt = ops.sort_curves(code0, used, end_bit)
-                for k, c in enumerate(used):
-                    lv0._order[c] = (srt[k], ops.current_stream_id(), None)
-
+        plan.levels[0] = Level(0, depth, n, grid0, bat0, code0, offs0)
+        coarse = [c for c in all_cum if c > 0]
         if coarse:
             dev = grid.device
+            last_idx = torch.tensor([v - 1 for v in offset_host], dtype=torch.int32, device=dev)
             cl_all, seg_all, meta = ops.pool_levels(zs, [3 * cum for cum in coarse], last_idx)
             tmp = [(cl_all[i], seg_all[i]) for i in range(len(coarse))]
-            if on_gpu:
-                # the pooled sizes (+ the duplicate-voxel count) come back through a pinned buffer; the host waits for THAT
-                # copy only, with the curve sort already queued behind it and its own host-only work done in the meantime
-                mt, mnp, _ = self._pin("meta", meta.numel())
-                mt[:meta.numel()].copy_(meta, non_blocking=True)
-                ev = ops.record_event()
-                sort_level0_curves()
-                if while_device_works is not None:
-                    while_device_works()
-                    while_device_works = None
-                ev.synchronize()  # the one sync for all pooled sizes
-                flat = mnp[:meta.numel()].tolist()
-            else:
-                flat = meta.cpu().tolist()
+            flat = meta.cpu().tolist()  # the one sync for all pooled sizes (+ the duplicate-voxel count)
             if gmax_host is not None:
                 true_depth = int(gmax_host.item()).bit_length()
                 self._depth_hint[grid.device] = true_depth
                 if true_depth != depth:  # the guess was wrong: everything built so far used the wrong code width
-                    return self.build_plan(grid, offset_dev, offset_host, n, _exact_depth=true_depth, defer_pads=defer_pads)
+                    return self.build_plan(grid, offset_dev, offset_host, n, _exact_depth=true_depth)
                 gmax_host = None
             if flat[-1]:
                 # the model's input contract (GridSample upstream, structure.py:39-102 downstream): one point per voxel.
@@ -833,72 +594,55 @@ class Engine:
             for fa, co in zip(cums[:-1], cums[1:]):
                 if co - fa == 1:
                     plan.levels[fa].parent = (plan.levels[co], plan.link(fa, co))
-            if on_gpu and self.eager_kernel_maps:
-                # ... and built NOW (every Block's conv needs its level's map): device work for the stretch of host
-                # arithmetic below.  Issued on the plan's stream ahead of any fork, so consumers need no event
-                share, SHARE_EVENTS.on = SHARE_EVENTS.on, False
-                try:
-                    for cum in reversed(cums):
-                        plan.levels[cum].nbr(3, True)
-                finally:
-                    SHARE_EVENTS.on = share
             # curve orders of the pooled levels: derived from the level-0 orders (hierarchical keys), not sorted
+            used = sorted({CURVES.index(o) for o in bb.order} - {0})
             if used:
-                sort_level0_curves()
+                lv0 = plan.levels[0]
+                # the level-0 orders of all curves in use with ONE sort (Onesweep's cost is mostly fixed)
+                if end_bit + 2 <= 64 and FUSED_CURVE_SORT and not all(c in lv0._order for c in used):
+                    srt = ops.sort_curves(code0, used, end_bit)
+                    for k, c in enumerate(used):
+                        lv0._order[c] = (srt[k], ops.current_stream_id(), None)
                 derived = ops.coarse_orders([t[0] for t in tmp], [lv0.order(c) for c in used], host[:len(coarse)])
                 for i, cum in enumerate(coarse):
                     for k, c in enumerate(used):
                         plan.levels[cum]._order[c] = (derived[i][k], ops.current_stream_id(), None)
-        if while_device_works is not None:
-            while_device_works()
         if gmax_host is not None:  # no pooled level, so no read has happened yet: verify the guessed depth now
             true_depth = int(gmax_dev.item()).bit_length()
             self._depth_hint[grid.device] = true_depth
             if true_depth != depth:
-                return self.build_plan(grid, offset_dev, offset_host, n, _exact_depth=true_depth, defer_pads=defer_pads)
-        def finish_pads():
-            # every padding plan the model will ask for, uploaded with ONE host->device copy
-            if self._pad_keys is None:  # static per model: walk the module tree once
-                self._pad_keys = self._collect_pad_keys()
-            pad_keys = self._pad_keys
-            flat_up, meta = [], []
-            for cum, lv in plan.levels.items():
-                for key in pad_keys:
-                    K, offs, offs_pad, patch_start = lv.pad_host_py(*key)
-                    meta.append((lv, key, K, offs_pad, patch_start, len(offs), len(offs_pad), len(patch_start)))
-                    flat_up += offs
-                    flat_up += offs_pad
-                    flat_up += patch_start
-            if on_gpu:
-                pt, pnp, slot = self._pin("pads", len(flat_up), ring=4)
-                pnp[:len(flat_up)] = flat_up
-                up = torch.empty(len(flat_up), dtype=torch.int32, device=grid.device)
-                up.copy_(pt[:len(flat_up)], non_blocking=True)
-                slot["ev"] = ops.record_event()
-            else:
-                up = torch.tensor(flat_up, dtype=torch.int32, device=grid.device)
-            pos = 0
-            for lv, key, K, offs_pad, patch_start, la, lb, lc in meta:
-                lv.set_pad(key, K, offs_pad, patch_start, up[pos:pos + la], up[pos + la:pos + la + lb],
-                           up[pos + la + lb:pos + la + lb + lc])
-                pos += la + lb + lc
-            # ... and every slot plan (level x curve x patch key) with ONE launch
-            curves = sorted({CURVES.index(o) for o in bb.order})
-            items, where = [], []
-            for cum, lv in plan.levels.items():
-                for key in pad_keys:
-                    K, n_pad, offs, offs_pad = lv.pad(*key)[:4]
-                    for c in curves:
-                        items.append((lv.order(c), offs, offs_pad, K, n_pad))
-                        where.append((lv, (c,) + key))
-            cur = ops.current_stream_id()
-            for (lv, key), gw in zip(where, ops.pad_plan_batch(items, nb)):
-                lv._slots[key] = (gw, cur, None)
-
-        if defer_pads and on_gpu:
-            plan._finish = finish_pads
-        else:
-            finish_pads()
+                return self.build_plan(grid, offset_dev, offset_host, n, _exact_depth=true_depth)
+        # every padding plan the model will ask for, uploaded with ONE host->device copy
+        if self._pad_keys is None:  # static per model: walk the module tree once
+            self._pad_keys = sorted({(int(m_.patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
+                                     if hasattr(m_, "patch_size") and hasattr(m_, "enable_flash")} |
+                                    {(int(m_.q_patch_size), bool(m_.enable_flash)) for m_ in bb.modules()
+                                     if hasattr(m_, "q_patch_size")})
+        pad_keys = self._pad_keys
+        chunks, meta = [], []
+        for cum, lv in plan.levels.items():
+            for key in pad_keys:
+                K, offs, offs_pad, patch_start = lv.pad_host(*key)
+                meta.append((lv, key, K, offs_pad, patch_start, len(offs), len(offs_pad), len(patch_start)))
+                chunks += [offs, offs_pad, patch_start]
+        up = torch.tensor(np.concatenate(chunks), device=grid.device)
+        pos = 0
+        for lv, key, K, offs_pad, patch_start, la, lb, lc in meta:
+            lv.set_pad(key, K, offs_pad, patch_start, up[pos:pos + la], up[pos + la:pos + la + lb],
+                       up[pos + la + lb:pos + la + lb + lc])
+            pos += la + lb + lc
+        # ... and every slot plan (level x curve x patch key) with ONE launch
+        curves = sorted({CURVES.index(o) for o in bb.order})
+        items, where = [], []
+        for cum, lv in plan.levels.items():
+            for key in pad_keys:
+                K, n_pad, offs, offs_pad = lv.pad(*key)[:4]
+                for c in curves:
+                    items.append((lv.order(c), offs, offs_pad, K, n_pad))
+                    where.append((lv, (c,) + key))
+        cur = ops.current_stream_id()
+        for (lv, key), gw in zip(where, ops.pad_plan_batch(items, nb)):
+            lv._slots[key] = (gw, cur, None)
         return plan
 
     # ------------------------------------------------------------------ layers
@@ -1383,19 +1127,10 @@ class Engine:
         cond = bb.condition
         c_ch = m.c_in_channels
         per_call = (2 + len(bb.c_stride) + len(bb.n_stride)) if cond else (1 + len(bb.n_stride))
-        box = {"draws": draws}
-
-        def host_draws():
-            # the random draws are host-only work (torch's CPU generator, in the reference's consumption order): taken while
-            # the device runs the first plan kernels (build_plan calls this once, before it waits for the pooled sizes)
-            if box["draws"] is None:
-                box["draws"] = self.draw(n, tuple(feat.shape), c_ch, noise_level, per_call * n_backbone_calls, always_noise)
-            d = box["draws"]
-            self._tls.rng = (d["rng_base"] if "rng_base" in d
-                             else self.reserve_rng(max(self.RNG_RESERVE, 2 + n_backbone_calls)))
-
-        plan = self.build_plan(grid, offset.to(torch.int64), offset_host, n, while_device_works=host_draws, defer_pads=True)
-        draws = box["draws"]
+        if draws is None:
+            draws = self.draw(n, tuple(feat.shape), c_ch, noise_level, per_call * n_backbone_calls, always_noise)
+        self._tls.rng = (draws["rng_base"] if "rng_base" in draws
+                         else self.reserve_rng(max(self.RNG_RESERVE, 2 + n_backbone_calls)))
         feat = feat.float().contiguous()
         if noise_level is not None:  # ref: default.py:373-374 (perturbs feat and rebinds it in input_dict)
             fn = draws.get("feat_noise")
@@ -1403,6 +1138,7 @@ class Engine:
             feat = ops.axpy(feat, fn.contiguous(), noise_level)
             input_dict["feat"] = feat
         perms = list(draws["perms"]) if bb.shuffle_orders else [None] * (per_call * n_backbone_calls)
+        plan = self.build_plan(grid, offset.to(torch.int64), offset_host, n)
         self.last_plan = plan
         return feat, draws, perms, plan, per_call
 
@@ -1556,11 +1292,8 @@ class Engine:
 
             fork = self.fork_stage if (dev.type == "cuda" and self.fork_stage is not None) else None
             SHARE_EVENTS.on = fork is not None
-            if fork is None:
-                plan.finish_pads()
             cst = c_branch() if fork is None else None
             nst = self._eng("n_emb").run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
-            plan.finish_pads()  # (deferred by _setup: the stem is device work for the plan's last stretch of host time)
             join = None
             for s in range(bb.n_num_stages):
                 if fork is not None and s == fork:
@@ -1574,7 +1307,6 @@ class Engine:
             e.run_cross_block(nst, cst)
         else:
             nst = self._eng("n_emb").run_embedding(plan, feat, plan.perm0, "n_emb", n_curves)
-            plan.finish_pads()
             for s in range(bb.n_num_stages):
                 nst = enc_stage(nst, "n", s, n_cum, next(pi) if s > 0 else None)
         self.trace = {"n_bottleneck": nst.x}

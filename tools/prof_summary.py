@@ -52,9 +52,44 @@ def concurrency(db, cur):
             ce = max(ce, b)
     busy += ce - cs
     total = sum(b - a for a, b in rows)
+    gaps(cur, rows[0][0])
     print(f"\n# timeline over the last 60% of dispatches: wall {1e-6 * (t1 - t0):.2f} ms, some kernel running "
           f"{100.0 * busy / (t1 - t0):.1f}% of it, sum of kernel durations / wall = {total / (t1 - t0):.2f} "
           f"(average kernels in flight)")
+
+
+def gaps(cur, t_from):
+    """Idle gaps of the device (no kernel of any stream running): histogram, and the (kernel before -> kernel after) pairs
+    that own most of the idle time."""
+    rows = list(cur.execute("select start, end, name from kernels where start >= ? order by start", (t_from,)))
+    if len(rows) < 2:
+        return
+    edges = [0, 1, 2, 4, 8, 16, 32, 64, 128, 1 << 30]
+    hist = [[0, 0.0] for _ in edges]
+    pairs = {}
+    ce, cname = rows[0][1], rows[0][2]
+    for a, b, n in rows[1:]:
+        if a > ce:
+            g = (a - ce) / 1e3
+            for i in range(len(edges) - 1):
+                if g < edges[i + 1]:
+                    hist[i][0] += 1
+                    hist[i][1] += g
+                    break
+            k = (short(cname)[:60], short(n)[:60])
+            c = pairs.setdefault(k, [0, 0.0])
+            c[0] += 1
+            c[1] += g
+        if b > ce:
+            ce, cname = b, n
+    tot = sum(h[1] for h in hist)
+    print(f"\n# idle gaps (no kernel running) over the same window: {sum(h[0] for h in hist)} gaps, {tot / 1e3:.3f} ms")
+    for i in range(len(edges) - 1):
+        hi = "inf" if edges[i + 1] >= 1 << 30 else str(edges[i + 1])
+        print(f"  {edges[i]:>4} .. {hi:>4} us: {hist[i][0]:6d} gaps {hist[i][1] / 1e3:9.3f} ms")
+    print("# idle time by (kernel that ended last -> kernel that started next), top 25")
+    for (a, b), (c, g) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"  {c:6d} x {g / c:8.2f} us = {g / 1e3:8.3f} ms   {a}  ->  {b}")
 
 
 if __name__ == "__main__":

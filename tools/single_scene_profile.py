@@ -7,6 +7,12 @@ sys.path.insert(0, os.getcwd())
 from cdsegnet_amd import _lib
 if os.environ.get("CDSEG_AB_LIB"):  # A/B runs against an experimental bfloat16 build (tools only): implies bf16+head
     _lib.LIB_PATH = os.path.abspath(os.environ["CDSEG_AB_LIB"])
+if os.environ.get("CDSEG_AB_ENGINE"):  # A/B of the host side: another engine.py in place of the package's (tools only)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cdsegnet_amd.engine", os.environ["CDSEG_AB_ENGINE"])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["cdsegnet_amd.engine"] = mod
+    spec.loader.exec_module(mod)
 from cdsegnet_amd import configs, synth
 from cdsegnet_amd.param_init import fill_state_dict
 from cdsegnet_amd.registry import build_model
@@ -30,3 +36,14 @@ for _ in range(20):
 torch.cuda.synchronize()
 print(f"single scene, {len(sc['coord'])} points: {1e3 * (time.perf_counter() - t) / 20:.2f} ms wall per inference "
       f"(30 inferences in this process incl. 10 warm-up)", flush=True)
+if os.environ.get("CDSEG_SYNC_EACH"):  # the reference's protocol: the reference's dict, one synchronisation per scene
+    ref = {k: inp[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    ts = []
+    for _ in range(60):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        model.inference(dict(ref), eval=False)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t)
+    ts.sort()
+    print(f"  synchronised per scene, no offset_host hint: median {1e3 * ts[len(ts) // 2]:.3f} ms, min {1e3 * ts[0]:.3f} ms", flush=True)
