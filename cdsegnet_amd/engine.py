@@ -255,7 +255,11 @@ class Engine:
         self._plan_specs = {}
         self.eager_kernel_maps = True  # kernel maps of all levels built inside build_plan (False: at first use; tools A/B)
         self._side = {}
-        self.fork_stage = 1  # dominant-branch encoder stage at which the noise-branch encoder is forked (None: serial)
+        # dominant-branch encoder stage at which the noise-branch encoder is forked onto its side stream (None: serial).  2 (round
+        # 6, was 1): the noise branch's throughput-bound 120 k-row Blocks then run next to the dominant branch's deep,
+        # latency-bound stages instead of next to its 55 k-row ones: bs = 1 3.87 -> 3.81 ms at 120 k points, 3.11 -> 3.01 ms at
+        # 60 k (tools/latency_probe.py, profiles/r06_fork_stage.txt)
+        self.fork_stage = int(os.environ["CDSEG_FORK_STAGE"]) if os.environ.get("CDSEG_FORK_STAGE") else 2
         self._work_lock = threading.Lock()
         self._tls = threading.local()  # per host thread: device-RNG cursor
         self.attn_work = 0.0  # algorithmic attention FLOPs issued so far (4 * 16 * H * sum_p L_p^2 per launch)
