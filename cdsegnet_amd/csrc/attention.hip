@@ -174,6 +174,7 @@ constexpr int ATTN_RUN = 8;        // query tiles per run: the unit slices of a 
 #endif
 constexpr int BF_WAVES = ATTN_BF16_WAVES, BF_THREADS = 64 * BF_WAVES;
 static_assert(BF_WAVES >= ATTN_RUN && BF_WAVES <= 12, "the first run of a block's tiles is pre-assigned to waves 0 .. 7");
+constexpr int BF_WAVES_WIDE = 16;  // the one-block-per-CU shape of under-filled launches (attn_bf16_kernel<16>)
 constexpr int KV_STAGE = 1024 * 32;  // K (or V) of one patch-head
 constexpr int ONES_BYTES = 2048;     // 8-byte words {1.0bf16, 0, 0, 0}: covers every immediate offset of a tile pair
 constexpr int SMEM_BF16 = 2 * KV_STAGE + ONES_BYTES + 64 + 4096;  // + slot -> query row table
@@ -247,7 +248,14 @@ __device__ __forceinline__ float sq8_bf16(const uint4& a) {
   return dot2_bf16(a.w, a.w, t);
 }
 
-__global__ __launch_bounds__(BF_THREADS, (2 * BF_WAVES) / 4) void attn_bf16_kernel(AttnP p) {
+// WAVES = 8: two blocks per CU (the product's shape for every launch that fills the chip).  WAVES = 16 (round 6): ONE block per
+// CU with four waves per SIMD behind a single K / V staging - for launches with at most one block per CU (a single scene's
+// stages 0 - 2: 236 / 216 / 2 x 112 blocks), where the 8-wave block left every SIMD with two waves and a second slice of the same
+// patch-head on the same CU paid a second staging (make_schedule picks; same arithmetic per output row, results identical).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void attn_bf16_kernel(AttnP p) {
+  constexpr int BF_WAVES = WAVES, BF_THREADS = 64 * WAVES;
+  constexpr int NPC = 32 / WAVES;  // 32-key pieces of K (and of V) a wave stages
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   unsigned* s_next = reinterpret_cast<unsigned*>(smem + 2 * KV_STAGE + ONES_BYTES + 48);  // query tiles handed out so far
@@ -308,9 +316,9 @@ __global__ __launch_bounds__(BF_THREADS, (2 * BF_WAVES) / 4) void attn_bf16_kern
   // ---- stage K and V by LDS-DMA.  Wave w moves the 32-key pieces w, w + 8, ..: lane -> (key = lane / 2, 16-B half).
   {
     const int kip = lane >> 1, hs = lane & 1;
-    int gk[4];
+    int gk[NPC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       const int s = (wave + BF_WAVES * i) * 32 + kip;
       gk[i] = s < L ? p.kv_gidx[ps + s] : -1;
     }
@@ -329,10 +337,10 @@ __global__ __launch_bounds__(BF_THREADS, (2 * BF_WAVES) / 4) void attn_bf16_kern
     // (the compiler waits for its own loads above; the DMAs are invisible to it and are waited for by hand below)
     // all source addresses first (pinned by the empty asm): the compiler's vmcnt(0) for an index load must not sit
     // between two DMAs, where it would wait for the DMA before it as well
-    const void* ksrc[4];
-    const void* vsrc[4];
+    const void* ksrc[NPC];
+    const void* vsrc[NPC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       const int s = (wave + BF_WAVES * i) * 32 + kip;
       ksrc[i] = vsrc[i] = (const char*)g_attn_zero + hs * 16;
       if (gk[i] >= 0) {
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(BF_THREADS, (2 * BF_WAVES) / 4) void attn_bf16_kern
       asm volatile("" : "+v"(ksrc[i]), "+v"(vsrc[i]));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       const int pc = wave + BF_WAVES * i;
       if (pc < nkt) {
         dma16(ksrc[i], lds_base + pc * 1024);
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(BF_THREADS, (2 * BF_WAVES) / 4) void attn_bf16_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (LP_IS_F16 && !(p.flags & CDSEG_ATTN_V_BF16)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NPC; ++i) {
         const int pc = wave + BF_WAVES * i;
         if (pc < nkt) {
           uint4* vp = reinterpret_cast<uint4*>(smem + KV_STAGE + pc * 1024 + lane * 16);
@@ -974,6 +982,16 @@ static unsigned make_schedule(AttnP& p, int num_patches, int num_heads, int max_
   return nblocks;
 }
 
+// One block per CU at most, every block a whole patch-head or a slice with >= 16 query tiles (so that 16 waves have a tile each):
+// the launches of a single scene's wide stages.  CDSEG_ATTN_W16 = 0 switches the shape off (tools A/B).
+static bool attention_wide16(const AttnP& p, unsigned nblocks, int max_len) {
+  const int on = cdseg_knob("CDSEG_ATTN_W16", 1);
+  const int max_blocks = cdseg_knob("CDSEG_ATTN_W16_MAX_BLOCKS", 256);
+  if (!on || nblocks > (unsigned)max_blocks || p.nzones != 1) return false;
+  const int nqt = (max_len + 31) / 32;
+  return nqt / p.zsplit[0] >= cdseg_knob("CDSEG_ATTN_W16_MIN_TILES", 16);
+}
+
 extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
                                   const int32_t* q_gidx, const int32_t* kv_gidx, const int32_t* widx,
                                   const int32_t* patch_start, int num_patches, int num_heads, int max_len, float scale,
@@ -998,12 +1016,16 @@ extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, i
   p.flags = flags | (out16 ? 0 : ATTN_STORE8);
   hipStream_t s = (hipStream_t)stream;
   const unsigned nblocks = make_schedule(p, num_patches, num_heads, max_len, dtype);
-  dim3 grid(nblocks), block(dtype == CDSEG_BF16 ? BF_THREADS : ATTN_THREADS);
+  // 16-bit kernel, at most one block per CU and at least 16 query tiles per block: the 16-wave block shape
+  const bool wide16 = dtype == CDSEG_BF16 && attention_wide16(p, nblocks, max_len);
+  dim3 grid(nblocks), block(dtype == CDSEG_BF16 ? (wide16 ? 64 * BF_WAVES_WIDE : BF_THREADS) : ATTN_THREADS);
   static std::once_flag attr_once;
   static bool attr_ok = false;
   std::call_once(attr_once, [] {
-    attr_ok = hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BF16) ==
-                  hipSuccess &&
+    attr_ok = hipFuncSetAttribute((const void*)attn_bf16_kernel<BF_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SMEM_BF16) == hipSuccess &&
+              hipFuncSetAttribute((const void*)attn_bf16_kernel<BF_WAVES_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SMEM_BF16) == hipSuccess &&
               hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F32) ==
                   hipSuccess &&
               hipFuncSetAttribute((const void*)attn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_X3) ==
@@ -1013,7 +1035,8 @@ extern "C" int cdseg_attention_ex(const void* q, const void* k, const void* v, i
   CdsegProfToken tok;
   const bool prof = cdseg_prof_begin(CDSEG_PROF_ATTENTION, s, &tok);
   if (dtype == CDSEG_BF16) {
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, block, SMEM_BF16, s, p);
+    if (wide16) hipLaunchKernelGGL(attn_bf16_kernel<BF_WAVES_WIDE>, grid, block, SMEM_BF16, s, p);
+    else hipLaunchKernelGGL(attn_bf16_kernel<BF_WAVES>, grid, block, SMEM_BF16, s, p);
   } else if (dtype == CDSEG_F32X3) {
     hipLaunchKernelGGL(attn_x3_kernel, grid, dim3(X3_THREADS), SMEM_X3, s, p);
   } else {

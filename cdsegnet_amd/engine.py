@@ -56,6 +56,16 @@ def _shared(cache, key, build):
     return ent[0]
 
 
+def _cut(lazy, cache, key):
+    """Native plan: the item `key` lives in the plan's arena and its view has not been cut yet - do it now (off the plan
+    phase's critical path: the host is ahead of the device once the Blocks are being issued)."""
+    lz = lazy.pop(key, None)
+    if lz is not None:
+        sid, parts = lz
+        vals = tuple(A[o:o + c] if shape is None else A[o:o + c].view(shape) for A, o, c, shape in parts)
+        cache[key] = (vals[0] if len(vals) == 1 else vals, sid, None)
+
+
 FUSED_CURVE_SORT = True  # the level-0 orders of all curves in use from ONE sort (False: one sort per curve; tools A/B)
 
 class Level:
@@ -74,11 +84,15 @@ class Level:
         # are cut on first use (a model touches ~20 of the ~110)
         self._pad_lazy = {}
         self._slot_lazy = {}
+        self._order_lazy = {}
+        self._nbr_lazy = {}
 
     def order(self, curve):
         """rank -> physical row for a curve (None = identity for z)."""
         if curve == 0:
             return None
+        if self._order_lazy:
+            _cut(self._order_lazy, self._order, curve)
 
         def build():
             nb = len(self.offs_host) - 1
@@ -89,6 +103,9 @@ class Level:
     def nbr(self, ksize, kmajor=False):
         # offset-major tables: a wave searches one offset of 64 consecutive z-ordered points (same cache lines);
         # an open-addressing hash table was measured and is NOT faster (two dependent random reads per lookup)
+        if self._nbr_lazy:
+            _cut(self._nbr_lazy, self._nbr, (ksize, kmajor))
+
         def build():
             if self.parent is not None:  # derive from the parent level's 3x3x3 map: ~3 cached reads per lookup
                 par, (cluster, seg) = self.parent
@@ -99,6 +116,9 @@ class Level:
 
     def child_info(self):
         """Per parent cell of this level's points: first child row + octant occupancy (the stem kernel's traversal)."""
+        if self._nbr_lazy:
+            _cut(self._nbr_lazy, self._nbr, "child_info")
+
         def build():
             par, (_, seg) = self.parent
             return ops.child_info(self.code4[0], seg, par.n)
@@ -161,6 +181,7 @@ class Plan:
         self.levels = {}
         self.links = {}
         self._finish = None  # Engine.build_plan(defer_pads=True): the padding / slot plans, not built yet
+        self._link_lazy = {}
 
     def finish_pads(self):
         """Build the deferred padding / slot plans (no-op when build_plan already did).  Called on the stream the plan was
@@ -171,6 +192,9 @@ class Plan:
 
     def link(self, a, b):
         """fine level a -> coarse level b: (cluster (n_a) int32, seg_start (n_b + 1) int32)."""
+        if self._link_lazy:
+            _cut(self._link_lazy, self.links, (a, b))
+
         def build():
             la, lb = self.levels[a], self.levels[b]
             if a > 0 and (0, a) in self.links and (0, b) in self.links:  # two gathers instead of a flag/scan pass
@@ -253,6 +277,7 @@ class Engine:
         self._pad_keys = None
         self.native_plan = True  # build_plan through cdseg_plan_begin / cdseg_plan_finish (False: one binding call per step; tools A/B)
         self._plan_specs = {}
+        self._tb_cache = {}  # timestep -> per-Block bias vectors (_t_bias)
         self.eager_kernel_maps = True  # kernel maps of all levels built inside build_plan (False: at first use; tools A/B)
         self._side = {}
         # dominant-branch encoder stage at which the noise-branch encoder is forked onto its side stream (None: serial).  2 (round
@@ -463,6 +488,7 @@ class Engine:
                 # shape: one launch on the streamed-weight kernel (csrc/deep.hip) instead of three GEMMs + their second passes
                 _, w["x.tail_img"] = ops.block_rr_pack(cb.q_channels, None, None, w["x.proj.w"], w["x.fc1.w"], w["x.fc2.w"])
         self.w = w
+        self._tb_cache = {}
         if T == torch.float16:
             # IEEE half ends at 65504 and torch's cast does not saturate (the kernels' own float -> half conversions do): a weight
             # beyond the range would enter every product as inf.  One reduction over the cast weights, one host read
@@ -676,24 +702,23 @@ class Engine:
             plan.links[(0, cum)] = ((cl_all[i], seg_all[i]), sid, None)
         for a, b in links:
             clo, sgo = next(it), next(it)
-            plan.links[(all_cum[a], all_cum[b])] = ((f32[clo:clo + sizes[a]], f32[sgo:sgo + sizes[b] + 1]), sid, None)
+            plan._link_lazy[(all_cum[a], all_cum[b])] = (sid, ((f32, clo, sizes[a], None), (f32, sgo, sizes[b] + 1, None)))
         for i in range(nlev):
             if all_cum[i + 1] - all_cum[i] == 1:
-                levels[i].parent = (levels[i + 1], plan.links[(all_cum[i], all_cum[i + 1])][0])
+                levels[i].parent = (levels[i + 1], plan.link(all_cum[i], all_cum[i + 1]))
         for i, lv in enumerate(levels):
-            o = next(it)
-            lv._nbr[(3, True)] = (f32[o:o + 27 * sizes[i]].view(27, sizes[i]), sid, None)
+            lv._nbr_lazy[(3, True)] = (sid, ((f32, next(it), 27 * sizes[i], (27, sizes[i])),))
         for i, lv in enumerate(levels):
             o = next(it)
             if o >= 0:
-                lv._nbr["child_info"] = (f64[o:o + sizes[i + 1]], sid, None)
+                lv._nbr_lazy["child_info"] = (sid, ((f64, o, sizes[i + 1], None),))
         pos = next(it)
         nc = len(used)
         for k, c in enumerate(used):
             lv0._order[c] = (orders0[k], sid, None)
         for i in range(1, nlev + 1):
             for k, c in enumerate(used):
-                levels[i]._order[c] = (f32[pos + k * sizes[i]:pos + (k + 1) * sizes[i]], sid, None)
+                levels[i]._order_lazy[c] = (sid, ((f32, pos + k * sizes[i], sizes[i], None),))
             pos += nc * sizes[i]
         q = 5
         per = []
@@ -1415,10 +1440,18 @@ class Engine:
         w = self.w
         if self.model.backbone.T_dim == -1 or "t.table" not in w:
             return {}
-        v = ops.gemv(w["t.fc1.w"], w["t.fc1.b"], w["t.table"][t + 1], ops.ACT_SWISH)  # table row 0 is t = -1
-        v = ops.gemv(w["t.fc2.w"], w["t.fc2.b"], v, ops.ACT_SWISH)
-        tall = ops.gemv(w["t.mlp.w"], w["t.mlp.b"], v, ops.ACT_NONE)
-        return {k: tall[a:b] for k, (a, b) in self.t_slices.items()}
+        # a function of the weights and t alone (every point of a forward has the same t; single-step inference always
+        # t = T - 1): computed once per (engine, t) - the engine is rebuilt when the weights change - and kept.  The first
+        # computation is waited for, so later forwards on other streams read finished values
+        ent = self._tb_cache.get(t)
+        if ent is None:
+            v = ops.gemv(w["t.fc1.w"], w["t.fc1.b"], w["t.table"][t + 1], ops.ACT_SWISH)  # table row 0 is t = -1
+            v = ops.gemv(w["t.fc2.w"], w["t.fc2.b"], v, ops.ACT_SWISH)
+            tall = ops.gemv(w["t.mlp.w"], w["t.mlp.b"], v, ops.ACT_NONE)
+            if tall.is_cuda:
+                torch.cuda.current_stream(tall.device).synchronize()
+            ent = self._tb_cache[t] = {k: tall[a:b] for k, (a, b) in self.t_slices.items()}
+        return ent
 
     def _sat_begin(self, dev):
         """Start of a forward: arm the saturation diagnostic (IEEE-half trunks only)."""

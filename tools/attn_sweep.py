@@ -117,6 +117,8 @@ for shape in args.shapes.split(";"):
         os.environ.pop("CDSEG_ATTN_QSPLIT", None)
         if len(kn) > 3 and kn[3] > 0:  # 4th value: uniform query split (0 = the library's own choice)
             os.environ["CDSEG_ATTN_QSPLIT"] = str(kn[3])
+        os.environ["CDSEG_ATTN_W16"] = str(kn[4]) if len(kn) > 4 else "1"  # 5th: 16-wave blocks for one-block-per-CU launches
+        os.environ["CDSEG_ATTN_W16_MIN_TILES"] = str(kn[5]) if len(kn) > 5 else "16"  # 6th: fewest query tiles per block for it
 
     set_knobs(configs[0][3])
     for _ in range(30):  # the chip settles on its sustained clock
