@@ -765,8 +765,14 @@ def main():
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tpath)} (offline rocprofv3 --pmc passes over bench.py's own forwards)"
                 # the counters belong to the build they were taken on: stale once the kernel's source is newer than the file
+                # (by content hash when the profile carries one - file times do not survive a checkout -, else by file time)
                 src = os.path.join(ROOT, "cdsegnet_amd", "csrc", "attention.hip")
-                res["roofline"]["traffic_stale"] = bool(os.path.getmtime(src) > os.path.getmtime(tpath))
+                if tj.get("attention_hip_sha256"):
+                    import hashlib
+                    with open(src, "rb") as f:
+                        res["roofline"]["traffic_stale"] = hashlib.sha256(f.read()).hexdigest() != tj["attention_hip_sha256"]
+                else:
+                    res["roofline"]["traffic_stale"] = bool(os.path.getmtime(src) > os.path.getmtime(tpath))
         if iso and "latency_ms" in iso:
             # the headline block a reader should see first: `value` needs this build's own `inference_many` (8 scenes collated
             # per forward, 3 forwards in flight) and the offset_host hint; the REFERENCE's loop (tools/test_*.py unchanged, one

@@ -10,7 +10,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   tail -2 /tmp/pmcb_$ctr.log | cut -c1-300
 done
 python3 - "$out" <<'PY'
-import csv, glob, json, sys, collections  # noqa: E401
+import csv, glob, hashlib, json, os, sys, collections  # noqa: E401
 out = sys.argv[1]
 tot = {}
 by_grid = {}  # attention launches by grid size (= by stage shape): counter -> grid -> [sum, launches]
@@ -44,6 +44,10 @@ res["attention_by_grid"] = {
              "read_MB_per_launch": 2 * by_grid["FETCH_SIZE"][g][0] / by_grid["FETCH_SIZE"][g][1] * 1024 / 1e6,
              "write_MB_per_launch": by_grid.get("WRITE_SIZE", {}).get(g, [0.0, 1])[0] / max(1, by_grid.get("WRITE_SIZE", {}).get(g, [0.0, 1])[1]) * 1024 / 1e6}
     for g in sorted(by_grid.get("FETCH_SIZE", {}))}
+# the counters belong to the kernel source they were taken on: bench.py marks them stale when attention.hip has changed since
+src = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "cdsegnet_amd", "csrc", "attention.hip")
+if os.path.exists(src):
+    res["attention_hip_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
 json.dump(res, open(out, "w"), indent=1)
 for g, v in res["attention_by_grid"].items():
     print(f"attention grid {g:>9s} threads: launches {v['launches']:3d}  read {v['read_MB_per_launch']:8.2f} MB  write {v['write_MB_per_launch']:8.2f} MB per launch")
