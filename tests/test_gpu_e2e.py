@@ -712,6 +712,14 @@ def test_degenerate_scenes_vs_oracle(kind, flash):
     out = run(model, inp, draws)
     err, agree = report(f"degenerate {kind} flash={flash} fp32 vs oracle", out, ref)
     assert out.shape == ref.shape and err < 1e-3
+    # the engine's first forward takes the exact serialization depth through the per-op plan; the second one speculates and
+    # goes through the native plan builder (csrc/plan.hip): the same logits, bit for bit, at the smallest sizes too
+    assert getattr(model.engine().last_plan, "native", None) is None
+    again = run(model, inp, draws)
+    eng = model.engine()  # (a scene shallower than the pooling pyramid - one_point - is outside the native builder's spec)
+    assert (getattr(eng.last_plan, "native", None) is not None) == any(v is not None for v in eng._plan_specs.values())
+    assert (kind == "one_point") == (getattr(eng.last_plan, "native", None) is None)
+    assert np.array_equal(out, again)
     model.precision = "bf16"
     o16 = run(model, inp, draws)
     assert np.isfinite(o16).all() and np.abs(o16 - ref).max() < 0.06
@@ -1001,7 +1009,8 @@ def _plan_items(plan, pad_keys, curves):
     return out
 
 
-@pytest.mark.parametrize("case", ["single_120k", "two_scenes", "eight_sweeps", "tiny", "flash_off"])
+@pytest.mark.parametrize("case", ["single_120k", "two_scenes", "eight_sweeps", "tiny", "flash_off", "one_point", "seven_and_many",
+                                  "collapses_early"])
 def test_native_plan_equals_per_op_plan(case):
     """Round 6: build_plan through the native builder (cdseg_plan_begin / cdseg_plan_finish, csrc/plan.hip: two library calls,
     two arenas) against the per-op path (one binding call per kernel) - every item of the plan bit for bit: sorted order,
@@ -1027,13 +1036,21 @@ def test_native_plan_equals_per_op_plan(case):
         scs = [synth.lidar_scene(i, 20000) for i in range(8)]
     elif case == "tiny":
         scs = [synth.room_scene(3, 600)]
-    else:
+    elif case == "flash_off":
         scs = [synth.room_scene(4, 9000), synth.room_scene(5, 2500)]
-    grid = torch.as_tensor(np.concatenate([s["grid_coord"] for s in scs])).cuda()
-    offs, tot = [], 0
-    for s in scs:
-        tot += len(s["grid_coord"])
-        offs.append(tot)
+    else:  # the degenerate inputs of test_degenerate_scenes_vs_oracle
+        scs = None
+    if scs is None:
+        ti = tiny_inputs(case)
+        grid = torch.as_tensor(np.asarray(ti["grid_coord"])).cuda()
+        offs = [int(v) for v in np.asarray(ti["offset"])]
+        tot = offs[-1]
+    else:
+        grid = torch.as_tensor(np.concatenate([s["grid_coord"] for s in scs])).cuda()
+        offs, tot = [], 0
+        for s in scs:
+            tot += len(s["grid_coord"])
+            offs.append(tot)
     offset = torch.tensor(offs, dtype=torch.int64).cuda()
     eng = model.engine()
     eng.prepare(grid.device)
@@ -1047,7 +1064,9 @@ def test_native_plan_equals_per_op_plan(case):
             # (the first call of an engine takes the exact depth through the per-op path; the second one speculates)
             for _ in range(2):
                 plan = eng.build_plan(grid, offset, offs, tot)
-            assert (getattr(plan, "native", None) is not None) == native
+            went_native = getattr(plan, "native", None) is not None
+            # (one_point: a scene shallower than the pooling pyramid is outside the native builder's spec: per-op path both times)
+            assert went_native == (native and case != "one_point")
             plans[native] = _plan_items(plan, eng._pad_keys, curves)
             torch.cuda.synchronize()
     finally:
