@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--no-agreement", action="store_true", help="skip the 16-bit-vs-fp32 agreement leg")
     ap.add_argument("--no-paper-pass", action="store_true",
                     help="skip the separate `--protocol paper` process whose result the default line carries as paper_protocol.own_process")
-    ap.add_argument("--scenes-per-forward", type=int, default=8,
+    ap.add_argument("--scenes-per-forward", type=int, default=24,
                     help="scenes collated into one forward (the reference's collate_fn batching); one step = "
                          "scenes-per-forward x lanes scenes (one batch per lane)")
     ap.add_argument("--lanes", type=int, default=3,
@@ -466,6 +466,25 @@ def main():
     elapsed = time.perf_counter() - t0
     last = out[-1]["seg_logits"]
     assert torch.isfinite(last).all()
+    # rounds 1 - 5 timed 8 scenes per forward x 3 lanes (24 scenes per step); round 6 collates 24 per forward (the deep stages'
+    # launches are three times as full, profiles/r06_lanes_sweep.txt).  The old setting on this step's first 24 scenes, right
+    # after the timed region, so that the line stays comparable with the earlier rounds' `value`
+    r5cfg = None
+    if rank == 0 and world == 1 and (args.scenes_per_forward, args.lanes) != (8, 3) and len(dicts) >= 24:
+        sub24 = dicts[:24]
+        k5 = max(3, args.steps // 2)
+        for _ in range(2):
+            model.inference_many([dict(d) for d in sub24], lanes=3, batch=8)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(k5):
+            model.inference_many([dict(d) for d in sub24], lanes=3, batch=8)
+        torch.cuda.synchronize()
+        e5 = time.perf_counter() - t5
+        r5cfg = {"points_per_s": float(sum(sizes[:24])) * k5 / e5, "ms_per_step": 1e3 * e5 / k5, "steps": k5,
+                 "scenes_per_forward": 8, "forwards_in_flight_per_gpu": 3, "scenes_per_step": 24,
+                 "what": "the configuration rounds 1 - 5 quoted `value` on (8 scenes collated per forward, 3 forwards in flight), "
+                         "the first 24 scenes of this step, timed right after the headline region"}
 
     # ---- kernel-level pass (rank 0): the SAME forward the timed region issues (first lane's 8 collated scenes), one
     # forward at a time, HIP events around every attention / sparse-conv launch on the launch stream.  Inside the timed
@@ -542,8 +561,8 @@ def main():
             lat.append(1e3 * (time.perf_counter() - t1))
         iso["latency_ms"] = float(np.median(lat))
         iso["latency_points"] = sizes[0]
-        # the reference's timing protocol on this step's 24 distinct scenes (tools/test_time.py: one scene at a time, wall
-        # clock): 13 passes = 312 inferences, the ScanNet val split's scene count.  `--protocol paper` runs 312 DISTINCT scenes.
+        # the reference's timing protocol on this step's distinct scenes (tools/test_time.py: one scene at a time, wall
+        # clock): 312 inferences, the ScanNet val split's scene count.  `--protocol paper` runs 312 DISTINCT scenes.
         # The dicts handed over are the REFERENCE's (coord, grid_coord, feat, offset - no offset_host hint): every host
         # read of the call is inside the clock, as in `--protocol paper`.
         ref_dicts = [{k: v for k, v in d.items() if k != "offset_host"} for d in dicts]
@@ -552,9 +571,8 @@ def main():
             model.inference(dict(d), eval=False)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(13):
-            for d in ref_dicts:
-                model.inference(dict(d), eval=False)
+        for i in range(312):  # (the step's distinct scenes, cycled)
+            model.inference(dict(ref_dicts[i % len(ref_dicts)]), eval=False)
         torch.cuda.synchronize()
         iso["paper_s"] = time.perf_counter() - t1
         # IEEE-half trunk: one diagnostic forward that counts the activations clamped at +-65504 (engine.count_saturation)
@@ -588,21 +606,22 @@ def main():
         model.noise_source = "device"
     parity_mode = None
     if rank == 0 and low and not args.no_agreement:
-        # throughput of the exact-fp32 mode (the only one inside north_star's 1e-3 logit bound): 4 collated scenes per
-        # forward, one lane, the same scene generator
+        # throughput of the exact-fp32 mode (inside north_star's 1e-3 logit bound): 8 collated scenes per forward, two
+        # forwards in flight (round 6; 4 x 1 before: 9.3 -> 10.9 M points/s, gpurun_out/r06ae_fp32_sweep.txt), the same scenes
         model.precision = "fp32"
         try:
-            sub = [dict(d) for d in dicts[:4]]
+            nf = min(16, len(dicts))
+            sub = [dict(d) for d in dicts[:nf]]
             for _ in range(2):
-                model.inference_many([dict(d) for d in sub], lanes=1, batch=4)
+                model.inference_many([dict(d) for d in sub], lanes=2, batch=8)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(3):
-                model.inference_many([dict(d) for d in sub], lanes=1, batch=4)
+                model.inference_many([dict(d) for d in sub], lanes=2, batch=8)
             torch.cuda.synchronize()
             el32 = (time.perf_counter() - t1) / 3
-            parity_mode = dict(precision="fp32", points_per_s=float(sum(sizes[:4]) / el32), ms_per_forward=1e3 * el32,
-                               scenes_per_forward=4,
+            parity_mode = dict(precision="fp32", points_per_s=float(sum(sizes[:nf]) / el32), ms_per_step=1e3 * el32,
+                               scenes_per_forward=8, forwards_in_flight=2,
                                note="exact-fp32 MFMA path (v_mfma_f32_16x16x4_f32): within 6e-6 of the reference's CPU logits on the "
                                     "golden fixtures (tests/test_gpu_e2e.py); the 16-bit trunk of the headline line is the IEEE-half build")
             # ... and of "fp32x3" (round 6): the same fp32 engine with every matrix product as three IEEE-half MFMAs on split
@@ -773,6 +792,8 @@ def main():
                         res["roofline"]["traffic_stale"] = hashlib.sha256(f.read()).hexdigest() != tj["attention_hip_sha256"]
                 else:
                     res["roofline"]["traffic_stale"] = bool(os.path.getmtime(src) > os.path.getmtime(tpath))
+        if r5cfg is not None:
+            res["value_at_round5_config"] = r5cfg
         if iso and "latency_ms" in iso:
             # the headline block a reader should see first: `value` needs this build's own `inference_many` (8 scenes collated
             # per forward, 3 forwards in flight) and the offset_host hint; the REFERENCE's loop (tools/test_*.py unchanged, one
@@ -780,7 +801,7 @@ def main():
             own = res.get("paper_protocol", {}).get("own_process", {})
             res["headline"] = {
                 "value_points_per_s": res["value"],
-                "value_needs": "DefaultSegmentorV2.inference_many(batch=8, lanes=3) + the offset_host key (INTEGRATION.md)",
+                "value_needs": f"DefaultSegmentorV2.inference_many(batch={args.scenes_per_forward}, lanes={args.lanes}) + the offset_host key (INTEGRATION.md)",
                 "bs1_ms_per_scene": own.get("ms_per_scene", 1e3 * iso["paper_s"] / 312.0),
                 "bs1_points_per_s": own.get("points_per_s", pts_per_step / scenes_per_step * 312.0 / iso["paper_s"]),
                 "bs1_what": "the reference's calling pattern: one inference(dict) per scene, the reference's dict, every host "

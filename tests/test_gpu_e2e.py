@@ -291,6 +291,49 @@ def test_nuscenes_eight_sweeps_collated_vs_oracle():
     assert np.isfinite(d16).all() and err < 0.06 and agree > 0.985  # measured 1.9e-2 / 99.99 %
 
 
+def test_twenty_four_scenes_collated_vs_oracle():
+    """The benchmark's forward shape since round 6: TWENTY-FOUR ragged ScanNet-shape scenes collated into one forward (5 batch
+    bits in every code, per-element patches, pooled levels of 24 elements), full-width model, shipped enable_flash=True.
+    (a) fp32 vs the oracle on the collated batch, twice (the second forward goes through the native plan builder); (b)
+    inference_many(batch=24, lanes=2) on 48 scenes returns exactly the slices of the two collated forwards; (c) the default
+    16-bit precision stays inside its bounds."""
+    from cdsegnet_amd.models import collate_device
+    cfg = configs.cdsegnet_config("scannet")
+    model = build_model(cfg)
+    sd = fill_state_dict(model.state_dict(), seed=21)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    scenes = [synth.room_scene(300 + i, 260 + 37 * (i % 7) + (900 if i == 5 else 0)) for i in range(48)]
+    both = synth.collate(scenes[:24])
+    n = len(both["coord"])
+    assert len(both["offset"]) == 24
+    inp = {k: both[k] for k in ("coord", "grid_coord", "feat", "offset")}
+    draws = OM.draw_rng(56, n, cfg["c_in_channels"])
+    ref = OM.inference(cfg["backbone"], sd, inp, draws, T=cfg["T"], flash_semantics=True).numpy()
+    model.precision = "fp32"
+    logits = run(model, inp, draws)
+    err, agree = report("24 scenes collated, full width fp32 vs oracle", logits, ref)
+    assert logits.shape == (n, 20) and err < 1e-3 and agree > 0.999
+    again = run(model, inp, draws)
+    assert getattr(model.engine().last_plan, "native", None) is not None and np.array_equal(again, logits)
+    dicts = [to_dev({k: s[k] for k in ("coord", "grid_coord", "feat", "offset")}) for s in scenes]
+    torch.manual_seed(8)
+    want = [model.inference(dict(collate_device([dict(d) for d in g])), eval=False)["seg_logits"] for g in (dicts[:24], dicts[24:])]
+    torch.manual_seed(8)
+    got = model.inference_many([dict(d) for d in dicts], lanes=2, batch=24)
+    torch.cuda.synchronize()
+    for g, w in zip((0, 24), want):
+        pos = 0
+        for d, o in zip(dicts[g:g + 24], got[g:g + 24]):
+            m = d["feat"].shape[0]
+            assert torch.equal(o["seg_logits"], w[pos:pos + m])
+            pos += m
+    model.precision = "fp16+head"
+    d16 = run(model, inp, draws)
+    err, agree = report("24 scenes collated, fp16+head vs oracle", d16, ref)
+    assert np.isfinite(d16).all() and err < 0.012 and agree > 0.99
+
+
 def test_device_noise_is_reproducible_under_reseed():
     """noise_source="device": the Philox stream ids are drawn from torch's CPU generator, so torch.manual_seed(s)
     followed by the same calls reproduces the logits whatever ran before (advisor finding, round 1)."""
