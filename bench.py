@@ -470,7 +470,8 @@ def main():
     # launches are three times as full, profiles/r06_lanes_sweep.txt).  The old setting on this step's first 24 scenes, right
     # after the timed region, so that the line stays comparable with the earlier rounds' `value`
     r5cfg = None
-    if rank == 0 and world == 1 and (args.scenes_per_forward, args.lanes) != (8, 3) and len(dicts) >= 24:
+    if (rank == 0 and world == 1 and (args.scenes_per_forward, args.lanes) != (8, 3) and len(dicts) >= 24
+            and not args.no_kernel_timer):  # (profiling / A-B runs pass --no-kernel-timer: the timed configuration only)
         sub24 = dicts[:24]
         k5 = max(3, args.steps // 2)
         for _ in range(2):

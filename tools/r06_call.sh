@@ -1,17 +1,15 @@
+# round 6, GPU call AH: the kernel traces again (the validation run's traces included the round-5-setting leg)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-O=gpurun_out/r06af
-t0=$SECONDS
-( timeout 900 python bench.py ) > ${O}_bench.json 2> ${O}_bench.err
-echo "bench.py took $((SECONDS - t0)) s"
-python3 -c "
-import json
-d=json.loads(open('${O}_bench.json').read().strip().splitlines()[-1])
-print('e2e', round(d['value']/1e6,2), 'M; ms/step', round(d['ms_per_step'],2), 'attn frac', round(d['roofline']['frac'],4), 'bs1', d['headline']['bs1_ms_per_scene'], 'host_issue', d['host_issue']['host_issue_ms_per_forward'], 'fwd alone', d['roofline_forward']['wall_ms'], 'single', d['single_scene_latency_ms'])
-print('r5cfg', d.get('value_at_round5_config'))
-print('parity', {k: (v if not isinstance(v, dict) else {a: b for a, b in v.items() if a != 'note'}) for k, v in d['parity_mode'].items() if k != 'note'})
-print('bf16', d['bf16_head']['points_per_s'], 'paper', d['paper_protocol']['seconds_for_312_scenes'], d['paper_protocol'].get('own_process'))
-print('conv', d['roofline_conv']['frac'], d['roofline_conv']['avg_launch_us'], 'deep', d['roofline_conv_deep']['frac'], d['roofline_conv_deep']['avg_launch_us'], 'stale', d['roofline'].get('traffic_stale'))
-"
-tail -2 ${O}_bench.err
+cd /tmp && export TMPDIR=/tmp
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_final -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-agreement --no-kernel-timer --no-paper-pass > gpurun_out/r06i_bench_under_rocprof.json 2> gpurun_out/r06i_prof.err )
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_final_l1 -o run -- python bench.py --scenes-per-forward 8 --lanes 1 --serial --steps 6 --warmup 2 --no-cpu-baseline --no-agreement --no-kernel-timer --no-paper-pass > gpurun_out/r06i_bench_lanes1.json 2>> gpurun_out/r06i_prof.err )
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_final_l1b -o run -- python bench.py --lanes 1 --serial --steps 4 --warmup 2 --no-cpu-baseline --no-agreement --no-kernel-timer --no-paper-pass > gpurun_out/r06i_bench_lanes1_24.json 2>> gpurun_out/r06i_prof.err )
+cd $GRAFT_REPO_ROOT
+DB=$(find /tmp/prof_final -name "*.db" | head -1); python tools/prof_summary.py $DB 6 > gpurun_out/r06i_kernel_stats.txt 2>&1
+DB=$(find /tmp/prof_final_l1 -name "*.db" | head -1); python tools/prof_summary.py $DB 8 > gpurun_out/r06i_lanes1_kernel_stats.txt 2>&1
+DB=$(find /tmp/prof_final_l1b -name "*.db" | head -1); python tools/prof_summary.py $DB 6 > gpurun_out/r06i_lanes1_24_kernel_stats.txt 2>&1
+head -24 gpurun_out/r06i_lanes1_kernel_stats.txt | cut -c1-150
+head -24 gpurun_out/r06i_lanes1_24_kernel_stats.txt | cut -c1-150
+tail -1 gpurun_out/r06i_bench_under_rocprof.json | cut -c1-200
 echo "done at $SECONDS s"
