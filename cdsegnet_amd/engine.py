@@ -650,6 +650,9 @@ class Engine:
         sp, used, curves, links = ent
         nb = len(offset_host)
         grid = grid.contiguous()
+        offset_dev = offset_dev.contiguous()  # (int64, the caller's cumulative offsets: Engine._setup / TrainGraph hand it over so)
+        if offset_dev.dtype != torch.int64:
+            offset_dev = offset_dev.to(torch.int64)
         nlev = sp.nlev
         nmeta = nlev * (1 + nb) + 1
         mt, mnp, _ = self._pin("meta", nmeta)
