@@ -71,9 +71,13 @@ FUSED_CURVE_SORT = True  # the level-0 orders of all curves in use from ONE sort
 class Level:
     """One voxel resolution of the scene, points in (batch | z) sorted order."""
 
-    def __init__(self, cum, depth, n, grid, batch, code4, offs_host):
+    def __init__(self, cum, depth, n, grid, batch, code4, offs_host, lazy=None):
         self.cum, self.depth, self.n = cum, depth, n
-        self.grid, self.batch, self.code4 = grid, batch, code4
+        # grid (n, 3) int32, batch (n) int32, code4 (4, n) int64 - or, for a pooled level of the native plan, `lazy` = (int32
+        # arena, grid offset, batch offset, int64 arena, code offset): the three views are cut when something asks for them (the
+        # inference path never does: kernel maps, orders and slot plans of that level already exist)
+        self._gbc = (grid, batch, code4) if lazy is None else None
+        self._gbc_lazy = lazy
         self.offs_host = offs_host  # (B+1) python ints
         self.parent = None  # (parent Level, (cluster, seg_start)) when the next pooled level is one octree step up
         self._order = {}
@@ -86,6 +90,25 @@ class Level:
         self._slot_lazy = {}
         self._order_lazy = {}
         self._nbr_lazy = {}
+
+    def _cut_gbc(self):
+        A, go, bo, Q, co = self._gbc_lazy
+        n = self.n
+        self._gbc = (A[go:go + 3 * n].view(n, 3), A[bo:bo + n], Q[co:co + 4 * n].view(4, n))
+        self._gbc_lazy = None
+        return self._gbc
+
+    @property
+    def grid(self):
+        return (self._gbc or self._cut_gbc())[0]
+
+    @property
+    def batch(self):
+        return (self._gbc or self._cut_gbc())[1]
+
+    @property
+    def code4(self):
+        return (self._gbc or self._cut_gbc())[2]
 
     def order(self, curve):
         """rank -> physical row for a curve (None = identity for z)."""
@@ -577,7 +600,7 @@ class Engine:
         return out, done
 
     # ------------------------------------------------------------------ plan
-    def _pin(self, name, numel, ring=1):
+    def _pin(self, name, numel, ring=1, dtype=torch.int32):
         """Per host thread: pinned int32 staging buffers (`ring` of them, handed out in turn together with the event that
         guards the buffer's previous use).  Returns (tensor, its numpy view, slot dict)."""
         slots = getattr(self._tls, "pins", None)
@@ -589,7 +612,7 @@ class Engine:
         i = ent["i"] = (ent["i"] + 1) % ring
         slot = ent["bufs"][i]
         if slot is None or slot["t"].numel() < numel:
-            t = torch.empty(max(256, int(numel * 1.5)), dtype=torch.int32, pin_memory=True)
+            t = torch.empty(max(256, int(numel * 1.5)), dtype=dtype, pin_memory=True)
             slot = ent["bufs"][i] = {"t": t, "np": t.numpy(), "ev": None}
         elif slot["ev"] is not None:
             slot["ev"].synchronize()  # (a copy out of this buffer issued `ring` plans ago: long done)
@@ -648,7 +671,7 @@ class Engine:
         a view into one of two arenas per call.  Same items, bit for bit, as the per-op path below
         (tests/test_gpu_ops.py::test_native_plan_equals_per_op_plan)."""
         sp, used, curves, links = ent
-        nb = len(offset_host)
+        nb = len(offset_host) if offset_host is not None else int(offset_dev.numel())
         grid = grid.contiguous()
         offset_dev = offset_dev.contiguous()  # (int64, the caller's cumulative offsets: Engine._setup / TrainGraph hand it over so)
         if offset_dev.dtype != torch.int64:
@@ -657,6 +680,10 @@ class Engine:
         nmeta = nlev * (1 + nb) + 1
         mt, mnp, _ = self._pin("meta", nmeta)
         call = ops.NativePlanCall(sp, grid, offset_dev, n, nb, depth, end_bit, gmax_host, mt)
+        opin = None
+        if offset_host is None:  # the reference's dict carries no host copy of the offsets: they ride along with the one read
+            opin, onp, _ = self._pin("offs", nb, dtype=torch.int64)
+            opin[:nb].copy_(offset_dev, non_blocking=True)
         call.begin(0)
         ev = ops.record_event()
         call.begin(1)  # the level-0 curve sort does not need the pooled sizes: queued before the host waits
@@ -665,6 +692,8 @@ class Engine:
         perm0, grid0, bat0, code0, cl_all, seg_all, orders0 = call.begin_views()
         ev.synchronize()  # the one sync: pooled sizes, duplicate-voxel count, grid maximum
         flat = mnp[:nmeta].tolist()
+        if opin is not None:
+            offset_host = onp[:nb].tolist()
         if gmax_host is not None:
             true_depth = int(gmax_host.item()).bit_length()
             self._depth_hint[grid.device] = true_depth
@@ -698,8 +727,7 @@ class Engine:
         for i in range(nlev):
             go, bo, co = next(it), next(it), next(it)
             mi, cum = m[i], all_cum[i + 1]
-            lv = Level(cum, depth - cum, mi, f32[go:go + 3 * mi].view(mi, 3), f32[bo:bo + mi], f64[co:co + 4 * mi].view(4, mi),
-                       offs_rows[i + 1])
+            lv = Level(cum, depth - cum, mi, None, None, None, offs_rows[i + 1], lazy=(f32, go, bo, f64, co))
             plan.levels[cum] = lv
             levels.append(lv)
             plan.links[(0, cum)] = ((cl_all[i], seg_all[i]), sid, None)
@@ -757,7 +785,7 @@ class Engine:
         arithmetic + one upload + one launch; first needed by the first Block's attention) are left to `plan.finish_pads()`,
         which `backbone` calls once the stem is queued - device work for that stretch of host time."""
         bb = self.model.backbone
-        nb = len(offset_host)
+        nb = len(offset_host) if offset_host is not None else int(offset_dev.numel())
         on_gpu = grid.is_cuda
         hint = self._depth_hint.get(grid.device) if _exact_depth is None else None
         gmax_host = gmax_dev = None
@@ -796,6 +824,8 @@ class Engine:
             if ent is not None:
                 return self._build_plan_native(ent, grid, offset_dev, offset_host, n, depth, end_bit, gmax_host, n_cum, c_cum,
                                                all_cum, while_device_works)
+        if offset_host is None:  # per-op path without the caller's hint: one more host read
+            offset_host = [int(v) for v in offset_dev.cpu().tolist()]
         if gmax_dev is None:
             gmax_dev = ops.grid_max(grid)
             if gmax_host is not None:
@@ -1410,8 +1440,9 @@ class Engine:
         grid = input_dict["grid_coord"]
         offset = input_dict["offset"]
         n = feat.shape[0]
-        offset_host = input_dict["offset_host"] if "offset_host" in input_dict else offset.cpu().tolist()
-        offset_host = [int(v) for v in offset_host]
+        # (no hint - the reference's dict -: the native plan builder brings the offsets to the host with the pooled sizes, the
+        # per-op path reads them itself; either way no read of its own up here)
+        offset_host = [int(v) for v in input_dict["offset_host"]] if "offset_host" in input_dict else None
         cond = bb.condition
         c_ch = m.c_in_channels
         per_call = (2 + len(bb.c_stride) + len(bb.n_stride)) if cond else (1 + len(bb.n_stride))
