@@ -693,7 +693,9 @@ def main():
                                            "--precision bf16+head runs the bfloat16 build; parity_mode = the exact-fp32 path",
                        "host_hints": ["offset_host"],
                        "host_hints_note": "the scene dicts carry offset_host (the batch offsets as Python ints) next to the "
-                                          "reference's keys: saves the engine one device->host read per forward"},
+                                          "reference's keys: collating resident scenes into one forward (models.collate_device) "
+                                          "then needs no device->host read per scene; the engine itself has not needed the hint "
+                                          "since round 6 (the offsets come to the host with the forward's one read)"},
         }
         if iso and iso["attn_ms"] > 0:
             peak = PEAK_TFLOPS[args.precision]
