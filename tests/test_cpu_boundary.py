@@ -183,3 +183,120 @@ def test_criteria_reproduce_the_reference_loss_parts():
     import pytest
     with pytest.raises(NotImplementedError):
         build_criteria([dict(type="BinaryFocalLoss")])
+
+
+def _shipped_plan_spec():
+    """The cdseg_plan_spec of the shipped CDSegNet configs (5 n-stages of stride 2, 3 c-stages of stride 4, four curves, one
+    padding key) - what Engine._native_spec builds; spelled out here so that the test does not need an engine."""
+    sp = _lib.PlanSpec()
+    sp.nlev = 4
+    for i, c in enumerate((0, 1, 2, 3, 4)):
+        sp.cum[i] = c
+    sp.ncurve = 3
+    for i, c in enumerate((1, 2, 3)):
+        sp.curve_rows[i] = c
+    sp.nslot_curve = 4
+    for i, c in enumerate((-1, 0, 1, 2)):
+        sp.slot_curve[i] = c
+    links = [(1, 2), (2, 3), (2, 4), (3, 4)]
+    sp.nlink = len(links)
+    for i, (a, b) in enumerate(links):
+        sp.link_a[i], sp.link_b[i] = a, b
+    sp.npad = 2
+    for i, (ps, fl) in enumerate(((1024, 1), (16, 0))):
+        sp.pad_patch[i], sp.pad_flash[i] = ps, fl
+    return sp, links
+
+
+def test_native_plan_layouts_are_consistent_with_the_python_padding_arithmetic(lib):
+    """Round 6: cdseg_plan_begin_layout / cdseg_plan_finish_layout are host-only - arena layouts (every item on a 256-byte
+    boundary, no overlap, inside the totals) and the padding plans' statistics (K, padded length, patches, longest patch, sum
+    of squared patch lengths), which the C side computes itself, against engine.Level.pad_host_py (ref: ptv3.py:188-250) on
+    random ragged batches incl. elements below a patch and enable_flash = False."""
+    import random
+    import struct
+    from cdsegnet_amd.engine import Level
+    sp, links = _shipped_plan_spec()
+    rnd = random.Random(7)
+    for trial in range(60):
+        nb = rnd.choice([1, 1, 2, 3, 8, 24])
+        # pooled sizes: every level keeps at least one point per batch element and never grows
+        offs = [[0]]
+        for b in range(nb):
+            offs[0].append(offs[0][-1] + rnd.choice([1, 7, 40, 1023, 1024, 1025, 5000, rnd.randint(1, 140000)]))
+        for lvl in range(1, 5):
+            row = [0]
+            for b in range(nb):
+                c = offs[-1][b + 1] - offs[-1][b]
+                row.append(row[-1] + max(1, c // rnd.choice([1, 2, 3, 5])))
+            offs.append(row)
+        n = offs[0][-1]
+        m = [offs[l][-1] for l in range(1, 5)]
+        off_b, tot_b = (ctypes.c_long * 13)(), (ctypes.c_long * 3)()
+        assert lib.cdseg_plan_begin_layout(ctypes.byref(sp), n, nb, off_b, tot_b) == 0
+        sizes_b = [n, n, 3 * n, n, nb, 4 * n, 4 * (n + 1), 4 * (1 + nb) + 1, 3 * n, 1, n, n, 4 * n]
+        for arena, idx in ((0, range(0, 9)), (1, range(9, 13))):
+            spans = sorted((off_b[i], off_b[i] + sizes_b[i]) for i in idx)
+            assert all(a % (64 if arena == 0 else 32) == 0 for a, _ in spans)
+            assert all(e <= s2 for (_, e), (s2, _) in zip(spans[:-1], spans[1:])) and spans[-1][1] <= tot_b[arena]
+        mh = (ctypes.c_long * 4)(*m)
+        flat = [v for r in offs for v in r]
+        oh = (ctypes.c_int * len(flat))(*flat)
+        n_off = 3 * 4 + 2 * len(links) + 2 * 5 + 1 + 3 * 5 * 2 + 2
+        off_f, info = (ctypes.c_long * n_off)(), (ctypes.c_long * (5 + 5 * 5 * 2))()
+        assert lib.cdseg_plan_finish_layout(ctypes.byref(sp), n, nb, mh, oh, off_f, info) == 0
+        sizes = [n] + m
+        spans32, spans64 = [], []
+        it = iter(off_f)
+        for l in range(1, 5):
+            spans32 += [(next(it), 3 * sizes[l]), (next(it), sizes[l])]
+            spans64.append((next(it), 4 * sizes[l]))
+        for a, b in links:
+            spans32 += [(next(it), sizes[a]), (next(it), sizes[b] + 1)]
+        for l in range(5):
+            spans32.append((next(it), 27 * sizes[l]))
+        for l in range(5):
+            o = next(it)
+            assert (o >= 0) == (l < 4)
+            if o >= 0:
+                spans64.append((o, sizes[l + 1]))
+        spans32.append((next(it), 3 * sum(m)))
+        q, total_slots, pads_lo = 5, 0, None
+        for l in range(5):
+            lv = Level(l, 10 - l, sizes[l], None, None, None, offs[l])
+            for ps, fl in ((1024, True), (16, False)):
+                oo, op, ot = next(it), next(it), next(it)
+                K, offs_l, offs_pad, patch_start = lv.pad_host_py(ps, fl)
+                lens = [b - a for a, b in zip(patch_start[:-1], patch_start[1:])]
+                want = (K, offs_pad[-1], len(patch_start) - 1, max(lens), float(sum(v * v for v in lens)))
+                got = tuple(info[q:q + 4]) + (struct.unpack("d", struct.pack("q", info[q + 4]))[0],)
+                assert got == want, (trial, l, ps, fl, got, want)
+                q += 5
+                assert op == oo + nb + 1 and ot == op + nb + 1
+                pads_lo = oo if pads_lo is None else pads_lo
+                total_slots += 4 * offs_pad[-1]
+        assert pads_lo == info[4]
+        spans32.append((info[4], info[3]))
+        g, w = next(it), next(it)
+        spans32 += [(g, total_slots), (w, total_slots)]
+        for spans, al, tot in ((spans32, 64, info[0]), (spans64, 32, info[1])):
+            spans = sorted((o, o + max(1, c)) for o, c in spans)
+            assert all(a % al == 0 for a, _ in spans)
+            assert all(e <= s2 for (_, e), (s2, _) in zip(spans[:-1], spans[1:])) and spans[-1][1] <= tot
+
+
+def test_native_plan_rejects_malformed_specs_and_sizes(lib):
+    sp, _ = _shipped_plan_spec()
+    off, tot = (ctypes.c_long * 13)(), (ctypes.c_long * 3)()
+    assert lib.cdseg_plan_begin_layout(ctypes.byref(sp), 0, 1, off, tot) == -1          # no points
+    sp.cum[2] = 1                                                                          # levels must strictly coarsen
+    assert lib.cdseg_plan_begin_layout(ctypes.byref(sp), 100, 1, off, tot) == -1
+    sp, _ = _shipped_plan_spec()
+    sp.nlink = 3                                                                           # (3, 4) missing: level 3's parent link
+    mh = (ctypes.c_long * 4)(50, 25, 12, 6)
+    oh = (ctypes.c_int * 10)(0, 100, 0, 50, 0, 25, 0, 12, 0, 6)
+    off_f, info = (ctypes.c_long * 64)(), (ctypes.c_long * 64)()
+    assert lib.cdseg_plan_finish_layout(ctypes.byref(sp), 100, 1, mh, oh, off_f, info) == -1
+    sp, _ = _shipped_plan_spec()
+    oh[3] = 49                                                                             # offsets disagree with the pooled size
+    assert lib.cdseg_plan_finish_layout(ctypes.byref(sp), 100, 1, mh, oh, off_f, info) == -1
