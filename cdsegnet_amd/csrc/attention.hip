@@ -70,6 +70,7 @@ struct AttnP {
   int nzones;
   int zcnt[ATTN_ZONES];
   int zsplit[ATTN_ZONES];
+  int full_patches;  // host only: the launch's longest patch has all 32 query tiles (zones are for those launches)
   int zfixed;    // sum of the fixed zone sizes
   int bulk_max;  // largest bulk zone over the XCDs (the grid's extent of that zone)
 };
@@ -931,6 +932,9 @@ static unsigned plan_zones(AttnP& p, int s0, int max_split, int lead, int tail1,
   const int s1 = 2 * s0 <= max_split ? 2 * s0 : 0, s2 = 4 * s0 <= max_split ? 4 * s0 : 0;
   auto units = [&](int blocks, int split) { return split && blocks > 0 ? (blocks + split - 1) / split : 0; };
   if (n_min < cdseg_knob("CDSEG_ATTN_ZONE_MIN", ATTN_ZONE_MIN_UNITS)) lead = tail1 = tail2 = 0;
+  // ... and only for full-length patches (32 query tiles): the 768-unit / 775-row launches of 24 collated scenes' deepest stage
+  // run 12 % SLOWER with their last units cut into slices of 6 - 13 tiles (profiles/r06_attention_zones24.txt)
+  if (max_split < cdseg_knob("CDSEG_ATTN_ZONE_MIN_SPLIT", 4) || !p.full_patches) lead = tail1 = tail2 = 0;
   int u_lead = units(lead, s1), u_head = u_lead ? units(32, s0) : 0;
   int u_t1 = units(tail1, s1), u_t2 = units(tail2, s2);
   // too few units per XCD for all the zones: drop the lead, then shrink the tails (at least a third stays bulk)
@@ -972,6 +976,7 @@ static unsigned make_schedule(AttnP& p, int num_patches, int num_heads, int max_
   const int max_split = (nqt + ATTN_RUN - 1) / ATTN_RUN;
   while (qsplit > 1 && qsplit > max_split) qsplit >>= 1;
   p.num_patches = num_patches;
+  p.full_patches = nqt * tile >= CDSEG_MAX_PATCH;
   for (int z = 0; z < ATTN_ZONES; ++z) p.zcnt[z] = p.zsplit[z] = 0;
   // (the fp32 parity kernel keeps the uniform schedule: one bulk zone)
   const bool graded = dtype == CDSEG_BF16;
