@@ -669,7 +669,7 @@ class Engine:
                            while_device_works):
         """build_plan through the native builder (csrc/plan.hip): two library calls around the one host read, every plan item
         a view into one of two arenas per call.  Same items, bit for bit, as the per-op path below
-        (tests/test_gpu_ops.py::test_native_plan_equals_per_op_plan)."""
+        (tests/test_gpu_e2e.py::test_native_plan_equals_per_op_plan)."""
         sp, used, curves, links = ent
         nb = len(offset_host) if offset_host is not None else int(offset_dev.numel())
         grid = grid.contiguous()

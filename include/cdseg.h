@@ -505,7 +505,7 @@ int cdseg_block_forward(const cdseg_block_desc* desc, const cdseg_block_io* io, 
  * The integer side of one forward - (batch | z) sort, level-0 codes, all pooled levels, links, 3x3x3 kernel maps, curve orders,
  * padding tables, slot plans - in TWO library calls around the forward's one host read (the pooled sizes), written into two
  * caller-owned arenas (int32 / int64 elements; every item starts on a 256-byte boundary).  Same kernels, same results as the
- * per-op entry points above (tests/test_gpu_ops.py::test_native_plan_equals_per_op_plan); exists because a single scene's
+ * per-op entry points above (tests/test_gpu_e2e.py::test_native_plan_equals_per_op_plan); exists because a single scene's
  * plan phase was bound by ~40 binding round trips, not by the device (csrc/plan.hip).
  * Level indices: 0 = the input resolution, 1 .. nlev the pooled levels in ascending cumulative pooling depth. */
 #define CDSEG_PLAN_MAX_LEVELS 8
