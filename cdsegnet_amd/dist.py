@@ -144,11 +144,17 @@ def gpu_pci_bus_ids(count):
     except OSError:
         return []
     out = []
-    for i in range(count):
+    visible = ctypes.c_int(0)
+    if hip.hipGetDeviceCount(ctypes.byref(visible)) != 0:
+        visible.value = 0
+    for i in range(min(int(count), visible.value)):  # (a rank may see fewer devices than the node has ranks: *_VISIBLE_DEVICES)
         buf = ctypes.create_string_buffer(64)
         if hip.hipDeviceGetPCIBusId(buf, 64, i) != 0:
             break
         out.append(buf.value.decode())
+    # a failed query leaves HIP's sticky last-error set ("invalid device ordinal"), which the next launch check of ANY library in
+    # the process (torch's included) would report as its own failure: clear it
+    hip.hipGetLastError()
     return out
 
 
@@ -162,7 +168,9 @@ def setup_rank_host(local_rank, local_world, max_threads=8, apply=True):
         return plan, None
     if plan["blocking_sync"] and torch.cuda.is_available():
         try:  # the flag belongs to the CURRENT device: select this rank's GPU first (no context yet)
-            ctypes.CDLL("libamdhip64.so").hipSetDevice(int(local_rank))
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipSetDevice(int(local_rank)) != 0:  # (a launcher that shows each rank only its own GPU: device 0 it is)
+                hip.hipGetLastError()  # clear the sticky error (see gpu_pci_bus_ids)
         except OSError:
             pass
     return plan, apply_rank_host_plan(plan)

@@ -25,9 +25,21 @@ def worker(rank, world, points, spf, forwards, barrier, q):
     # host reads BLOCK instead of spinning (hipDeviceScheduleBlockingSync, set before the first HIP call of the process):
     # with the default policy the thread burns CPU inside the forward's two device->host reads for as long as the
     # (time-shared) GPU makes it wait, and thread_time would measure the GPU's queue, not the host's work
-    hip = ctypes.CDLL("libamdhip64.so")
-    rc = hip.hipSetDeviceFlags(ctypes.c_uint(0x4))
-    assert rc == 0, f"hipSetDeviceFlags failed: {rc}"
+    if os.environ.get("CDSEG_HOST_PLAN"):
+        # the shipped per-rank host plan (dist.setup_rank_host, what bench.py applies for WORLD_SIZE > 1): CPU slice, thread cap
+        # and blocking sync in one call - on a one-GPU box every rank falls back to a slice of all allowed CPUs
+        from cdsegnet_amd import dist as cdist
+        # (plan only, then applied by hand: setup_rank_host(apply=True) would select GPU `rank`, and this box has one)
+        plan, _ = cdist.setup_rank_host(rank, world, apply=False)
+        plan["blocking_sync"] = True
+        applied = cdist.apply_rank_host_plan(plan)
+        assert applied["blocking_sync"], applied
+        if rank == 0:
+            print(f"# rank 0 of {world}: {applied}", flush=True)
+    else:
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipSetDeviceFlags(ctypes.c_uint(0x4))
+        assert rc == 0, f"hipSetDeviceFlags failed: {rc}"
     from cdsegnet_amd import configs, synth
     from cdsegnet_amd.models import collate_device
     from cdsegnet_amd.param_init import fill_state_dict
@@ -73,7 +85,7 @@ def run(world, points, spf, forwards):
     procs = [ctx.Process(target=worker, args=(r, world, points, spf, forwards, barrier, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join()
     return sorted(res, key=lambda r: r["rank"])
