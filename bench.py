@@ -466,6 +466,7 @@ def main():
     elapsed = time.perf_counter() - t0
     last = out[-1]["seg_logits"]
     assert torch.isfinite(last).all()
+    hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30  # (allocator high-water mark through warm-up + timed region)
     # rounds 1 - 5 timed 8 scenes per forward x 3 lanes (24 scenes per step); round 6 collates 24 per forward (the deep stages'
     # launches are three times as full, profiles/r06_lanes_sweep.txt).  The old setting on this step's first 24 scenes, right
     # after the timed region, so that the line stays comparable with the earlier rounds' `value`
@@ -684,7 +685,7 @@ def main():
                        "points_per_scene_mean": pts_per_step / scenes_per_step, "points_per_scene_min": min(sizes),
                        "points_per_scene_max": max(sizes), "precision": args.precision,
                        "scenes_per_step_per_gpu": scenes_per_step, "scenes_per_forward": args.scenes_per_forward,
-                       "forwards_in_flight_per_gpu": args.lanes, "noise": "device Philox",
+                       "forwards_in_flight_per_gpu": args.lanes, "hbm_peak_allocated_gb": round(hbm_peak_gb, 2), "noise": "device Philox",
                        "trunk_16bit_type": ("IEEE half (fp16)" if variant == "f16" else "bfloat16") if low else "none (fp32)",
                        "trunk_16bit_note": "BASELINE.json configs[1] names bf16; the default trunk is IEEE half - the same MFMA rate and "
                                            "bytes as bfloat16, 11 instead of 8 mantissa bits (arg-max agreement with the exact-fp32 path "
