@@ -1226,8 +1226,11 @@ constexpr int gemm_smem_bytes() {
 template <typename CT, int NCH, bool GATHER>
 int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
   constexpr int BK = NCH * (16 / (int)sizeof(CT));
-  static const int split_target = cdseg_knob("CDSEG_GEMM_SPLIT_TARGET", 512);
-  static const int split_max = cdseg_knob("CDSEG_GEMM_SPLIT_MAX", 32);
+  // split-K of few-tile problems (a single scene's deep stages): blocks the split aims for, and the most slices.  320 / 16 (round
+  // 6; 512 / 32 before): fewer, longer slices - less partial-sum traffic and a cheaper second pass - single scene 3.61 -> 3.52 ms,
+  // flat between 192 and 384 blocks / 8 and 16 slices (profiles/r06_splitk_sweep.txt)
+  static const int split_target = cdseg_knob("CDSEG_GEMM_SPLIT_TARGET", 320);
+  static const int split_max = cdseg_knob("CDSEG_GEMM_SPLIT_MAX", 16);
   static const int xmode_env = cdseg_knob("CDSEG_GEMM_XMODE", -1);
   const bool ln = p.ln_pre_g || p.ln_post_g;
   // sparse convs: 128-row tiles (8 waves): half the W re-reads per row through L2 -> LDS, the path every conv level is
