@@ -82,6 +82,31 @@ __device__ __forceinline__ void load_tile(const bf16_t* src, int ld, long m0, lo
   }
 }
 
+// The same tile from `splits` raw split-K partial planes (splits, n, C) fp32 of the conv that produced y: slice sum in slice order,
+// + bias, rounded with the conversion the conv's own second pass uses (gemm.hip splitk_epilogue_kernel / epilogue4 / store_vec4):
+// bit-identical rows, one launch fewer.
+template <int C, int BM>
+__device__ __forceinline__ void load_tile_partials(const float* part, int splits, const float* bias, long m0, long n, char* buf,
+                                                   int tid) {
+  constexpr int NCH = C / 8, NT = 2 * C, PT = BM * NCH / NT;
+  const long plane = n * (long)C;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int id = i * NT + tid, row = id / NCH, c = id % NCH;
+    long m = m0 + row;
+    if (m >= n) m = n - 1;
+    const float* q = part + m * C + c * 8;
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(q), b = *reinterpret_cast<const f32x4_t*>(q + 4);
+    for (int s = 1; s < splits; ++s) {
+      a = a + *reinterpret_cast<const f32x4_t*>(q + s * plane);
+      b = b + *reinterpret_cast<const f32x4_t*>(q + s * plane + 4);
+    }
+    a = a + *reinterpret_cast<const f32x4_t*>(bias + c * 8);
+    b = b + *reinterpret_cast<const f32x4_t*>(bias + c * 8 + 4);
+    *reinterpret_cast<uint4*>(buf + act_off<NCH>(row, c)) = pack8(a, b);
+  }
+}
+
 // acc[pt][f] (channels 8 g + 4 f + r of the wave's 32, point 16 pt + p) += W X^T over K = C: KS steps of 32, the two
 // weight fragments of a step from the ring, the next ring slot requested right after.  `step0`: position of the
 // product's first step in the wave's weight stream; requests past the end re-read the last step (no branch around a
@@ -200,6 +225,7 @@ struct DeepHeadP {
   long n; int ldy, ldx, ldxo, ldqkv; float eps;
   int v_bf16;  // IEEE-half build: write the v third as bfloat16 (CDSEG_ATTN_V_BF16)
   int nsplit;  // 1: a workgroup writes q, k and v of its tile; 3: workgroup (tile, c) writes column block c only (few-row launches)
+  const float* ypart; const float* ybias; int ysplits;  // ysplits > 1: y as raw split-K partial planes + bias (load_tile_partials)
 };
 
 template <int C, int BM>
@@ -228,7 +254,8 @@ __global__ __launch_bounds__(2 * C, 2) void deep_head_kernel(DeepHeadP P) {
     pr[4 * C + c] = P.ln1_g[c]; pr[5 * C + c] = P.ln1_b[c];
   }
   for (int c = tid; c < 3 * C; c += NT) pr[6 * C + c] = P.bqkv[c];
-  load_tile<C, BM>(P.y, P.ldy, m0, P.n, bufA, tid);
+  if (P.ysplits > 1) load_tile_partials<C, BM>(P.ypart, P.ysplits, P.ybias, m0, P.n, bufA, tid);
+  else load_tile<C, BM>(P.y, P.ldy, m0, P.n, bufA, tid);
   const int ch0 = 32 * wave + 8 * g;  // the lane's channels: ch0 + 4 f + r
   lds_barrier();  // tile + parameters visible
   DT_STAMP(1);
@@ -616,8 +643,10 @@ int deep_pack(int C, const void* wl, const void* wqkv, void* head_img, const voi
 
 int deep_head(const void* y, int ldy, const void* head_img, const float* bl, const float* lnp_g, const float* lnp_b,
               const float* x, int ldx, float* x_out, int ldxo, const float* colbias, const float* ln1_g, const float* ln1_b, float eps, const float* bqkv, void* qkv,
-              int ldqkv, long n, int channels, int qkv_flags, hipStream_t s) {
+              int ldqkv, long n, int channels, int qkv_flags, hipStream_t s, const float* ypart, int ysplits, const float* ybias) {
   DeepHeadP p;
+  p.ypart = ypart; p.ybias = ybias; p.ysplits = (ypart && ybias && ysplits > 1) ? ysplits : 1;
+  if (p.ysplits > 1 && ((((uintptr_t)ypart) | ((uintptr_t)ybias)) & 15)) return CDSEG_ERR_ARG;
   p.v_bf16 = (qkv_flags & CDSEG_ATTN_V_BF16) ? 1 : 0;
   p.y = (const bf16_t*)y; p.wimg = (const uint4*)head_img; p.bl = bl; p.lnp_g = lnp_g; p.lnp_b = lnp_b; p.x = x;
   p.x_out = x_out; p.ldxo = ldxo;

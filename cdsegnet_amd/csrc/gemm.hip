@@ -1212,6 +1212,11 @@ __global__ __launch_bounds__(SQ ? 512 : 4 * BM) void gemm_dma_kernel(GemmP g) {
 #endif
 }
 
+// gemm_leave_partials (bottom of the file): this thread's next split-K launch with a bias-only epilogue leaves its raw partial
+// tiles in the workspace instead of launching splitk_epilogue_kernel
+thread_local bool tl_leave_partials = false;
+thread_local int tl_partial_splits = 1;
+
 template <typename CT, int BN, int NCH, int BM>
 constexpr int gemm_smem_bytes() {
   constexpr int ab = (BM + BN) * NCH * 16, c = 64 * (BN + 4) * 4;
@@ -1492,6 +1497,12 @@ int launch_bn(GemmP p, size_t ws_bytes, hipStream_t s) {
     hipLaunchKernelGGL(row_finish_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
     if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
   } else if (p.fix == 1) {
+    // (gemm_leave_partials: the consumer - the deep Block head - sums the slices and adds the bias itself, in this order)
+    if (tl_leave_partials && p.vec_ok && p.bias && !p.scale && p.act == CDSEG_ACT_NONE && !p.res && !p.add_src && !p.out2 &&
+        !p.out_idx && !p.colbias) {
+      tl_partial_splits = p.splits;
+      return CDSEG_OK;
+    }
     const long groups = p.M * (long)(p.N >> 2);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
     if (hipGetLastError() != hipSuccess) return CDSEG_ERR_LAUNCH;
@@ -1575,5 +1586,19 @@ extern "C" int cdseg_gemm(const cdseg_gemm_args* a, void* stream) {
   else if (a->compute_dtype == CDSEG_F32) rc = a->nbr ? launch<float, true>(p, wsb, s) : launch<float, false>(p, wsb, s);
   else if (a->compute_dtype == CDSEG_F32X3) rc = a->nbr ? launch<F32X3, true>(p, wsb, s) : launch<F32X3, false>(p, wsb, s);
   if (prof) cdseg_prof_end(tok, s);
+  return rc;
+}
+
+// Internal (deep.h; csrc/runtime.hip): cdseg_gemm, except that a split-K launch whose epilogue is a bias add only does NOT run its
+// second pass - *splits (> 1) raw partial planes (splits, M, N) fp32 stay in a->ws for the consumer, which sums them in slice
+// order and adds the bias (what splitk_epilogue_kernel + epilogue4 do, bit for bit: csrc/deep.hip load_tile_partials).  *splits
+// = 1: the launch did not split (or its epilogue is more than a bias) and a->out holds the result as usual.  Saves a launch per
+// sparse conv of a few-row deep stage (a single scene: 14 of 242).
+int gemm_leave_partials(const cdseg_gemm_args* a, int* splits, void* stream) {
+  tl_leave_partials = true;
+  tl_partial_splits = 1;
+  const int rc = cdseg_gemm(a, stream);
+  tl_leave_partials = false;
+  *splits = tl_partial_splits;
   return rc;
 }

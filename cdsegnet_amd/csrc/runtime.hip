@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "deep.h"
 
 namespace {
 
@@ -125,6 +126,12 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
   // (the weight-stationary kernel addresses its buffers with 32-bit offsets: inputs past those limits - 16.7 M rows at
   // C = 64 - take the gathered GEMM below, which handled them before that kernel existed)
   const bool conv_fits = n * 27 * 4 < (1l << 31) && n * (long)C * 2 < (1l << 31) - 65536;
+  // (the Block head that follows is deep.hip's - decided below with the same conditions -: it can take the conv's output as raw
+  // split-K slices)
+  const bool deep_head_next = cdseg_knob("CDSEG_DEEP_FUSED", 1) != 0 && T == CDSEG_BF16 && (C == 128 || C == 256) &&
+                              d->hidden == 4 * C && d->head_img;
+  int ysplits = 1;
+  const float* ypart = nullptr;
   if (d->cpe_conv_wimg && T == CDSEG_BF16 && (C == 32 || C == 64) && conv_fits) {
     // wide stages: weight-stationary register-gather conv (conv.hip)
     rc = cdseg_subm_conv3(io->xc_in, C, d->cpe_conv_wimg, (const float*)d->cpe_conv_b, io->nbr, n, C, L.y, C, stream);
@@ -133,7 +140,17 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
     cdseg_gemm_args a = base_args(d, L, n);
     a.A = io->xc_in; a.lda = C; a.W = d->cpe_conv_w; a.bias = d->cpe_conv_b; a.nbr = io->nbr; a.nbr_kmajor = 1; a.kvol = 27;
     a.N = C; a.K = C; a.out = L.y; a.ldo = C; a.out_dtype = T;
-    if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) return rc;
+    // few-row deep stages (a single scene): the conv runs split-K, and its second pass - sum the slices, add the bias, round -
+    // is what the deep Block head's tile load can do on its way into LDS: the raw slices stay in the workspace, one launch and
+    // one round trip of y fewer per Block (round 6; C = 128 / 256 - at C = 512 three workgroups per tile would each re-read
+    // ~0.8 MB of slices; not with the saturation diagnostic, which reads y)
+    static const bool partials_on = cdseg_knob("CDSEG_CONV_PARTIALS", 1) != 0;
+    if (partials_on && deep_head_next && (C == 128 || C == 256) && !io->sat_counter && a.ws && a.bias) {
+      if ((rc = gemm_leave_partials(&a, &ysplits, stream)) != CDSEG_OK) return rc;
+      if (ysplits > 1) ypart = (const float*)a.ws;
+    } else if ((rc = cdseg_gemm(&a, stream)) != CDSEG_OK) {
+      return rc;
+    }
   }
   static const bool fused_head = cdseg_knob("CDSEG_FUSED_HEAD", 1) != 0;
   // deep stages (C = 128 / 256) with weight-stream images: head and tail are one launch each (deep.hip)
@@ -148,7 +165,15 @@ static int block_forward_impl(const cdseg_block_desc* d, const cdseg_block_io* i
                     (C == 128 || C == 256 || (C == 512 && (n >= deep512_min || (deep512_split && L.xs)))) && d->hidden == 4 * C;
   const bool head = (fused_head && T == CDSEG_BF16 && (C == 32 || C == 64)) || (deep && d->head_img);
   const bool pingpong = deep && d->head_img && d->tail_img && L.xs;
-  if (pingpong) {
+  if (ypart) {  // (deep_head_next held: the head below is deep.hip's; x -> xs when the ping-pong buffer exists, else in place)
+    float* xo = pingpong ? (float*)L.xs : (float*)io->x;
+    if ((rc = deep_head(L.y, C, d->head_img, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g, (const float*)d->cpe_ln_b,
+                        (const float*)io->x, C, xo, C, (const float*)io->tbias, (const float*)d->norm1_g,
+                        (const float*)d->norm1_b, d->ln_eps, (const float*)d->qkv_b, L.qkv, 3 * C, n, C, CDSEG_ATTN_V_BF16,
+                        (hipStream_t)stream, ypart, ysplits, (const float*)d->cpe_conv_b)) != CDSEG_OK)
+      return rc;
+    attn_flags |= CDSEG_ATTN_V_BF16;
+  } else if (pingpong) {
     if ((rc = cdseg_cpe_head_rr2(L.y, C, d->head_img, (const float*)d->cpe_lin_b, (const float*)d->cpe_ln_g,
                                  (const float*)d->cpe_ln_b, (const float*)io->x, C, (float*)L.xs, C, (const float*)io->tbias,
                                  (const float*)d->norm1_g, (const float*)d->norm1_b, d->ln_eps, (const float*)d->qkv_b, L.qkv,
